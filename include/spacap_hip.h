@@ -1,0 +1,151 @@
+/*
+ * spacap_hip.h -- C ABI of libspacap_hip.so, the MI355X (gfx950) implementation of the
+ * SpaCap3D hot path.
+ *
+ * Boundary B1 replaces the nine functions the reference registers in its pybind module
+ * `pointnet2._ext` (lib/pointnet2/_ext_src/src/bindings.cpp:6-19).  Boundary B2 replaces the
+ * Python function `attention()` (models/transformer_captioner.py:27-37) and the relation feature
+ * built from its outputs (models/transformer_captioner.py:392-397).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer (hipMalloc'd / torch CUDA
+ *    tensor storage) unless it is named host_*; tensors are dense row-major in the stated shape
+ *    unless explicit strides are passed;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); kernels are enqueued,
+ *    never synchronised (the reference enqueues on the current stream the same way,
+ *    include/cuda_utils.h + at::cuda::getCurrentCUDAStream());
+ *  - every entry point returns 0 on success and a negative SPACAP_E_* code otherwise (the
+ *    reference prints and exit(-1)s on a launch failure, include/cuda_utils.h:30-39; a library
+ *    must not), `spacap_last_error()` returns a thread-local message for the last failure;
+ *  - no entry point allocates, frees or synchronises: all scratch is caller-provided
+ *    (`*_workspace_bytes`), so every call is hipGraph-capturable;
+ *  - outputs that the reference creates with torch::zeros and then scatters into
+ *    (`*_grad`) are zero-filled by the entry point itself (a memset node on `stream`).
+ */
+#ifndef SPACAP_HIP_H
+#define SPACAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPACAP_ABI_VERSION 1
+
+#define SPACAP_OK 0
+#define SPACAP_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
+#define SPACAP_E_LAUNCH (-2)    /* hipGetLastError() after a launch / memset                    */
+#define SPACAP_E_NO_DEVICE (-3) /* no HIP device visible                                         */
+
+typedef void *spacap_stream_t; /* hipStream_t */
+
+int spacap_abi_version(void);
+const char *spacap_last_error(void);
+/* number of HIP devices visible, or a negative SPACAP_E_* (used by the host shim to fail loudly) */
+int spacap_device_count(void);
+
+/* The reference's launch helper, restated for the host side: clamp(2^floor(log2 w), 1, 512)
+ * computed through the same double-precision log quotient (include/cuda_utils.h:15-19).  The FPS
+ * arg-max tie-break depends on it. */
+int spacap_opt_n_threads(int work_size);
+
+/* ---- sampling (replaces src/sampling.cpp) -------------------------------------------------- */
+
+/* furthest_point_sampling(points f32[B,N,3], nsamples) -> i32[B,m]   (src/sampling.cpp:66-87,
+ * kernel src/sampling_gpu.cu:69-173).  Bit-exact indices, including the reference's block-tree
+ * tie-break and its |p|^2 <= 1e-3 skip.  `workspace` replaces the reference's `tmp` tensor
+ * (B*N floats filled with 1e10): size it with spacap_fps_workspace_bytes; contents need no
+ * initialisation. */
+size_t spacap_fps_workspace_bytes(int B, int N);
+int spacap_fps_f32(const float *xyz, int B, int N, int m, void *workspace, int32_t *idx,
+                   spacap_stream_t stream);
+
+/* gather_points(points f32[B,C,N], idx i32[B,m]) -> f32[B,C,m]   (src/sampling.cpp:15-38) */
+int spacap_gather_points_f32(const float *points, const int32_t *idx, int B, int C, int N, int m,
+                             float *out, spacap_stream_t stream);
+/* gather_points_grad(grad_out f32[B,C,m], idx, n) -> f32[B,C,n]   (src/sampling.cpp:40-65);
+ * grad_points is zero-filled here, then scatter-added. */
+int spacap_gather_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N,
+                                  int m, float *grad_points, spacap_stream_t stream);
+
+/* ---- ball query (replaces src/ball_query.cpp) ----------------------------------------------- */
+
+/* ball_query(new_xyz f32[B,m,3], xyz f32[B,N,3], radius, nsample) -> i32[B,m,nsample]
+ * (src/ball_query.cpp:8-32, kernel src/ball_query_gpu.cu:9-44): first `nsample` points in index
+ * order with d2 < radius*radius, padded with the first hit, all-zero rows when there is none.
+ * Every element of idx is written. */
+int spacap_ball_query_f32(const float *new_xyz, const float *xyz, int B, int N, int m,
+                          float radius, int nsample, int32_t *idx, spacap_stream_t stream);
+
+/* ---- grouping (replaces src/group_points.cpp) ------------------------------------------------ */
+
+/* group_points(points f32[B,C,N], idx i32[B,P,S]) -> f32[B,C,P,S]   (src/group_points.cpp:12-36) */
+int spacap_group_points_f32(const float *points, const int32_t *idx, int B, int C, int N, int P,
+                            int S, float *out, spacap_stream_t stream);
+/* group_points_grad(grad_out f32[B,C,P,S], idx, n) -> f32[B,C,n]   (src/group_points.cpp:38-62);
+ * grad_points is zero-filled here, then scatter-added. */
+int spacap_group_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N,
+                                 int P, int S, float *grad_points, spacap_stream_t stream);
+
+/* ---- interpolation (replaces src/interpolate.cpp) -------------------------------------------- */
+
+/* three_nn(unknown f32[B,n,3], known f32[B,m,3]) -> dist2 f32[B,n,3], idx i32[B,n,3]
+ * (src/interpolate.cpp:14-40).  dist2 is SQUARED distance as in the reference. */
+int spacap_three_nn_f32(const float *unknown, const float *known, int B, int n, int m,
+                        float *dist2, int32_t *idx, spacap_stream_t stream);
+/* three_interpolate(points f32[B,C,m], idx i32[B,n,3], weight f32[B,n,3]) -> f32[B,C,n]
+ * (src/interpolate.cpp:42-70) */
+int spacap_three_interpolate_f32(const float *points, const int32_t *idx, const float *weight,
+                                 int B, int C, int m, int n, float *out, spacap_stream_t stream);
+/* three_interpolate_grad(grad_out f32[B,C,n], idx, weight, m) -> f32[B,C,m]
+ * (src/interpolate.cpp:71-99); grad_points is zero-filled here, then scatter-added. */
+int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
+                                      const float *weight, int B, int C, int n, int m,
+                                      float *grad_points, spacap_stream_t stream);
+
+/* ---- attention (replaces models/transformer_captioner.py:27-37) ------------------------------ */
+
+/* One fused launch for  S = Q K^T * scale (+bias);  S[mask==0] = -1e9;  P = softmax(S);
+ * P = dropout(P);  O = P V.   d_k must be 16, 32 or 64; Lk <= 512.
+ *
+ *  q,k,v   f32, logical shape [B,h,L,d_k], last dim contiguous, element strides (sb, sh, sl)
+ *          (the reference passes transposed views of [B,L,h*d_k] projections,
+ *           models/transformer_captioner.py:59-60)
+ *  mask    uint8 or NULL, logical [B,Lq,Lk] with element strides (mask_sb, mask_sq), mask_sq = 0
+ *          broadcasts one key mask over the queries (encoder), keys contiguous; 0 = masked
+ *  bias    f32 or NULL, logical [B,h,Lq,Lk] added to the scaled logits before masking, element
+ *          strides (bias_sb, bias_sh, bias_sq), keys contiguous.  The reference adds no bias
+ *          (SURVEY.md fact 1); the argument exists for the spatial-relation bias of north_star.
+ *  dropout_p in [0,1): keep-probability 1-p, kept entries scaled by 1/(1-p); the mask is a
+ *          counter hash of (seed, b, h, q, k) so backward regenerates it.
+ *  out     f32 [B,Lq,h,d_k] dense (i.e. already in the layout of `x.transpose(1,2).contiguous()`,
+ *          models/transformer_captioner.py:68)
+ *  p_out   f32 [B,h,Lq,Lk] dense or NULL: the post-dropout attention matrix the reference returns
+ *          as `p_attn` and stores as `self.attn` (models/transformer_captioner.py:63)
+ *  lse     f32 [B,h,Lq] dense: log-sum-exp of the masked logits, consumed by backward. */
+int spacap_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
+                       long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
+                       const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
+                       long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
+                       int d_k, float scale, float dropout_p, uint64_t seed, float *out,
+                       float *p_out, float *lse, spacap_stream_t stream);
+
+/* Backward of the above.  d_out f32 [B,Lq,h,d_k] dense; d_p f32 [B,h,Lq,Lk] dense or NULL is the
+ * gradient w.r.t. the returned post-dropout p_attn (non-NULL for the encoder layer that feeds
+ * the relation head, models/transformer_captioner.py:392-394).  Outputs dq,dk,dv f32
+ * [B,L,h,d_k] dense (the layout of the projections before `.transpose(1,2)`); dk and dv are
+ * zero-filled here and accumulated. */
+int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
+                       long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
+                       const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
+                       long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
+                       int d_k, float scale, float dropout_p, uint64_t seed, const float *lse,
+                       const float *d_out, const float *d_p, float *dq, float *dk, float *dv,
+                       spacap_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPACAP_HIP_H */

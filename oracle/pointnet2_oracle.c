@@ -1,0 +1,319 @@
+/*
+ * oracle/pointnet2_oracle.c  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Single-threaded CPU restatement of the nine native operators of the
+ * reference's `pointnet2._ext` module (lib/pointnet2/_ext_src).  The reference
+ * ships those operators as CUDA only (every host wrapper ends in
+ * AT_ASSERT(false, "CPU not supported"): src/sampling.cpp:33-35,60-62,82-84,
+ * src/ball_query.cpp:27-29, src/group_points.cpp:31-33,57-59,
+ * src/interpolate.cpp:35-37,65-67,94-96), so it cannot be built or run in a
+ * container without nvcc / an NVIDIA GPU.  This file restates the algorithm of
+ * each kernel from its source, in un-contracted IEEE fp32, evaluated left to
+ * right exactly as the .cu sources write it (compile with -ffp-contract=off,
+ * no -ffast-math).
+ *
+ * PARITY STATUS: "parity unpinned" for furthest_point_sampling, ball_query,
+ * group_points, gather_points and three_nn -- the reference holds no golden
+ * vector or known-answer test for them.  The only
+ * reference test on this path, lib/pointnet2/pointnet2_test.py:14-26
+ * (three_interpolate with fixed idx / weight), is reproduced as a
+ * known-answer test in tests/test_oracle.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product path (spacap3d_amd/) never does.
+ *
+ * Every function cites the reference file:line it follows.  Nothing here is
+ * copied: the reference is a CUDA grid/block program, this is a scalar loop
+ * nest that reproduces its observable results (including the block-tree
+ * tie-break of the FPS arg-max).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_TOTAL_THREADS 512 /* include/cuda_utils.h:13 */
+
+/* include/cuda_utils.h:15-19: pow_2 = (int)(log(work)/log(2)); clamp(1<<pow_2, 1, 512).
+ * The double-precision quotient is restated literally because its truncation
+ * decides the FPS block size and with it the arg-max tie-break. */
+int oracle_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(log((double)work_size) / log(2.0));
+  int t = 1 << pow_2;
+  if (t > ORACLE_TOTAL_THREADS) t = ORACLE_TOTAL_THREADS;
+  if (t < 1) t = 1;
+  return t;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------ *
+ * furthest_point_sampling
+ *   host:   src/sampling.cpp:66-87   (temp filled with 1e10, idx zeros)
+ *   kernel: src/sampling_gpu.cu:69-173
+ * One CUDA block of `bs = opt_n_threads(n)` threads per scene.  Thread t owns
+ * points t, t+bs, t+2bs, ...; per round it keeps (best, besti) with strict
+ * `>` starting from (-1, 0) (:94-95,108-109); points with |p|^2 <= 1e-3
+ * (double comparison, the literal is a double) are skipped and their temp is
+ * never touched (:100-101).  The block arg-max is a shared-memory tree in
+ * which the LOWER slot wins ties at every level (__update, :59-65).
+ * ------------------------------------------------------------------------ */
+static void fps_one_scene(int n, int m, const float *dataset, float *temp,
+                          int *idxs, float *dists, int *dists_i) {
+  if (m <= 0) return; /* :73 */
+  const int bs = oracle_opt_n_threads(n);
+  int old = 0;
+  idxs[0] = old; /* :88 */
+  for (int j = 1; j < m; j++) {
+    for (int t = 0; t < bs; ++t) { /* :94-95 */
+      dists[t] = -1.0f;
+      dists_i[t] = 0;
+    }
+    const float x1 = dataset[old * 3 + 0];
+    const float y1 = dataset[old * 3 + 1];
+    const float z1 = dataset[old * 3 + 2];
+    /* Walking k upwards visits every thread's points in that thread's own
+     * order (k = t, t+bs, ...), so the per-thread strict-> scan is unchanged. */
+    for (int k = 0; k < n; ++k) {
+      const int t = k % bs;
+      const float x2 = dataset[k * 3 + 0];
+      const float y2 = dataset[k * 3 + 1];
+      const float z2 = dataset[k * 3 + 2];
+      const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2); /* :100 */
+      if ((double)mag <= 1e-3) continue;                   /* :101 */
+      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
+                      (z2 - z1) * (z2 - z1); /* :103-104 */
+      const float d2 = fminf(d, temp[k]);    /* :106 */
+      temp[k] = d2;
+      if (d2 > dists[t]) { /* :108-109 */
+        dists_i[t] = k;
+        dists[t] = d2;
+      }
+    }
+    /* :115-168 -- tree reduction, stride bs/2 ... 1, lower slot wins ties */
+    for (int s = bs / 2; s >= 1; s >>= 1) {
+      for (int t = 0; t < s; ++t) {
+        const float v1 = dists[t], v2 = dists[t + s];
+        const int i1 = dists_i[t], i2 = dists_i[t + s];
+        dists[t] = v1 > v2 ? v1 : v2; /* max(v1, v2), :62 */
+        if (v2 > v1) dists_i[t] = i2; /* :63 */
+        else dists_i[t] = i1;
+      }
+    }
+    old = dists_i[0]; /* :170 */
+    idxs[j] = old;
+  }
+}
+
+/* temp is caller-provided scratch (b*n floats), (re)filled with 1e10 here as
+ * src/sampling.cpp:74-76 does. */
+void oracle_furthest_point_sampling(int b, int n, int m, const float *xyz,
+                                    float *temp, int *idxs) {
+  for (long i = 0; i < (long)b * n; ++i) temp[i] = 1e10f;
+  for (long i = 0; i < (long)b * m; ++i) idxs[i] = 0;
+#pragma omp parallel
+  {
+    float *dists = (float *)malloc(sizeof(float) * ORACLE_TOTAL_THREADS);
+    int *dists_i = (int *)malloc(sizeof(int) * ORACLE_TOTAL_THREADS);
+#pragma omp for schedule(dynamic, 1)
+    for (int bi = 0; bi < b; ++bi) {
+      fps_one_scene(n, m, xyz + (long)bi * n * 3, temp + (long)bi * n,
+                    idxs + (long)bi * m, dists, dists_i);
+    }
+    free(dists);
+    free(dists_i);
+  }
+}
+
+/* ------------------------------------------------------------------------ *
+ * gather_points: src/sampling.cpp:15-38, src/sampling_gpu.cu:8-20
+ *   out[b,c,j] = points[b,c,idx[b,j]]
+ * ------------------------------------------------------------------------ */
+void oracle_gather_points(int b, int c, int n, int m, const float *points,
+                          const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        const int a = idx[(long)i * m + j];
+        out[((long)i * c + l) * m + j] = points[((long)i * c + l) * n + a];
+      }
+}
+
+/* gather_points_grad: src/sampling.cpp:40-65, src/sampling_gpu.cu:34-47.
+ * The reference scatters with atomicAdd (:42) in an unspecified order; the
+ * oracle fixes the order to ascending j, which is one of the admissible
+ * orders.  Output is zero-initialised as sampling.cpp:52-54. */
+void oracle_gather_points_grad(int b, int c, int n, int m,
+                               const float *grad_out, const int *idx,
+                               float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * n);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int i = 0; i < b; ++i)
+    for (int l = 0; l < c; ++l)
+      for (int j = 0; j < m; ++j) {
+        const int a = idx[(long)i * m + j];
+        grad_points[((long)i * c + l) * n + a] +=
+            grad_out[((long)i * c + l) * m + j];
+      }
+}
+
+/* ------------------------------------------------------------------------ *
+ * ball_query: src/ball_query.cpp:8-32 (idx zeros, :19-21),
+ *             src/ball_query_gpu.cu:9-44
+ * Per centre j: scan k = 0..n-1 in index order while cnt < nsample (:27);
+ * d2 = (cx-x)^2 + (cy-y)^2 + (cz-z)^2 left to right (:31-32); hit iff
+ * d2 < radius*radius in fp32 (:22,:33); the first hit fills every slot
+ * (:34-38); rows without a hit stay all zero.
+ * ------------------------------------------------------------------------ */
+void oracle_ball_query(int b, int n, int m, float radius, int nsample,
+                       const float *new_xyz, const float *xyz, int *idx) {
+  memset(idx, 0, sizeof(int) * (size_t)b * m * nsample);
+  const float radius2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(dynamic, 64)
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < m; ++j) {
+      const float *pts = xyz + (long)bi * n * 3;
+      const float *ctr = new_xyz + ((long)bi * m + j) * 3;
+      int *row = idx + ((long)bi * m + j) * nsample;
+      const float new_x = ctr[0], new_y = ctr[1], new_z = ctr[2];
+      for (int k = 0, cnt = 0; k < n && cnt < nsample; ++k) {
+        const float x = pts[k * 3 + 0];
+        const float y = pts[k * 3 + 1];
+        const float z = pts[k * 3 + 2];
+        const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
+                         (new_z - z) * (new_z - z);
+        if (d2 < radius2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) row[l] = k;
+          row[cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * group_points: src/group_points.cpp:12-36, src/group_points_gpu.cu:8-28
+ *   out[b,c,j,k] = points[b,c,idx[b,j,k]]
+ * ------------------------------------------------------------------------ */
+void oracle_group_points(int b, int c, int n, int npoints, int nsample,
+                         const float *points, const int *idx, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      const float *p = points + ((long)bi * c + l) * n;
+      const int *id = idx + (long)bi * npoints * nsample;
+      float *o = out + ((long)bi * c + l) * npoints * nsample;
+      for (long e = 0; e < (long)npoints * nsample; ++e) o[e] = p[id[e]];
+    }
+}
+
+/* group_points_grad: src/group_points.cpp:38-62, src/group_points_gpu.cu:43-64
+ * (atomicAdd :60; oracle order: ascending (j,k)). */
+void oracle_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                              const float *grad_out, const int *idx,
+                              float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * n);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      float *g = grad_points + ((long)bi * c + l) * n;
+      const int *id = idx + (long)bi * npoints * nsample;
+      const float *go = grad_out + ((long)bi * c + l) * npoints * nsample;
+      for (long e = 0; e < (long)npoints * nsample; ++e) g[id[e]] += go[e];
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * three_nn: src/interpolate.cpp:14-40, src/interpolate_gpu.cu:9-59
+ * bests are doubles initialised to 1e40 and compared against the fp32 d
+ * (:27,:34-49); strict `<` cascade, so the earlier index wins ties; outputs
+ * are the bests converted back to fp32 (1e40 -> +inf when m < 3) and are
+ * SQUARED distances (pointnet2_utils.py:142 applies the sqrt).
+ * ------------------------------------------------------------------------ */
+static float dbl_to_f32(double v) { return v > (double)FLT_MAX ? INFINITY : (float)v; }
+
+void oracle_three_nn(int b, int n, int m, const float *unknown,
+                     const float *known, float *dist2, int *idx) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int j = 0; j < n; ++j) {
+      const float *u = unknown + ((long)bi * n + j) * 3;
+      const float *kn = known + (long)bi * m * 3;
+      const float ux = u[0], uy = u[1], uz = u[2];
+      double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+      int besti1 = 0, besti2 = 0, besti3 = 0;
+      for (int k = 0; k < m; ++k) {
+        const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
+        const float d =
+            (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        if ((double)d < best1) {
+          best3 = best2; besti3 = besti2;
+          best2 = best1; besti2 = besti1;
+          best1 = d;     besti1 = k;
+        } else if ((double)d < best2) {
+          best3 = best2; besti3 = besti2;
+          best2 = d;     besti2 = k;
+        } else if ((double)d < best3) {
+          best3 = d;     besti3 = k;
+        }
+      }
+      float *dd = dist2 + ((long)bi * n + j) * 3;
+      int *ii = idx + ((long)bi * n + j) * 3;
+      dd[0] = dbl_to_f32(best1); dd[1] = dbl_to_f32(best2); dd[2] = dbl_to_f32(best3);
+      ii[0] = besti1; ii[1] = besti2; ii[2] = besti3;
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * three_interpolate: src/interpolate.cpp:42-70, src/interpolate_gpu.cu:72-101
+ *   out[b,c,j] = p[i1]*w1 + p[i2]*w2 + p[i3]*w3   (left to right, :98-99)
+ * ------------------------------------------------------------------------ */
+void oracle_three_interpolate(int b, int c, int m, int n, const float *points,
+                              const int *idx, const float *weight, float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      const float *p = points + ((long)bi * c + l) * m;
+      const int *id = idx + (long)bi * n * 3;
+      const float *w = weight + (long)bi * n * 3;
+      float *o = out + ((long)bi * c + l) * n;
+      for (int j = 0; j < n; ++j)
+        o[j] = p[id[j * 3 + 0]] * w[j * 3 + 0] + p[id[j * 3 + 1]] * w[j * 3 + 1] +
+               p[id[j * 3 + 2]] * w[j * 3 + 2];
+    }
+}
+
+/* three_interpolate_grad: src/interpolate.cpp:71-99,
+ * src/interpolate_gpu.cu:116-143 (three atomicAdds :139-141; oracle order:
+ * ascending j, slots 1,2,3). */
+void oracle_three_interpolate_grad(int b, int c, int n, int m,
+                                   const float *grad_out, const int *idx,
+                                   const float *weight, float *grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * c * m);
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int bi = 0; bi < b; ++bi)
+    for (int l = 0; l < c; ++l) {
+      float *g = grad_points + ((long)bi * c + l) * m;
+      const int *id = idx + (long)bi * n * 3;
+      const float *w = weight + (long)bi * n * 3;
+      const float *go = grad_out + ((long)bi * c + l) * n;
+      for (int j = 0; j < n; ++j) {
+        g[id[j * 3 + 0]] += go[j] * w[j * 3 + 0];
+        g[id[j * 3 + 1]] += go[j] * w[j * 3 + 1];
+        g[id[j * 3 + 2]] += go[j] * w[j * 3 + 2];
+      }
+    }
+}

@@ -1,0 +1,66 @@
+"""ctypes binding of ``libspacap_hip.so`` (C ABI: ``include/spacap_hip.h``).
+
+The library is built in-tree by ``spacap3d_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no fallback: if the shared object is missing or a symbol does not resolve, importing
+this module raises, and every operator raises ``RuntimeError`` on a non-zero return code.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspacap_hip.so")
+ABI_VERSION = 1
+
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+_p = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); one row per declaration in include/spacap_hip.h
+SIGNATURES = {
+    "spacap_abi_version": (_i, []),
+    "spacap_last_error": (ctypes.c_char_p, []),
+    "spacap_device_count": (_i, []),
+    "spacap_opt_n_threads": (_i, [_i]),
+    "spacap_fps_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
+    "spacap_fps_f32": (_i, [_p, _i, _i, _i, _p, _p, _p]),
+    "spacap_gather_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p]),
+    "spacap_group_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "spacap_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "spacap_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "spacap_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_mha_fwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
+                           + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p]),
+    "spacap_mha_bwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
+                           + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p, _p, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C spacap3d_amd/csrc`). "
+            "spacap3d_amd has no CPU or PyTorch fallback for its native operators.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.spacap_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libspacap_hip.so ABI {got} != expected {ABI_VERSION}: rebuild the extension")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.spacap_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

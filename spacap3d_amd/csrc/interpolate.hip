@@ -1,0 +1,144 @@
+// three_nn / three_interpolate (+grad) for gfx950 (MI355X).
+//
+// Replaces lib/pointnet2/_ext_src/src/interpolate_gpu.cu:9-154 (host: src/interpolate.cpp:14-99).
+//  * three_nn: indices bit-exact -- sequential scan over the known points in index order with the
+//    reference's strict `<` cascade (interpolate_gpu.cu:34-49), un-contracted fp32 distance (:32).
+//    The reference holds its bests in doubles initialised to 1e40 but only ever compares them with,
+//    and assigns them from, fp32 values; fp32 bests initialised to +inf take the same branches and
+//    convert to the same outputs (1e40 -> +inf in fp32).
+//  * three_interpolate: p[i1]*w1 + p[i2]*w2 + p[i3]*w3, left to right, un-contracted (:98-99).
+//  * three_interpolate_grad: three float atomic adds per element (:139-141).
+//
+// Design: one lane per unknown point with the known point of each step held in SGPRs (its index is
+// wave-uniform, so the loads are scalar and broadcast for free); 64-thread workgroups so that the
+// (B, n/64) grid spreads over the chip.  Interpolation uses lane = unknown index (coalesced weight /
+// index / output traffic) and a channel slab per workgroup.
+#include <math.h>
+
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__global__ __launch_bounds__(64) void three_nn_kernel(const float *__restrict__ unknown_all,
+                                                      const float *__restrict__ known_all, int n, int m,
+                                                      float *__restrict__ dist2_all,
+                                                      int32_t *__restrict__ idx_all) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  const float *__restrict__ known = known_all + (size_t)b * m * 3;
+  const int jj = j < n ? j : n - 1;
+  const float *__restrict__ u = unknown_all + ((size_t)b * n + jj) * 3;
+  const float ux = u[0], uy = u[1], uz = u[2];
+  float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k = 0; k < m; ++k) {
+    const float x = known[k * 3 + 0], y = known[k * 3 + 1], z = known[k * 3 + 2];
+    const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+    if (d < best1) {
+      best3 = best2; besti3 = besti2;
+      best2 = best1; besti2 = besti1;
+      best1 = d;     besti1 = k;
+    } else if (d < best2) {
+      best3 = best2; besti3 = besti2;
+      best2 = d;     besti2 = k;
+    } else if (d < best3) {
+      best3 = d;     besti3 = k;
+    }
+  }
+  if (j < n) {
+    float *__restrict__ dd = dist2_all + ((size_t)b * n + j) * 3;
+    int32_t *__restrict__ ii = idx_all + ((size_t)b * n + j) * 3;
+    dd[0] = best1; dd[1] = best2; dd[2] = best3;
+    ii[0] = besti1; ii[1] = besti2; ii[2] = besti3;
+  }
+}
+
+constexpr int CHUNK = 8;
+
+__global__ __launch_bounds__(256) void three_interpolate_kernel(const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ weight, int C,
+                                                                int m, int n, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const size_t r = ((size_t)b * n + j) * 3;
+  const float w1 = weight[r + 0], w2 = weight[r + 1], w3 = weight[r + 2];
+  const int i1 = idx[r + 0], i2 = idx[r + 1], i3 = idx[r + 2];
+  const int c0 = blockIdx.y * CHUNK, c1 = min(c0 + CHUNK, C);
+  const float *__restrict__ p = points + ((size_t)b * C + c0) * m;
+  float *__restrict__ o = out + ((size_t)b * C + c0) * n + j;
+  for (int c = c0; c < c1; ++c, p += m, o += n) *o = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(const float *__restrict__ grad_out,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     int C, int n, int m,
+                                                                     float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const size_t r = ((size_t)b * n + j) * 3;
+  const float w1 = weight[r + 0], w2 = weight[r + 1], w3 = weight[r + 2];
+  const int i1 = idx[r + 0], i2 = idx[r + 1], i3 = idx[r + 2];
+  const int c0 = blockIdx.y * CHUNK, c1 = min(c0 + CHUNK, C);
+  float *__restrict__ g = grad_points + ((size_t)b * C + c0) * m;
+  const float *__restrict__ go = grad_out + ((size_t)b * C + c0) * n + j;
+  for (int c = c0; c < c1; ++c, g += m, go += n) {
+    const float v = *go;
+    atomicAdd(g + i1, v * w1);
+    atomicAdd(g + i2, v * w2);
+    atomicAdd(g + i3, v * w3);
+  }
+}
+
+}  // namespace
+
+extern "C" int spacap_three_nn_f32(const float *unknown, const float *known, int B, int n, int m,
+                                   float *dist2, int32_t *idx, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && n >= 0 && m >= 0, "spacap_three_nn_f32: bad sizes");
+  if (B == 0 || n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(unknown && dist2 && idx && (known || m == 0), "spacap_three_nn_f32: null pointer");
+  SPACAP_REQUIRE(B <= 65535, "spacap_three_nn_f32: B out of range");
+  dim3 grid((n + 63) / 64, B);
+  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(64), 0, spacap::as_stream(stream), unknown, known, n, m,
+                     dist2, idx);
+  SPACAP_CHECK_LAUNCH("spacap_three_nn_f32");
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_three_interpolate_f32(const float *points, const int32_t *idx, const float *weight,
+                                            int B, int C, int m, int n, float *out,
+                                            spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && C >= 0 && m >= 0 && n >= 0, "spacap_three_interpolate_f32: bad sizes");
+  if (B == 0 || C == 0 || n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(points && idx && weight && out, "spacap_three_interpolate_f32: null pointer");
+  SPACAP_REQUIRE(B <= 65535, "spacap_three_interpolate_f32: B out of range");
+  dim3 grid((n + 255) / 256, (C + CHUNK - 1) / CHUNK, B);
+  hipLaunchKernelGGL(three_interpolate_kernel, grid, dim3(256), 0, spacap::as_stream(stream), points, idx,
+                     weight, C, m, n, out);
+  SPACAP_CHECK_LAUNCH("spacap_three_interpolate_f32");
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
+                                                 const float *weight, int B, int C, int n, int m,
+                                                 float *grad_points, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && C >= 0 && m >= 0 && n >= 0, "spacap_three_interpolate_grad_f32: bad sizes");
+  if (B == 0 || C == 0 || m == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(grad_points, "spacap_three_interpolate_grad_f32: null pointer");
+  hipStream_t s = spacap::as_stream(stream);
+  SPACAP_CHECK_HIP(hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * m, s),
+                   "spacap_three_interpolate_grad_f32(memset)");
+  if (n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(grad_out && idx && weight, "spacap_three_interpolate_grad_f32: null pointer");
+  SPACAP_REQUIRE(B <= 65535, "spacap_three_interpolate_grad_f32: B out of range");
+  dim3 grid((n + 255) / 256, (C + CHUNK - 1) / CHUNK, B);
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, grid, dim3(256), 0, s, grad_out, idx, weight, C, n, m,
+                     grad_points);
+  SPACAP_CHECK_LAUNCH("spacap_three_interpolate_grad_f32");
+  return SPACAP_OK;
+}

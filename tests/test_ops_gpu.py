@@ -1,0 +1,161 @@
+"""Parity of the HIP operators (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): FPS / ball_query / three_nn indices and every gathered value bit-exact;
+scatter-add gradients within fp32 re-association error (the reference itself uses atomics).
+"""
+import numpy as np
+import pytest
+import torch
+
+from spacap3d_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _scene(n, seed, B=2):
+    return S.scene_batch(B, n, use_height=False, seed=seed)  # (B, n, 3)
+
+
+FPS_CASES = [  # (N, m) -- every kernel variant: 1-wave, 256-thread, 1024-thread register, hybrid, generic
+    (37, 37), (64, 16), (100, 30), (128, 128), (300, 64), (512, 256), (700, 100), (1024, 256), (1024, 512),
+    (2048, 1024), (3000, 200), (4096, 512), (8192, 128), (10000, 256), (20000, 256), (24576, 64),
+    (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (80000, 96),
+]
+
+
+@pytest.mark.parametrize("N,m", FPS_CASES)
+def test_fps_bit_exact(hip_ext, oracle_ext, N, m):
+    xyz = _scene(N, seed=N + m)
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    assert got.dtype == torch.int32 and got.shape == (xyz.shape[0], m)
+    assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("N,m", [(512, 128), (700, 64), (2048, 256), (5000, 300), (40000, 400)])
+def test_fps_ties_on_a_grid(hip_ext, oracle_ext, N, m):
+    """Integer-lattice points: almost every round has many exactly equal maxima, so the result is decided
+    by the reference's tree tie-break (sampling_gpu.cu:59-65)."""
+    g = torch.Generator().manual_seed(N)
+    xyz = (torch.randint(0, 6, (2, N, 3), generator=g).float() * 0.5).contiguous()
+    xyz[:, 5] = 0.0            # skipped by the |p|^2 <= 1e-3 rule
+    xyz[:, 9] = torch.tensor([0.01, 0.02, 0.0])
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_all_points_skipped(hip_ext, oracle_ext):
+    xyz = (torch.rand(1, 300, 3) * 0.01).contiguous()  # every |p|^2 <= 1e-3 -> all indices 0
+    want = oracle_ext.furthest_point_sampling(xyz, 10)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), 10).cpu()
+    assert torch.equal(got, want) and int(want.abs().sum()) == 0
+
+
+def test_fps_skip_threshold_is_a_double_compare(hip_ext, oracle_ext):
+    """|p|^2 == float32(1e-3) is > the double literal 1e-3, so that point is NOT skipped."""
+    xyz = torch.zeros(1, 64, 3)
+    xyz[0, :, 0] = torch.linspace(1.0, 2.0, 64)
+    r = np.sqrt(np.float32(1e-3)).astype(np.float32)
+    xyz[0, 3] = torch.tensor([float(r), 0.0, 0.0])
+    want = oracle_ext.furthest_point_sampling(xyz.contiguous(), 64)
+    got = hip_ext.furthest_point_sampling(xyz.contiguous().to(DEV), 64).cpu()
+    assert torch.equal(got, want)
+
+
+BQ_CASES = [  # (N, m, radius, nsample)
+    (40000, 2048, 0.2, 64), (2048, 1024, 0.4, 32), (1024, 512, 0.8, 16), (512, 256, 1.2, 16),
+    (1024, 256, 0.3, 16), (4096, 64, 0.3, 16), (777, 33, 0.5, 5), (100, 7, 0.05, 8), (5000, 130, 10.0, 128),
+]
+
+
+@pytest.mark.parametrize("N,m,radius,nsample", BQ_CASES)
+def test_ball_query_bit_exact(hip_ext, oracle_ext, N, m, radius, nsample):
+    xyz = _scene(N, seed=N)
+    inds = oracle_ext.furthest_point_sampling(xyz, m).long()
+    new_xyz = torch.gather(xyz, 1, inds.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    new_xyz[:, -1] += 50.0  # one centre with an empty ball -> all-zero row
+    want = oracle_ext.ball_query(new_xyz, xyz, radius, nsample)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), radius, nsample).cpu()
+    assert torch.equal(got, want)
+    assert int(want[:, -1].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("C,N,P,Sn", [(1, 40000, 2048, 64), (3, 40000, 2048, 64), (128, 2048, 1024, 32),
+                                      (7, 300, 17, 5), (256, 1024, 256, 16)])
+def test_group_points_and_grad(hip_ext, oracle_ext, C, N, P, Sn):
+    g = torch.Generator().manual_seed(C * N)
+    B = 2
+    pts = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, P, Sn), generator=g, dtype=torch.int32)
+    want = oracle_ext.group_points(pts, idx)
+    got = hip_ext.group_points(pts.to(DEV), idx.to(DEV)).cpu()
+    assert torch.equal(got, want)
+    go = torch.randn(B, C, P, Sn, generator=g)
+    want_g = oracle_ext.group_points_grad(go, idx, N)
+    got_g = hip_ext.group_points_grad(go.to(DEV), idx.to(DEV), N).cpu()
+    torch.testing.assert_close(got_g, want_g, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("C,N,m", [(3, 40000, 2048), (3, 2048, 1024), (5, 100, 100), (64, 1000, 10)])
+def test_gather_points_and_grad(hip_ext, oracle_ext, C, N, m):
+    g = torch.Generator().manual_seed(C + N)
+    B = 2
+    pts = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, m), generator=g, dtype=torch.int32)
+    assert torch.equal(hip_ext.gather_points(pts.to(DEV), idx.to(DEV)).cpu(), oracle_ext.gather_points(pts, idx))
+    go = torch.randn(B, C, m, generator=g)
+    torch.testing.assert_close(hip_ext.gather_points_grad(go.to(DEV), idx.to(DEV), N).cpu(),
+                               oracle_ext.gather_points_grad(go, idx, N), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m", [(512, 256), (1024, 512), (100, 2), (77, 1), (300, 1000)])
+def test_three_nn_bit_exact(hip_ext, oracle_ext, n, m):
+    g = torch.Generator().manual_seed(n * m)
+    B = 2
+    unknown = torch.rand(B, n, 3, generator=g)
+    known = torch.rand(B, m, 3, generator=g)
+    if m > 4:
+        known[:, 3] = known[:, 1]  # exact duplicate: tie decided by the strict `<` cascade
+    d_want, i_want = oracle_ext.three_nn(unknown, known)
+    d_got, i_got = hip_ext.three_nn(unknown.to(DEV), known.to(DEV))
+    assert torch.equal(i_got.cpu(), i_want)
+    assert torch.equal(d_got.cpu(), d_want)  # includes +inf slots when m < 3
+
+
+@pytest.mark.parametrize("C,m,n", [(256, 256, 512), (256, 512, 1024), (2, 4, 2), (33, 50, 77)])
+def test_three_interpolate_and_grad(hip_ext, oracle_ext, C, m, n):
+    g = torch.Generator().manual_seed(C + m + n)
+    B = 2
+    pts = torch.randn(B, C, m, generator=g)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, generator=g)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    assert torch.equal(hip_ext.three_interpolate(pts.to(DEV), idx.to(DEV), w.to(DEV)).cpu(),
+                       oracle_ext.three_interpolate(pts, idx, w))
+    go = torch.randn(B, C, n, generator=g)
+    torch.testing.assert_close(hip_ext.three_interpolate_grad(go.to(DEV), idx.to(DEV), w.to(DEV), m).cpu(),
+                               oracle_ext.three_interpolate_grad(go, idx, w, m), rtol=1e-4, atol=1e-4)
+
+
+def test_reference_known_answer_three_interpolate(hip_ext):
+    """The one native-op test the reference ships: lib/pointnet2/pointnet2_test.py:14-26 (fixed idx / weight)."""
+    feats = torch.tensor([[[1.0, 2.0, 3.0, 4.0], [-1.0, 0.5, 2.5, 8.0]]], device=DEV)
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32, device=DEV)
+    w = torch.tensor([[[1.0, 1.0, 1.0], [2.0, 2.0, 2.0]]], device=DEV)
+    out = hip_ext.three_interpolate(feats, idx, w).cpu()
+    assert torch.equal(out, torch.tensor([[[6.0, 18.0], [2.0, 22.0]]]))
+    g = hip_ext.three_interpolate_grad(torch.ones(1, 2, 2, device=DEV), idx, w, 4).cpu()
+    assert torch.equal(g, torch.tensor([[[1.0, 3.0, 3.0, 2.0], [1.0, 3.0, 3.0, 2.0]]]))
+
+
+def test_rejects_cpu_and_bad_dtypes(hip_ext):
+    xyz = torch.rand(1, 64, 3)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        hip_ext.furthest_point_sampling(xyz, 8)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        hip_ext.furthest_point_sampling(torch.rand(1, 3, 64, device=DEV).transpose(1, 2), 8)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        hip_ext.gather_points(torch.rand(1, 3, 64, device=DEV), torch.zeros(1, 8, dtype=torch.int64, device=DEV))
