@@ -1,0 +1,110 @@
+"""Fused scaled-dot-product attention on libspacap_hip.so -- boundary B2 of SURVEY.md section 8b.
+
+Replaces the four-kernel Python ``attention()`` of the reference
+(models/transformer_captioner.py:27-37:  QK^T/sqrt(d_k) -> masked_fill(mask==0, -1e9) -> softmax ->
+dropout -> PV) with one launch of ``spacap_mha_fwd_f32`` and one of ``spacap_mha_bwd_f32``.
+
+``attention(query, key, value, mask, dropout_p, training, need_p)`` returns ``(out, p_attn)`` like the
+reference: ``out`` is (B,h,Lq,d_k) (a transposed view of a dense (B,Lq,h,d_k) buffer, so the caller's
+``x.transpose(1,2).contiguous()`` is free) and ``p_attn`` the post-dropout (B,h,Lq,Lk) matrix the
+reference stores as ``self.attn`` -- or None when ``need_p`` is False, in which case the L x L matrix
+never leaves registers.  Gradients flow to q, k, v from both outputs (the relation head consumes
+``p_attn`` of the last encoder layer, models/transformer_captioner.py:392-394).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from ._native import check, lib
+
+
+def _strides3(t):
+    assert t.stride(3) == 1, "last (d_k) dimension must be contiguous"
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def _prep_mask(mask, B, Lq, Lk):
+    """reference masks: (B,1,1,Lk) int64 key mask or (B,1,Lq,Lk) bool -> uint8 (B,Lq|1,Lk)."""
+    if mask is None:
+        return None, 0, 0
+    m = mask
+    if m.dim() == 4:
+        assert m.size(1) == 1, "per-head masks are not used by the reference"
+        m = m[:, 0]
+    assert m.dim() == 3 and m.size(-1) == Lk and m.size(1) in (1, Lq)
+    m = (m != 0).to(torch.uint8)
+    if m.size(0) != B:
+        m = m.expand(B, -1, -1)
+    m = m.contiguous()
+    return m, m.stride(0), (0 if m.size(1) == 1 else m.stride(1))
+
+
+class FusedAttention(Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask_u8, mask_sb, mask_sq, bias, dropout_p, seed, need_p):
+        if not q.is_cuda:
+            raise RuntimeError("CPU not supported")
+        B, h, Lq, dk = q.shape
+        Lk = k.shape[2]
+        if q.stride(3) != 1:
+            q = q.contiguous()
+        if k.stride(3) != 1:
+            k = k.contiguous()
+        if v.stride(3) != 1:
+            v = v.contiguous()
+        scale = 1.0 / math.sqrt(dk)
+        with torch.cuda.device(q.device):
+            out = torch.empty(B, Lq, h, dk, dtype=torch.float32, device=q.device)
+            p = torch.empty(B, h, Lq, Lk, dtype=torch.float32, device=q.device) if need_p else None
+            lse = torch.empty(B, h, Lq, dtype=torch.float32, device=q.device)
+            bs = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else (0, 0, 0)
+            check(lib.spacap_mha_fwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), *_strides3(q), *_strides3(k), *_strides3(v),
+                mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq,
+                bias.data_ptr() if bias is not None else None, *bs,
+                B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed),
+                out.data_ptr(), p.data_ptr() if need_p else None, lse.data_ptr(),
+                torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_fwd_f32")
+        ctx.save_for_backward(q, k, v, mask_u8, bias, lse)
+        ctx.meta = (mask_sb, mask_sq, dropout_p, seed, scale, need_p)
+        out_v = out.transpose(1, 2)
+        if need_p:
+            return out_v, p
+        ctx.mark_non_differentiable(lse)
+        return out_v, lse  # second output unused by callers when need_p is False
+
+    @staticmethod
+    def backward(ctx, d_out, d_p):
+        q, k, v, mask_u8, bias, lse = ctx.saved_tensors
+        mask_sb, mask_sq, dropout_p, seed, scale, need_p = ctx.meta
+        B, h, Lq, dk = q.shape
+        Lk = k.shape[2]
+        with torch.cuda.device(q.device):
+            d_out_c = d_out.transpose(1, 2).contiguous()  # (B, Lq, h, dk)
+            d_p_c = d_p.contiguous() if (need_p and d_p is not None) else None
+            dq = torch.empty(B, Lq, h, dk, dtype=torch.float32, device=q.device)
+            dk_ = torch.empty(B, Lk, h, dk, dtype=torch.float32, device=q.device)
+            dv = torch.empty(B, Lk, h, dk, dtype=torch.float32, device=q.device)
+            bs = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else (0, 0, 0)
+            check(lib.spacap_mha_bwd_f32(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), *_strides3(q), *_strides3(k), *_strides3(v),
+                mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq,
+                bias.data_ptr() if bias is not None else None, *bs,
+                B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed), lse.data_ptr(),
+                d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None,
+                dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(),
+                torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_bwd_f32")
+        return (dq.transpose(1, 2), dk_.transpose(1, 2), dv.transpose(1, 2), None, None, None, None, None, None,
+                None)
+
+
+def attention(query, key, value, mask=None, dropout_p=0.0, training=False, need_p=True, bias=None):
+    """(out (B,h,Lq,d_k), p_attn (B,h,Lq,Lk) or None); see the module docstring."""
+    B, h, Lq, dk = query.shape
+    Lk = key.shape[2]
+    m, msb, msq = _prep_mask(mask, B, Lq, Lk)
+    p = float(dropout_p) if training else 0.0
+    seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p > 0.0 else 0
+    out, second = FusedAttention.apply(query, key, value, m, msb, msq, bias, p, seed, need_p)
+    return out, (second if need_p else None)

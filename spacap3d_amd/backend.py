@@ -1,0 +1,49 @@
+"""Operator backend selection.
+
+The product has exactly one backend: the HIP library (``spacap3d_amd.ext`` + ``spacap3d_amd.attention``).
+``set_backend`` exists so that *tests and the CPU-baseline leg of bench.py* can drive the same host code
+with the CPU oracle (``oracle/``) as the checker; nothing inside this package ever selects it, and there is
+no automatic fallback: if the HIP library is missing, ``ops()`` raises ImportError.
+"""
+import contextlib
+
+_current = None
+
+
+class HipBackend:
+    """The nine ``_ext`` entry points + fused attention, all on libspacap_hip.so."""
+
+    name = "hip"
+
+    def __init__(self):
+        from . import ext  # raises ImportError when the extension is not built
+        from . import attention as _att
+        self._ext = ext
+        for n in ("gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
+                  "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
+                  "group_points_grad"):
+            setattr(self, n, getattr(ext, n))
+        self.attention = _att.attention
+
+
+def ops():
+    global _current
+    if _current is None:
+        _current = HipBackend()
+    return _current
+
+
+def set_backend(b):
+    global _current
+    prev = _current
+    _current = b
+    return prev
+
+
+@contextlib.contextmanager
+def use_backend(b):
+    prev = set_backend(b)
+    try:
+        yield b
+    finally:
+        set_backend(prev)

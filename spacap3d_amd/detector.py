@@ -1,0 +1,175 @@
+"""PointNet++ backbone, voting module and proposal module -- counterparts of the reference's
+``models/backbone_module.py``, ``models/voting_module.py`` and ``models/proposal_module.py``.
+
+Same constructor arguments, ``data_dict`` keys, tensor shapes and state-dict key layout
+(``sa{1..4}.mlp_module.*``, ``fp{1,2}.mlp.*``, ``conv{1,2,3}``, ``bn{1,2}``, ``vote_aggregation.*``,
+``proposal.{0,1,3,4,6}.*``) as the reference.  Differences, all below the observable interface:
+  * device-agnostic (the reference hard-codes ``.cuda()``, proposal_module.py:100,141,143);
+  * the predicted box corners are decoded on the device in float64 instead of the reference's
+    GPU -> CPU -> numpy -> GPU round trip every forward (proposal_module.py:81-104); ScanNet boxes are
+    axis aligned (heading is identically 0, model_util_scannet.py:136-146), so the corners are
+    centre +/- size / 2 in the corner order of utils/box_util.py:360-383.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+
+class Pointnet2Backbone(nn.Module):
+    """4 set-abstraction + 2 feature-propagation layers (backbone_module.py:28-66)."""
+
+    def __init__(self, input_feature_dim=0):
+        super().__init__()
+        self.input_feature_dim = input_feature_dim
+        self.sa1 = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64,
+                                         mlp=[input_feature_dim, 64, 64, 128], use_xyz=True, normalize_xyz=True)
+        self.sa2 = PointnetSAModuleVotes(npoint=1024, radius=0.4, nsample=32,
+                                         mlp=[128, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.sa3 = PointnetSAModuleVotes(npoint=512, radius=0.8, nsample=16,
+                                         mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.sa4 = PointnetSAModuleVotes(npoint=256, radius=1.2, nsample=16,
+                                         mlp=[256, 128, 128, 256], use_xyz=True, normalize_xyz=True)
+        self.fp1 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+        self.fp2 = PointnetFPModule(mlp=[256 + 256, 256, 256])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., :3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, data_dict):
+        xyz, features = self._break_up_pc(data_dict["point_clouds"])
+        xyz, features, fps_inds = self.sa1(xyz, features)
+        data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
+        xyz, features, fps_inds = self.sa2(xyz, features)
+        data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
+        xyz, features, fps_inds = self.sa3(xyz, features)
+        data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
+        xyz, features, fps_inds = self.sa4(xyz, features)
+        data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
+        features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
+                            data_dict["sa4_features"])
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+        data_dict["fp2_features"] = features
+        data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
+        num_seed = data_dict["fp2_xyz"].shape[1]
+        # VoteNet quirk kept on purpose (backbone_module.py:127): the vote loss gathers labels with it.
+        data_dict["fp2_inds"] = data_dict["sa1_inds"][:, 0:num_seed]
+        return data_dict
+
+
+class VotingModule(nn.Module):
+    """Conv1d 256->256->256->(3+256)*vote_factor with BN+ReLU on the first two, residual votes
+    (voting_module.py:28-61)."""
+
+    def __init__(self, vote_factor, seed_feature_dim):
+        super().__init__()
+        self.vote_factor = vote_factor
+        self.in_dim = seed_feature_dim
+        self.out_dim = self.in_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.conv3 = nn.Conv1d(self.in_dim, (3 + self.out_dim) * self.vote_factor, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+
+    def forward(self, seed_xyz, seed_features):
+        B, num_seed = seed_xyz.shape[0], seed_xyz.shape[1]
+        num_vote = num_seed * self.vote_factor
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        net = self.conv3(net)
+        net = net.transpose(2, 1).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
+        vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, num_vote, 3)
+        vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[:, :, :, 3:]
+        vote_features = vote_features.contiguous().view(B, num_vote, self.out_dim).transpose(2, 1).contiguous()
+        return vote_xyz, vote_features
+
+
+_CORNER_SIGNS = torch.tensor(  # utils/box_util.py:377-379 (l on x, w on y, h on z)
+    [[1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1], [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]],
+    dtype=torch.float64)
+
+
+class ProposalModule(nn.Module):
+    """Vote aggregation SA (npoint=P, r=0.3, ns=16, mlp [256+3,128,128,128]) + Conv1d head
+    128->128->128->(2+3+2*NH+4*NS+num_class) (proposal_module.py:34-54) + score decoding (:106-158)."""
+
+    def __init__(self, num_class, num_heading_bin, num_size_cluster, mean_size_arr, num_proposal, sampling,
+                 seed_feat_dim=256, size_decoded=False):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_size_cluster = num_size_cluster
+        self.num_proposal = num_proposal
+        self.sampling = sampling
+        self.seed_feat_dim = seed_feat_dim
+        self.size_decoded = size_decoded
+        msa = torch.as_tensor(np.asarray(mean_size_arr), dtype=torch.float64)
+        assert msa.shape == (num_size_cluster, 3)
+        # non-persistent: not part of the reference's state dict
+        self.register_buffer("mean_size_f64", msa, persistent=False)
+        self.register_buffer("mean_size_f32", msa.float(), persistent=False)
+        self.register_buffer("corner_signs", _CORNER_SIGNS.clone(), persistent=False)
+        self.vote_aggregation = PointnetSAModuleVotes(npoint=num_proposal, radius=0.3, nsample=16,
+                                                      mlp=[seed_feat_dim, 128, 128, 128], use_xyz=True,
+                                                      normalize_xyz=True)
+        self.proposal = nn.Sequential(
+            nn.Conv1d(128, 128, 1, bias=False), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Conv1d(128, 128, 1, bias=False), nn.BatchNorm1d(128), nn.ReLU(),
+            nn.Conv1d(128, 2 + 3 + num_heading_bin * 2 + num_size_cluster * 4 + num_class, 1))
+
+    def forward(self, xyz, features, data_dict):
+        xyz, features, fps_inds = self.vote_aggregation(xyz, features)
+        data_dict["aggregated_vote_xyz"] = xyz
+        data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
+        data_dict["aggregated_vote_inds"] = fps_inds
+        net = self.proposal(features)
+        return self.decode_scores(net, data_dict)
+
+    def decode_pred_box(self, data_dict):
+        """(B, P, 8, 3) float64 corners of the arg-max size class box (proposal_module.py:81-104)."""
+        center = data_dict["center"].detach().double()
+        size_class = torch.argmax(data_dict["size_scores"], -1)
+        size_res = torch.gather(data_dict["size_residuals"].detach(), 2,
+                                size_class.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)).squeeze(2)
+        box_size = self.mean_size_f64[size_class] + size_res.double()  # class2size_batch
+        return center.unsqueeze(2) + self.corner_signs * (box_size / 2).unsqueeze(2)
+
+    def decode_scores(self, net, data_dict):
+        NH, NS = self.num_heading_bin, self.num_size_cluster
+        nt = net.transpose(2, 1).contiguous()
+        B, P = nt.shape[0], nt.shape[1]
+        objectness_scores = nt[:, :, 0:2]
+        center = data_dict["aggregated_vote_xyz"] + nt[:, :, 2:5]
+        heading_scores = nt[:, :, 5:5 + NH]
+        heading_residuals_normalized = nt[:, :, 5 + NH:5 + NH * 2]
+        size_scores = nt[:, :, 5 + NH * 2:5 + NH * 2 + NS]
+        size_residuals_normalized = nt[:, :, 5 + NH * 2 + NS:5 + NH * 2 + NS * 4].view(B, P, NS, 3)
+        sem_cls_scores = nt[:, :, 5 + NH * 2 + NS * 4:]
+        msa = self.mean_size_f32.unsqueeze(0).unsqueeze(0)
+        data_dict["objectness_scores"] = objectness_scores
+        data_dict["center"] = center
+        data_dict["heading_scores"] = heading_scores
+        data_dict["heading_residuals_normalized"] = heading_residuals_normalized
+        data_dict["heading_residuals"] = heading_residuals_normalized * (math.pi / NH)
+        data_dict["size_scores"] = size_scores
+        data_dict["size_residuals_normalized"] = size_residuals_normalized
+        data_dict["size_residuals"] = size_residuals_normalized * msa
+        if self.size_decoded:
+            size_recover = data_dict["size_residuals"] + msa
+            cls = torch.argmax(size_scores, -1).unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
+            data_dict["pred_size"] = torch.gather(size_recover, 2, cls).squeeze(2)
+        data_dict["sem_cls_scores"] = sem_cls_scores
+        data_dict["bbox_corner"] = self.decode_pred_box(data_dict)
+        data_dict["bbox_feature"] = data_dict["aggregated_vote_features"]
+        data_dict["bbox_mask"] = objectness_scores.argmax(-1)
+        data_dict["bbox_sems"] = sem_cls_scores.argmax(-1)
+        data_dict["sem_cls"] = sem_cls_scores.argmax(-1)
+        return data_dict

@@ -1,0 +1,206 @@
+"""Training loss of the scene captioner -- counterpart of ``lib/loss_helper.py`` (+ ``utils/nn_distance.py``).
+
+Same terms, weights and ``data_dict`` keys as ``get_scene_cap_loss`` (lib/loss_helper.py:291-385):
+    loss = 10 * (vote + 0.5 * objectness + box + 0.1 * sem_cls) + caption + 0.1 * relation
+Restated so that one training step needs NO host synchronisation:
+  * no hard-coded ``.cuda()`` (the reference allocates with it, :94-95,102,158,175,181);
+  * ``nn_distance`` broadcasts instead of materialising two ``repeat`` copies (nn_distance.py:49-51);
+  * the relation loss (:240-289) selects pairs (i, j) of "positive, GT-valid" proposals with boolean-mask
+    indexing, i.e. data-dependent shapes; here the same mean is a dense pair-weighted sum
+    sum(W * CE) / sum(W) with W[b,i,j] = sel[b,i] * sel[b,j]  (identical value; when no pair is selected the
+    reference yields NaN, this yields 0);
+  * caption accuracy / ious use masked sums instead of ``if num_good > 0`` branches (:223-237).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+FAR_THRESHOLD = 0.6
+NEAR_THRESHOLD = 0.3
+GT_VOTE_FACTOR = 3
+OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]
+
+
+def huber_loss(error, delta=1.0):
+    abs_error = torch.abs(error)
+    quadratic = torch.clamp(abs_error, max=delta)
+    linear = abs_error - quadratic
+    return 0.5 * quadratic ** 2 + delta * linear
+
+
+def nn_distance(pc1, pc2, l1smooth=False, delta=1.0, l1=False):
+    """pc1 (B,N,C), pc2 (B,M,C) -> dist1 (B,N), idx1 (B,N), dist2 (B,M), idx2 (B,M)  (nn_distance.py:32-62)."""
+    diff = pc1.unsqueeze(2) - pc2.unsqueeze(1)  # (B,N,M,C)
+    if l1smooth:
+        pc_dist = torch.sum(huber_loss(diff, delta), dim=-1)
+    elif l1:
+        pc_dist = torch.sum(torch.abs(diff), dim=-1)
+    else:
+        pc_dist = torch.sum(diff ** 2, dim=-1)
+    dist1, idx1 = torch.min(pc_dist, dim=2)
+    dist2, idx2 = torch.min(pc_dist, dim=1)
+    return dist1, idx1, dist2, idx2
+
+
+def compute_vote_loss(d):
+    B, num_seed = d["seed_xyz"].shape[0], d["seed_xyz"].shape[1]
+    vote_xyz = d["vote_xyz"]
+    seed_inds = d["seed_inds"].long()
+    seed_gt_votes_mask = torch.gather(d["vote_label_mask"], 1, seed_inds)
+    seed_inds_expand = seed_inds.view(B, num_seed, 1).expand(-1, -1, 3 * GT_VOTE_FACTOR)
+    seed_gt_votes = torch.gather(d["vote_label"], 1, seed_inds_expand) + d["seed_xyz"].repeat(1, 1, 3)
+    vote_xyz_reshape = vote_xyz.view(B * num_seed, -1, 3)
+    seed_gt_votes_reshape = seed_gt_votes.view(B * num_seed, GT_VOTE_FACTOR, 3)
+    _, _, dist2, _ = nn_distance(vote_xyz_reshape, seed_gt_votes_reshape, l1=True)
+    votes_dist, _ = torch.min(dist2, dim=1)
+    votes_dist = votes_dist.view(B, num_seed)
+    m = seed_gt_votes_mask.float()
+    return torch.sum(votes_dist * m) / (torch.sum(m) + 1e-6)
+
+
+def compute_objectness_loss(d):
+    agg = d["aggregated_vote_xyz"]
+    gt_center = d["center_label"][:, :, 0:3]
+    dist1, ind1, _, _ = nn_distance(agg, gt_center)
+    euclid = torch.sqrt(dist1 + 1e-6)
+    near = euclid < NEAR_THRESHOLD
+    objectness_label = near.long()
+    objectness_mask = (near | (euclid > FAR_THRESHOLD)).float()
+    w = torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=torch.float32, device=agg.device)
+    loss = F.cross_entropy(d["objectness_scores"].transpose(2, 1), objectness_label, weight=w, reduction="none")
+    loss = torch.sum(loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
+    return loss, objectness_label, objectness_mask, ind1
+
+
+def compute_box_and_sem_cls_loss(d, num_heading_bin, num_size_cluster, mean_size_arr):
+    oa = d["object_assignment"]
+    pred_center = d["center"]
+    gt_center = d["center_label"][:, :, 0:3]
+    dist1, _, dist2, _ = nn_distance(pred_center, gt_center)
+    box_label_mask = d["box_label_mask"]
+    obj = d["objectness_label"].float()
+    n_obj = torch.sum(obj) + 1e-6
+    center_loss = torch.sum(dist1 * obj) / n_obj + torch.sum(dist2 * box_label_mask) / (torch.sum(box_label_mask) + 1e-6)
+
+    heading_class_label = torch.gather(d["heading_class_label"], 1, oa)
+    heading_class_loss = F.cross_entropy(d["heading_scores"].transpose(2, 1), heading_class_label, reduction="none")
+    heading_class_loss = torch.sum(heading_class_loss * obj) / n_obj
+    heading_residual_label = torch.gather(d["heading_residual_label"], 1, oa)
+    heading_residual_normalized_label = heading_residual_label / (math.pi / num_heading_bin)
+    heading_one_hot = F.one_hot(heading_class_label, num_heading_bin).float()
+    hr = huber_loss(torch.sum(d["heading_residuals_normalized"] * heading_one_hot, -1)
+                    - heading_residual_normalized_label, delta=1.0)
+    heading_reg_loss = torch.sum(hr * obj) / n_obj
+
+    size_class_label = torch.gather(d["size_class_label"], 1, oa)
+    size_class_loss = F.cross_entropy(d["size_scores"].transpose(2, 1), size_class_label, reduction="none")
+    size_class_loss = torch.sum(size_class_loss * obj) / n_obj
+    size_residual_label = torch.gather(d["size_residual_label"], 1, oa.unsqueeze(-1).expand(-1, -1, 3))
+    size_one_hot = F.one_hot(size_class_label, num_size_cluster).float().unsqueeze(-1)  # (B,K,NS,1)
+    pred_size_res_norm = torch.sum(d["size_residuals_normalized"] * size_one_hot, 2)
+    msa = torch.as_tensor(mean_size_arr, dtype=torch.float32, device=pred_center.device).unsqueeze(0).unsqueeze(0)
+    mean_size_label = torch.sum(size_one_hot * msa, 2)
+    size_residual_label_normalized = size_residual_label / mean_size_label
+    sr = torch.mean(huber_loss(pred_size_res_norm - size_residual_label_normalized, delta=1.0), -1)
+    size_reg_loss = torch.sum(sr * obj) / n_obj
+
+    sem_cls_label = torch.gather(d["sem_cls_label"], 1, oa)
+    sem_cls_loss = F.cross_entropy(d["sem_cls_scores"].transpose(2, 1), sem_cls_label, reduction="none")
+    sem_cls_loss = torch.sum(sem_cls_loss * obj) / n_obj
+    return center_loss, heading_class_loss, heading_reg_loss, size_class_loss, size_reg_loss, sem_cls_loss
+
+
+def compute_cap_loss(d):
+    pred_caps = d["lang_cap"]  # (B, num_words, V) log-probs
+    num_words, V = pred_caps.size(1), pred_caps.size(2)
+    target_caps = d["lang_ids"][:, 1:num_words + 1]
+    assert pred_caps.shape[0:2] == target_caps.shape[0:2]
+    cap_loss = F.cross_entropy(pred_caps.reshape(-1, V), target_caps.reshape(-1), ignore_index=0, reduction="none")
+    good = d["good_bbox_masks"].unsqueeze(1).expand(-1, num_words).reshape(-1).float()
+    cap_loss = torch.sum(cap_loss * good) / (torch.sum(good) + 1e-6)
+    # accuracy over non-pad words of good boxes (0 when there are none)
+    hit = (pred_caps.argmax(-1) == target_caps).reshape(-1).float()
+    valid = (target_caps.reshape(-1) != 0).float() * good
+    cap_acc = torch.sum(hit * valid) / torch.sum(valid).clamp(min=1.0)
+    return cap_loss, cap_acc
+
+
+def compute_relation_loss(d):
+    oa = d["object_assignment"]
+    B, K = oa.shape
+    M = d["y_label"].shape[1]
+    sel = (torch.gather(d["box_label_mask_int"], 1, oa) & d["objectness_label"]).float()  # (B,K)
+    W = sel.unsqueeze(2) * sel.unsqueeze(1)                                             # (B,K,K)
+    n = W.sum().clamp(min=1.0)
+    out = {}
+    rows = oa.unsqueeze(-1).expand(-1, -1, M)
+    cols = oa.unsqueeze(-2).expand(-1, K, -1)
+    for a, sl in (("x", slice(0, 3)), ("y", slice(3, 6)), ("z", slice(6, 9))):
+        lab = torch.gather(torch.gather(d[f"{a}_label"], 1, rows), 2, cols)          # (B,K,K)
+        pred = d["relation_pred"][..., sl]
+        ce = F.cross_entropy(pred.reshape(-1, 3), lab.reshape(-1), reduction="none").view(B, K, K)
+        out[f"{a}_loss"] = (ce * W).sum() / n
+        out[f"{a}_acc"] = ((pred.argmax(-1) == lab).float() * W).sum() / n
+    return out
+
+
+def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, caption=True, use_relation=False,
+                       num_heading_bin=1, num_size_cluster=18, mean_size_arr=None):
+    """Mutates and returns ``data_dict`` with every key the reference writes (lib/loss_helper.py:291-385).
+    ``config`` may be an object with num_heading_bin / num_size_cluster / mean_size_arr (the reference's DC)."""
+    d = data_dict
+    if config is not None:
+        num_heading_bin, num_size_cluster, mean_size_arr = (config.num_heading_bin, config.num_size_cluster,
+                                                            config.mean_size_arr)
+    dev = d["seed_xyz"].device
+    zero = torch.zeros((), device=dev)
+
+    vote_loss = compute_vote_loss(d)
+    objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)
+    total = objectness_label.shape[0] * objectness_label.shape[1]
+    d["objectness_label"] = objectness_label
+    d["objectness_mask"] = objectness_mask
+    d["object_assignment"] = object_assignment
+    d["pos_ratio"] = torch.sum(objectness_label.float()) / float(total)
+    d["neg_ratio"] = torch.sum(objectness_mask) / float(total) - d["pos_ratio"]
+
+    center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
+        compute_box_and_sem_cls_loss(d, num_heading_bin, num_size_cluster, mean_size_arr)
+    box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
+
+    d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
+        torch.sum(objectness_mask) + 1e-6)
+
+    if use_relation:
+        rel = compute_relation_loss(d)
+        d.update(rel)
+        d["relation_loss"] = rel["y_loss"] + rel["z_loss"] + rel["x_loss"]
+    else:
+        for k in ("x_loss", "y_loss", "z_loss", "relation_loss", "x_acc", "y_acc", "z_acc"):
+            d[k] = zero
+
+    names = ("vote_loss", "objectness_loss", "center_loss", "heading_cls_loss", "heading_reg_loss",
+             "size_cls_loss", "size_reg_loss", "sem_cls_loss", "box_loss")
+    vals = (vote_loss, objectness_loss, center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss,
+            size_reg_loss, sem_cls_loss, box_loss)
+    for k, v in zip(names, vals):
+        d[k] = v if detection else zero
+    if not detection:
+        d["det_loss"] = zero
+
+    if caption:
+        d["cap_loss"], d["cap_acc"] = compute_cap_loss(d)
+    else:
+        d["cap_loss"], d["cap_acc"], d["pred_ious"] = zero, zero, zero
+
+    loss = 0
+    if detection:
+        d["det_loss"] = d["vote_loss"] + 0.5 * d["objectness_loss"] + d["box_loss"] + 0.1 * d["sem_cls_loss"]
+        loss = loss + 10 * d["det_loss"]
+    if caption:
+        loss = loss + d["cap_loss"]
+    if use_relation:
+        loss = loss + 0.1 * d["relation_loss"]
+    d["loss"] = loss
+    return d

@@ -1,0 +1,100 @@
+"""Set-abstraction / feature-propagation modules -- counterpart of the two classes the reference model
+actually uses from ``lib/pointnet2/pointnet2_modules.py`` (PointnetSAModuleVotes :165-276,
+PointnetFPModule :361-421) and of ``SharedMLP`` (lib/pointnet2/pytorch_utils.py:11-36,67-120).
+
+Parameter / buffer names reproduce the reference's state-dict layout
+(``mlp_module.layer{i}.conv.weight``, ``mlp_module.layer{i}.bn.bn.{weight,bias,running_mean,...}``,
+``mlp.layer{i}...``) so VoteNet checkpoints of the reference load unchanged.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+
+
+class _BN2d(nn.Sequential):
+    """pytorch_utils.py:39-58: a Sequential holding one BatchNorm2d named ``bn`` (weight 1, bias 0)."""
+
+    def __init__(self, channels: int):
+        super().__init__()
+        self.add_module("bn", nn.BatchNorm2d(channels))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0.0)
+
+
+class _ConvBNReLU2d(nn.Sequential):
+    """pytorch_utils.py:67-120 with the arguments SharedMLP passes: 1x1 Conv2d (bias only without BN,
+    kaiming-normal weight, :87-97) -> BatchNorm2d -> ReLU(inplace)."""
+
+    def __init__(self, cin: int, cout: int, bn: bool):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0), bias=not bn)
+        nn.init.kaiming_normal_(conv.weight)
+        if not bn:
+            nn.init.constant_(conv.bias, 0.0)
+        self.add_module("conv", conv)
+        if bn:
+            self.add_module("bn", _BN2d(cout))
+        self.add_module("activation", nn.ReLU(inplace=True))
+
+
+class SharedMLP(nn.Sequential):
+    def __init__(self, args: List[int], *, bn: bool = False):
+        super().__init__()
+        for i in range(len(args) - 1):
+            self.add_module(f"layer{i}", _ConvBNReLU2d(args[i], args[i + 1], bn))
+
+
+class PointnetSAModuleVotes(nn.Module):
+    """FPS -> gather centres -> ball-query grouping -> SharedMLP -> max over the samples.
+    Returns (new_xyz (B,npoint,3), new_features (B,C_out,npoint), inds (B,npoint) int32).
+    Only max pooling is provided (the model uses nothing else; avg / rbf at :260-270 are unused)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pooling: str = "max", normalize_xyz: bool = False):
+        super().__init__()
+        assert pooling == "max", "only max pooling is on the SpaCap3D path"
+        assert npoint is not None, "GroupAll is not on the SpaCap3D path"
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.use_xyz, self.normalize_xyz = use_xyz, normalize_xyz
+        self.grouper = pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz, ret_grouped_xyz=True,
+                                                     normalize_xyz=normalize_xyz)
+        mlp_spec = list(mlp)
+        if use_xyz and len(mlp_spec) > 0:
+            mlp_spec[0] += 3
+        self.mlp_module = SharedMLP(mlp_spec, bn=bn)
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        else:
+            assert inds.shape[1] == self.npoint
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, C+3, npoint, nsample)
+        new_features = self.mlp_module(grouped_features)                         # (B, mlp[-1], npoint, nsample)
+        new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
+        return new_xyz, new_features, inds
+
+
+class PointnetFPModule(nn.Module):
+    """three_nn -> inverse-distance weights -> three_interpolate -> cat skip -> SharedMLP (:376-421)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = SharedMLP(list(mlp), bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
+        return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)

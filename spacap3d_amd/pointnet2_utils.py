@@ -1,0 +1,141 @@
+"""Autograd wrappers around the native operators -- the drop-in counterpart of the reference's
+``lib/pointnet2/pointnet2_utils.py`` (same public names, argument order and return values):
+
+    furthest_point_sample(xyz, npoint)            pointnet2_utils.py:51-80
+    gather_operation(features, idx)               :83-117
+    three_nn(unknown, known) -> (dist, idx)       :120-149   (dist = sqrt of the native dist2, :142)
+    three_interpolate(features, idx, weight)      :152-206
+    grouping_operation(features, idx)             :209-257
+    ball_query(radius, nsample, xyz, new_xyz)     :260-291   (note the argument order)
+    QueryAndGroup                                 :294-380
+
+The native calls go through ``backend.ops()`` (the HIP library); the model code above this file is
+unchanged relative to the reference's call pattern.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .backend import ops
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        inds = ops().furthest_point_sampling(xyz, npoint)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, grad=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return ops().gather_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return ops().gather_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        dist2, idx = ops().three_nn(unknown, known)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        ctx.m = features.size(2)
+        ctx.save_for_backward(idx, weight)
+        return ops().three_interpolate(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        return ops().three_interpolate_grad(grad_out.contiguous(), idx, weight, ctx.m), None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.n = features.size(2)
+        ctx.save_for_backward(idx)
+        return ops().group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return ops().group_points_grad(grad_out.contiguous(), idx, ctx.n), None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        inds = ops().ball_query(new_xyz, xyz, radius, nsample)
+        ctx.mark_non_differentiable(inds)
+        return inds
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball-query grouping: idx -> grouped xyz (centre-subtracted, optionally / radius) ++ grouped features,
+    xyz channels first (pointnet2_utils.py:334-362).  ``sample_uniformly`` is dead code in the reference
+    (it prints and exits, :337-339) and is not provided."""
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if self.normalize_xyz:
+            grouped_xyz = grouped_xyz / self.radius
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            new_features = torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        if self.ret_grouped_xyz:
+            return new_features, grouped_xyz
+        return new_features

@@ -1,0 +1,377 @@
+"""Spatiality-guided Transformer captioner -- counterpart of ``models/transformer_captioner.py``.
+
+Same module tree / parameter names as the reference (so its state dicts load), same ``data_dict``
+contract.  The hot spots run on the HIP library:
+  * ``attention()`` (reference :27-37) -> one fused kernel (``spacap3d_amd.attention``); the L x L matrix
+    ``p_attn`` is materialised only for layers whose ``self.attn`` is consumed (``store_attn``), i.e. the
+    last encoder layer (relation head, :392-394) -- or for every layer when ``store_attn_all`` is set,
+    which reproduces the reference's always-on ``self.attn`` (used by its eval-time attention dumps);
+  * the relation feature  R[b,i,j,(h,d)] = P[b,h,i,j] * V[b,h,j,d]  (:393-396) is formed by one broadcast
+    product (the reference materialises an extra ``repeat`` copy of P first).
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backend import ops
+from .loss_helper import nn_distance
+
+MAX_DES_LEN = 30  # lib/config.py:55
+
+
+def subsequent_mask(size, device=None):
+    """(1, size, size) bool, True on and below the diagonal (:16-20)."""
+    return torch.ones(1, size, size, dtype=torch.bool, device=device).tril()
+
+
+def clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def attention(query, key, value, mask=None, dropout=None, need_p=True):
+    """Reference signature (:27) plus ``need_p``; returns (P V, p_attn)."""
+    p = dropout.p if dropout is not None else 0.0
+    training = dropout.training if dropout is not None else False
+    return ops().attention(query, key, value, mask=mask, dropout_p=p, training=training, need_p=need_p)
+
+
+class MultiHeadedAttention(nn.Module):
+    def __init__(self, h, d_model, dropout=0.1, keep_value=False, store_attn=None):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        self.linears = clones(nn.Linear(d_model, d_model), 4)
+        self.attn = None
+        self.value = None
+        self.dropout = nn.Dropout(p=dropout)
+        self.keep_value = keep_value
+        # None: follow the module-wide default (see TransformerDecoderModel.store_attn_all)
+        self.store_attn = store_attn
+
+    def forward(self, query, key, value, mask=None):
+        if mask is not None:
+            mask = mask.unsqueeze(1)
+        nb = query.size(0)
+        query, key, value = [l(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
+                             for l, x in zip(self.linears, (query, key, value))]
+        need_p = self.keep_value if self.store_attn is None else (self.store_attn or self.keep_value)
+        x, self.attn = attention(query, key, value, mask=mask, dropout=self.dropout, need_p=need_p)
+        if self.keep_value:
+            self.value = value
+        x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
+        return self.linears[-1](x)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        return self.w_2(self.dropout(F.relu(self.w_1(x))))
+
+
+class Embeddings(nn.Module):
+    def __init__(self, d_model, vocab):
+        super().__init__()
+        self.lut = nn.Embedding(vocab, d_model)
+        self.d_model = d_model
+
+    def forward(self, x):
+        return self.lut(x) * math.sqrt(self.d_model)
+
+
+class Generator(nn.Module):
+    def __init__(self, d_model, vocab):
+        super().__init__()
+        self.proj = nn.Linear(d_model, vocab)
+
+    def forward(self, x):
+        return F.log_softmax(self.proj(x), dim=-1)
+
+
+class LayerNorm(nn.Module):
+    """a * (x - mean) / (std_unbiased + eps) + b   (:102-113) -- NOT nn.LayerNorm."""
+
+    def __init__(self, features, eps=1e-6):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(-1, keepdim=True)
+        std = x.std(-1, keepdim=True)
+        return self.a_2 * (x - mean) / (std + self.eps) + self.b_2
+
+
+class SublayerConnection(nn.Module):
+    def __init__(self, size, dropout):
+        super().__init__()
+        self.norm = LayerNorm(size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, sublayer):
+        return x + self.dropout(sublayer(self.norm(x)))
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len).unsqueeze(1).float()
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * -(math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x, src_pos=None):
+        return self.dropout(x + self.pe[:, :x.size(1)])
+
+
+class PositionalEncodingLearned(nn.Module):
+    def __init__(self, input_channel, d_model=128):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, d_model, kernel_size=1), nn.BatchNorm1d(d_model), nn.ReLU(inplace=True),
+            nn.Conv1d(d_model, d_model, kernel_size=1))
+
+    def forward(self, x, xyz):
+        return x + self.position_embedding_head(xyz.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+
+
+class Encoder(nn.Module):
+    def __init__(self, layer, N):
+        super().__init__()
+        self.layers = clones(layer, N)
+        self.norm = LayerNorm(layer.size)
+
+    def forward(self, x, mask):
+        for layer in self.layers:
+            x = layer(x, mask)
+        return self.norm(x)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, size, self_attn, feed_forward, dropout):
+        super().__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.sublayer = clones(SublayerConnection(size, dropout), 2)
+        self.size = size
+
+    def forward(self, x, mask):
+        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, mask))
+        return self.sublayer[1](x, self.feed_forward)
+
+
+class Decoder(nn.Module):
+    def __init__(self, layer, N):
+        super().__init__()
+        self.layers = clones(layer, N)
+        self.norm = LayerNorm(layer.size)
+
+    def forward(self, x, memory, src_mask, tgt_mask, obj_indicator=None):
+        if obj_indicator is not None:
+            x = torch.cat((obj_indicator, x), dim=1)
+        for layer in self.layers:
+            x = layer(x, memory, src_mask, tgt_mask)
+        return self.norm(x)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, size, self_attn, src_attn, feed_forward, dropout, early_guide=True):
+        super().__init__()
+        self.size = size
+        self.self_attn = self_attn
+        self.src_attn = src_attn
+        self.feed_forward = feed_forward
+        self.early_guide = early_guide
+        self.sublayer = clones(SublayerConnection(size, dropout), 3)
+
+    def forward(self, x, memory, src_mask, tgt_mask):
+        m = memory
+        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, tgt_mask))
+        if not self.early_guide:
+            x = self.sublayer[1](x, lambda y: self.src_attn(y, m, m, src_mask))
+        return self.sublayer[2](x, self.feed_forward)
+
+
+class _Identity(nn.Module):
+    def forward(self, x, *a):
+        return x
+
+
+class EncoderDecoder(nn.Module):
+    def __init__(self, encoder, decoder, src_embed, tgt_embed, generator, early_guide=True):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.src_embed = src_embed
+        self.tgt_embed = tgt_embed
+        self.generator = generator
+        self.early_guide = early_guide
+
+    def forward(self, src, tgt, src_mask, tgt_mask, obj_indicator=None, src_pos=None, obj_idx=None, memory=None):
+        if memory is None:
+            if self.encoder is None:
+                memory = self.src_embed(src, src_pos) if src_pos is not None else src
+            else:
+                memory = self.encode(src, src_pos, src_mask)
+        return self.decode(memory, src_mask, tgt, tgt_mask, obj_indicator=obj_indicator, obj_idx=obj_idx)
+
+    def encode(self, src, src_pos, src_mask):
+        return self.encoder(self.src_embed(src, src_pos), src_mask)
+
+    def decode(self, memory, src_mask, tgt, tgt_mask, obj_indicator=None, obj_idx=None):
+        if memory.shape[0] != tgt.shape[0]:  # inference: B*K sequences over B scenes (:252-257)
+            assert memory.shape[0] * memory.shape[1] == tgt.shape[0]
+            B, K, _ = memory.shape
+            obj_indicator = obj_indicator + memory.reshape(B * K, -1).unsqueeze(1)
+            if self.early_guide:
+                # the reference materialises repeat_interleave(memory, K) = (B*K, K, d); in early-guide mode
+                # the decoder never reads it (no cross-attention, :223-224), so it is not built here
+                memory = None
+        if obj_idx is not None:  # training (:260-261)
+            obj_indicator = obj_indicator + torch.gather(
+                memory, 1, obj_idx.repeat(1, memory.size(-1)).unsqueeze(1))
+        if self.early_guide:
+            return self.decoder(self.tgt_embed(tgt), memory, src_mask, tgt_mask, obj_indicator=obj_indicator)
+        return self.decoder(self.tgt_embed(tgt), obj_indicator, None, tgt_mask, None)
+
+
+class TransformerDecoderModel(nn.Module):
+    def __init__(self, vocabulary, N, h, d_model, d_ff, transformer_dropout, bn_momentum=0.1, src_pos_type=None,
+                 use_transformer_encoder=False, early_guide=True, check_relation=False, store_attn_all=False):
+        super().__init__()
+        self.word_to_idx = vocabulary["word2idx"]
+        self.src_pos_type = src_pos_type
+        self.vocabulary = vocabulary
+        self.use_transformer_encoder = use_transformer_encoder
+        self.check_relation = check_relation
+        self.early_guide = early_guide
+        self.store_attn_all = store_attn_all
+        self.model = self.make_model(len(vocabulary["word2idx"]), N=N, h=h, d_model=d_model, d_ff=d_ff,
+                                     dropout=transformer_dropout, bn_momentum=bn_momentum,
+                                     src_pos_type=src_pos_type, use_transformer_encoder=use_transformer_encoder,
+                                     early_guide=early_guide)
+        if check_relation:
+            self.relation_proposal = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(),
+                                                   nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, 9))
+        if store_attn_all:
+            for mod in self.modules():
+                if isinstance(mod, MultiHeadedAttention):
+                    mod.store_attn = True
+
+    def make_model(self, tgt_vocab, N=6, h=8, d_model=512, d_ff=2048, dropout=0.1, bn_momentum=0.1,
+                   src_pos_type=None, use_transformer_encoder=False, early_guide=True):
+        c = copy.deepcopy
+        attn = MultiHeadedAttention(h, d_model)
+        ff = PositionwiseFeedForward(d_model, d_ff, dropout)
+        position = PositionalEncoding(d_model, dropout)
+        if src_pos_type is not None:
+            src_position = PositionalEncodingLearned(3 if src_pos_type in ("xyz", "center") else 6, d_model)
+        else:
+            src_position = c(position)
+        encoder = None
+        if use_transformer_encoder:
+            # only the LAST encoder layer's P and V are read (relation head), the reference keeps all six
+            layer = EncoderLayer(d_model, MultiHeadedAttention(h, d_model, keep_value=False), c(ff), dropout)
+            encoder = Encoder(layer, N)
+            encoder.layers[-1].self_attn.keep_value = self.check_relation
+        model = EncoderDecoder(
+            encoder,
+            Decoder(DecoderLayer(d_model, c(attn), c(attn), c(ff), dropout, early_guide), N),
+            src_position if use_transformer_encoder else _Identity(),
+            nn.Sequential(Embeddings(d_model, tgt_vocab), c(position)),
+            Generator(d_model, tgt_vocab), early_guide=early_guide)
+        for p in model.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.momentum = bn_momentum
+        return model
+
+    def _prepare_feature(self, seq):
+        seq = seq[:, :-1] if self.early_guide else seq[:, 1:-1]
+        seq_mask = (seq > 0).unsqueeze(-2)
+        seq_mask = seq_mask & subsequent_mask(seq.size(-1), device=seq.device)
+        return (seq[:, 1:] if self.early_guide else seq), seq_mask
+
+    def forward(self, data_dict, is_eval=False):
+        return self.forward_eval(data_dict) if is_eval else self.forward_train(data_dict)
+
+    def _src_pos(self, ep):
+        if self.src_pos_type == "xyz":
+            return ep["aggregated_vote_xyz"]
+        if self.src_pos_type == "center":
+            return ep["center"]
+        if self.src_pos_type == "loc":
+            return torch.cat([ep["center"], ep["pred_size"]], -1)
+        return None
+
+    def relation_feature(self):
+        """R[b,i,j,h*16+d] = P[b,h,i,j] * V[b,h,j,d] of the last encoder layer (:393-396)."""
+        sa = self.model.encoder.layers[-1].self_attn
+        P, V = sa.attn, sa.value                      # (B,h,K,K), (B,h,K,d_k)
+        B, H, K, _ = P.shape
+        R = P.unsqueeze(-1) * V.unsqueeze(-3)         # (B,h,K,K,d_k)
+        return R.permute(0, 2, 3, 1, 4).reshape(B, K, K, H * V.shape[-1])
+
+    def forward_train(self, ep):
+        src = ep["aggregated_vote_features"]
+        src_pos = self._src_pos(ep)
+        _, _, target_ious, idx = nn_distance(ep["aggregated_vote_xyz"], ep["ref_center_label"].unsqueeze(1))
+        ep["match_idx"] = idx.squeeze(1)
+        ref_obj_feature = torch.gather(src, 1, idx.repeat(1, src.size(-1)).unsqueeze(1))
+        seq, seq_mask = self._prepare_feature(ep["lang_label"])
+        out = self.model(src=src, tgt=seq, src_mask=ep["bbox_mask"].unsqueeze(1), tgt_mask=seq_mask,
+                         obj_indicator=ref_obj_feature, src_pos=src_pos,
+                         obj_idx=idx if self.use_transformer_encoder else None)
+        out = out[:, 1:, :] if self.early_guide else out
+        ep["lang_cap"] = self.model.generator(out)
+        good = (target_ious > -1).squeeze(1)
+        # mean over the good boxes without a host sync (the reference branches on .sum() > 0, :385)
+        n_good = good.sum()
+        ep["pred_ious"] = (target_ious.squeeze(1) * good).sum() / n_good.clamp(min=1)
+        ep["good_bbox_masks"] = good
+        if self.check_relation:
+            ep["relation_pred"] = self.relation_proposal(self.relation_feature())
+        return ep
+
+    def forward_eval(self, ep):
+        """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder at every
+        one of the 31 steps; the encoder output does not depend on the words, so it is computed once."""
+        obj_features = ep["aggregated_vote_features"]
+        B, K, _ = obj_features.shape
+        src_pos = self._src_pos(ep)
+        if not self.use_transformer_encoder:
+            src = torch.repeat_interleave(obj_features, K, dim=0)
+            if src_pos is not None:
+                src_pos = torch.repeat_interleave(src_pos, K, dim=0)
+        else:
+            src = obj_features
+        src_mask = ep["bbox_mask"].unsqueeze(1)
+        if self.model.encoder is None:
+            memory = self.model.src_embed(src, src_pos) if src_pos is not None else src
+        else:
+            memory = self.model.encode(src, src_pos, src_mask)
+        obj_flat = obj_features.reshape(B * K, -1)
+        ys = torch.full((B * K, 1), self.word_to_idx["sos"], dtype=torch.long, device=obj_features.device)
+        for _ in range(MAX_DES_LEN + 1):
+            L = ys.size(1) + 1 if self.early_guide else ys.size(1)
+            out = self.model(src, ys, src_mask, subsequent_mask(L, device=ys.device),
+                             obj_flat.unsqueeze(1), src_pos=src_pos, memory=memory)
+            prob = self.model.generator(out[:, -1, :])
+            next_word = prob.argmax(dim=-1)
+            ys = torch.cat([ys, next_word.unsqueeze(1)], dim=1)
+        ep["lang_cap"] = ys[:, 1:].view(B, K, -1)
+        return ep
