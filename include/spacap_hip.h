@@ -124,26 +124,30 @@ int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
  *          models/transformer_captioner.py:68)
  *  p_out   f32 [B,h,Lq,Lk] dense or NULL: the post-dropout attention matrix the reference returns
  *          as `p_attn` and stores as `self.attn` (models/transformer_captioner.py:63)
- *  lse     f32 [B,h,Lq] dense: log-sum-exp of the masked logits, consumed by backward. */
+ *  stats   f32 [B,h,Lq,2] dense: (row max, row sum of exp) of the masked logits, consumed by backward
+ *          (kept as a pair rather than one log-sum-exp: a fully masked row has max = -1e9, where
+ *          max + log(sum) is not representable in fp32). */
 int spacap_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                        const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
                        int d_k, float scale, float dropout_p, uint64_t seed, float *out,
-                       float *p_out, float *lse, spacap_stream_t stream);
+                       float *p_out, float *stats, spacap_stream_t stream);
 
-/* Backward of the above.  d_out f32 [B,Lq,h,d_k] dense; d_p f32 [B,h,Lq,Lk] dense or NULL is the
- * gradient w.r.t. the returned post-dropout p_attn (non-NULL for the encoder layer that feeds
- * the relation head, models/transformer_captioner.py:392-394).  Outputs dq,dk,dv f32
- * [B,L,h,d_k] dense (the layout of the projections before `.transpose(1,2)`); dk and dv are
- * zero-filled here and accumulated. */
+/* Backward of the above (two launches, no atomics, bitwise reproducible).  d_out f32 [B,Lq,h,d_k]
+ * dense; d_p f32 [B,h,Lq,Lk] dense or NULL is the gradient w.r.t. the returned post-dropout p_attn
+ * (non-NULL for the encoder layer that feeds the relation head,
+ * models/transformer_captioner.py:392-394).  `workspace`: spacap_mha_bwd_workspace_bytes(B,h,Lq)
+ * bytes of scratch.  Outputs dq f32 [B,Lq,h,d_k], dk,dv f32 [B,Lk,h,d_k] dense (the layout of the
+ * projections before `.transpose(1,2)`); every element is written. */
+size_t spacap_mha_bwd_workspace_bytes(int B, int h, int Lq);
 int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                        const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
-                       int d_k, float scale, float dropout_p, uint64_t seed, const float *lse,
-                       const float *d_out, const float *d_p, float *dq, float *dk, float *dv,
-                       spacap_stream_t stream);
+                       int d_k, float scale, float dropout_p, uint64_t seed, const float *stats,
+                       const float *d_out, const float *d_p, void *workspace, float *dq, float *dk,
+                       float *dv, spacap_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -57,7 +57,7 @@ class FusedAttention(Function):
         with torch.cuda.device(q.device):
             out = torch.empty(B, Lq, h, dk, dtype=torch.float32, device=q.device)
             p = torch.empty(B, h, Lq, Lk, dtype=torch.float32, device=q.device) if need_p else None
-            lse = torch.empty(B, h, Lq, dtype=torch.float32, device=q.device)
+            lse = torch.empty(B, h, Lq, 2, dtype=torch.float32, device=q.device)  # (row max, row sum)
             bs = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else (0, 0, 0)
             check(lib.spacap_mha_fwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), *_strides3(q), *_strides3(k), *_strides3(v),
@@ -86,13 +86,15 @@ class FusedAttention(Function):
             dq = torch.empty(B, Lq, h, dk, dtype=torch.float32, device=q.device)
             dk_ = torch.empty(B, Lk, h, dk, dtype=torch.float32, device=q.device)
             dv = torch.empty(B, Lk, h, dk, dtype=torch.float32, device=q.device)
+            ws = torch.empty(max(int(lib.spacap_mha_bwd_workspace_bytes(B, h, Lq)), 16), dtype=torch.uint8,
+                             device=q.device)
             bs = (bias.stride(0), bias.stride(1), bias.stride(2)) if bias is not None else (0, 0, 0)
             check(lib.spacap_mha_bwd_f32(
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), *_strides3(q), *_strides3(k), *_strides3(v),
                 mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq,
                 bias.data_ptr() if bias is not None else None, *bs,
                 B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed), lse.data_ptr(),
-                d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None,
+                d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None, ws.data_ptr(),
                 dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(),
                 torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_bwd_f32")
         return (dq.transpose(1, 2), dk_.transpose(1, 2), dv.transpose(1, 2), None, None, None, None, None, None,

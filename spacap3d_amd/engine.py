@@ -1,0 +1,58 @@
+"""Minimal training engine for the hot path: forward of SpaCapNet + total loss + backward + the single
+gradient all-reduce + Adam -- what ``Solver._forward/_compute_loss/_backward`` do per iteration in the
+reference (lib/solver.py:343-385), without its host synchronisations (``.item()`` x9, timers,
+CUDA_LAUNCH_BLOCKING=1) and without logging / checkpointing (out of scope).
+"""
+import torch
+
+from . import synthetic as S
+from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
+from .loss_helper import get_scene_cap_loss
+
+
+class Trainer:
+    def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
+                 use_relation: bool = True):
+        self.model = model
+        self.mean_size_arr = mean_size_arr
+        self.use_relation = use_relation
+        self.lr, self.weight_decay = lr, weight_decay
+        self.bucket = None
+        self.optimizer = None
+        broadcast_parameters(model)
+
+    def loss(self, data_dict):
+        d = self.model(dict(data_dict))
+        d = get_scene_cap_loss(d, use_relation=self.use_relation, mean_size_arr=self.mean_size_arr)
+        return d
+
+    def _setup(self, data_dict):
+        """First step: discover which parameters the loss reaches, then lay their gradients out in one flat
+        bucket and build Adam over exactly those (scripts/train.py:262: Adam lr 1e-3, weight_decay 1e-5)."""
+        d = self.loss(data_dict)
+        used = used_parameters(self.model, d["loss"])
+        self.bucket = FlatGradBucket(used)
+        kw = dict(lr=self.lr, weight_decay=self.weight_decay)
+        try:
+            self.optimizer = torch.optim.Adam(used, fused=used[0].is_cuda, **kw)
+        except (RuntimeError, TypeError):
+            self.optimizer = torch.optim.Adam(used, **kw)
+
+    def step(self, data_dict):
+        """One full training step; returns the (device) loss tensor, no host sync."""
+        if self.bucket is None:
+            self._setup(data_dict)
+        self.bucket.zero()
+        d = self.loss(data_dict)
+        d["loss"].backward()
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        return d["loss"].detach()
+
+
+def synthetic_batch(batch: int, n_points: int, device, seed: int = 0, vocab: int = 3001, use_color=False,
+                    use_normal=False, use_multiview=False, use_height=True):
+    d = {"point_clouds": S.scene_batch(batch, n_points, use_color=use_color, use_normal=use_normal,
+                                       use_multiview=use_multiview, use_height=use_height, seed=seed)}
+    d.update(S.labels(batch, n_points, vocab=vocab, seed=seed))
+    return {k: v.to(device) for k, v in d.items()}
