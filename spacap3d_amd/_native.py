@@ -7,6 +7,12 @@ this module raises, and every operator raises ``RuntimeError`` on a non-zero ret
 import ctypes
 import os
 
+# torch must be imported BEFORE the library is dlopen'ed: torch ships its own libamdhip64.so and loads it
+# RTLD_GLOBAL; loaded after it, libspacap_hip.so binds its hip* symbols to that same runtime, so the
+# hipStream_t handles torch hands us are valid.  Loaded first, it would bind to /opt/rocm's runtime and the
+# process would hold two HIP runtimes ("no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspacap_hip.so")
 ABI_VERSION = 1

@@ -1,0 +1,100 @@
+"""World-size-2 CPU (gloo) tests of the data-parallel path: scene sharding, parameter broadcast, and the single
+flat-bucket gradient all-reduce; two ranks on half batches must produce the gradients / weights of one rank on the
+full batch for a batch-separable model (BatchNorm statistics are per rank by design, as under DataParallel)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from spacap3d_amd.distributed import FlatGradBucket, broadcast_parameters, shard_scenes
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _make_model(seed=100 + rank)  # ranks start DIFFERENT; broadcast must align them
+        broadcast_parameters(model)
+        bucket = FlatGradBucket(model.parameters())
+        opt = torch.optim.Adam(bucket.params, lr=1e-2)
+        g = torch.Generator().manual_seed(0)
+        X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+        mine = list(shard_scenes(8, rank, world))
+        for _ in range(3):
+            bucket.zero()
+            loss = ((model(X[mine]) - Y[mine]) ** 2).mean()
+            loss.backward()
+            bucket.all_reduce_mean()
+            opt.step()
+        out_q.put((rank, [p.detach().clone() for p in model.parameters()], bucket.flat.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_full_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict()
+    for _ in range(2):
+        r, params, flat = q.get(timeout=120)
+        results[r] = (params, flat)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, full batch, starting from rank 0's weights
+    model = _make_model(seed=100)
+    bucket = FlatGradBucket(model.parameters())
+    opt = torch.optim.Adam(bucket.params, lr=1e-2)
+    g = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 3, generator=g)
+    for _ in range(3):
+        bucket.zero()
+        ((model(X) - Y) ** 2).mean().backward()
+        bucket.all_reduce_mean()  # no-op without a process group
+        opt.step()
+    for r in (0, 1):
+        for a, b in zip(results[r][0], model.parameters()):
+            torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(results[0][1], results[1][1])  # both ranks hold the same reduced gradient bucket
+
+
+def test_flat_bucket_views_and_zero():
+    m = _make_model(0)
+    b = FlatGradBucket(m.parameters())
+    assert b.flat.numel() == sum(p.numel() for p in m.parameters())
+    m(torch.ones(2, 6)).sum().backward()
+    assert float(b.flat.abs().sum()) > 0
+    for p in m.parameters():
+        assert p.grad.data_ptr() >= b.flat.data_ptr()
+    b.zero()
+    assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+
+
+def test_shard_scenes_partitions_the_batch():
+    seen = []
+    for r in range(4):
+        seen += list(shard_scenes(64, r, 4))
+    assert seen == list(range(64))
+    with pytest.raises(AssertionError):
+        shard_scenes(10, 0, 4)

@@ -1,0 +1,152 @@
+"""The CPU oracle itself (runs everywhere, no GPU): the C restatement against
+  * an independent, thread-by-thread pure-Python simulation of the reference CUDA blocks (oracle/literal_py.py),
+  * the one known-answer input set the reference ships for this path (lib/pointnet2/pointnet2_test.py:14-26),
+  * hand-derived edge cases (skip rule, empty balls, padding, ties, m < 3 neighbours).
+The reference holds no golden vectors for FPS / ball_query / group / gather / three_nn ("parity unpinned").
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import literal_py as L
+from spacap3d_amd import synthetic as S
+
+
+@pytest.mark.parametrize("n,m", [(37, 37), (100, 30), (512, 100), (700, 64), (1500, 50)])
+@pytest.mark.parametrize("kind", ["lattice", "room"])
+def test_fps_c_matches_literal_simulation(oracle_ext, n, m, kind):
+    rng = np.random.default_rng(n)
+    if kind == "lattice":  # many exact ties -> exercises the tree tie-break
+        pts = rng.integers(0, 4, size=(n, 3)).astype(np.float32) * 0.5
+        pts[5] = 0.0
+    else:
+        pts = S.room_xyz(n, torch.Generator().manual_seed(n)).numpy()
+    got = oracle_ext.furthest_point_sampling(torch.from_numpy(pts)[None], m)[0].numpy()
+    assert np.array_equal(got, L.fps_literal(pts, m))
+
+
+def test_fps_semantics_by_hand(oracle_ext):
+    # 4 collinear points: start at 0, then the farthest (3), then the one maximising the min distance
+    pts = torch.tensor([[[1.0, 0, 0], [2.0, 0, 0], [4.0, 0, 0], [8.0, 0, 0]]])
+    assert oracle_ext.furthest_point_sampling(pts, 4)[0].tolist() == [0, 3, 2, 1]
+    # a point with |p|^2 <= 1e-3 is never selected (but index 0 is always the start)
+    pts = torch.tensor([[[1.0, 0, 0], [0.01, 0.0, 0.0], [3.0, 0, 0], [2.0, 0, 0]]])
+    assert oracle_ext.furthest_point_sampling(pts, 4)[0].tolist() == [0, 2, 3, 0]  # after 3 valid points: d2=0 ties -> key order
+    # all skipped -> zeros
+    assert oracle_ext.furthest_point_sampling(torch.full((1, 9, 3), 0.001), 5)[0].tolist() == [0] * 5
+
+
+def test_fps_tie_break_is_bit_reversed_slot_order(oracle_ext):
+    """n = 8 -> block of 8 threads; all points but #0 equidistant from #0: the tree prefers slot bit-reversal
+    order 0,4,2,6,1,5,3,7 among equal values, so the second pick is index 4."""
+    pts = torch.zeros(1, 8, 3)
+    pts[0, 0] = torch.tensor([5.0, 0.0, 0.0])
+    for i in range(1, 8):
+        pts[0, i] = torch.tensor([5.0, 1.0, 0.0])  # duplicates: same distance 1 from point 0
+    assert oracle_ext.opt_n_threads(8) == 8
+    assert oracle_ext.furthest_point_sampling(pts, 2)[0].tolist() == [0, 4]
+
+
+def test_opt_n_threads_matches_the_double_log_formula(oracle_ext):
+    for w in list(range(1, 70)) + [127, 128, 129, 511, 512, 513, 1000, 1024, 40000, 80000, 2 ** 20]:
+        want = max(min(1 << int(math.log(float(w)) / math.log(2.0)), 512), 1)
+        assert oracle_ext.opt_n_threads(w) == want == L.opt_n_threads(w)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(700, 20, 0.2, 8), (300, 15, 0.5, 4), (64, 5, 0.01, 3)])
+def test_ball_query_c_matches_literal(oracle_ext, n, m, r, ns):
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3)).astype(np.float32)
+    ctr = pts[rng.choice(n, m, replace=False)].copy()
+    ctr[-1] += 9.0  # empty ball
+    got = oracle_ext.ball_query(torch.from_numpy(ctr)[None].contiguous(), torch.from_numpy(pts)[None], r, ns)[0].numpy()
+    assert np.array_equal(got, L.ball_query_literal(ctr, pts, r, ns))
+    assert (got[-1] == 0).all()
+
+
+def test_ball_query_semantics_by_hand(oracle_ext):
+    xyz = torch.tensor([[[0.0, 0, 0], [0.1, 0, 0], [5.0, 0, 0], [0.05, 0, 0], [0.2, 0, 0]]])
+    ctr = torch.tensor([[[0.0, 0, 0], [9.0, 9, 9]]])
+    idx = oracle_ext.ball_query(ctr, xyz, 0.15, 4)[0]
+    assert idx[0].tolist() == [0, 1, 3, 0]   # first 3 hits in index order, padded with the first hit
+    assert idx[1].tolist() == [0, 0, 0, 0]   # empty ball -> zeros
+    # strict '<': a point at exactly radius is outside (0.25^2 = 0.0625 exactly representable)
+    xyz = torch.tensor([[[0.25, 0, 0], [0.125, 0, 0]]])
+    assert oracle_ext.ball_query(torch.zeros(1, 1, 3), xyz, 0.25, 2)[0, 0].tolist() == [1, 1]
+    # nsample reached -> later hits ignored
+    xyz = torch.zeros(1, 10, 3)
+    assert oracle_ext.ball_query(torch.zeros(1, 1, 3), xyz, 1.0, 3)[0, 0].tolist() == [0, 1, 2]
+
+
+@pytest.mark.parametrize("n,m", [(50, 20), (30, 2), (10, 1)])
+def test_three_nn_c_matches_literal(oracle_ext, n, m):
+    rng = np.random.default_rng(n + m)
+    u = rng.random((n, 3)).astype(np.float32)
+    k = rng.random((m, 3)).astype(np.float32)
+    if m > 3:
+        k[2] = k[0]
+    d2, idx = oracle_ext.three_nn(torch.from_numpy(u)[None], torch.from_numpy(k)[None])
+    dl, il = L.three_nn_literal(u, k)
+    assert np.array_equal(idx[0].numpy(), il) and np.array_equal(d2[0].numpy(), dl)
+    if m < 3:
+        assert np.isinf(d2[0].numpy()[:, m:]).all() and (idx[0].numpy()[:, m:] == 0).all()
+
+
+def test_reference_known_answer_three_interpolate(oracle_ext):
+    """Inputs of lib/pointnet2/pointnet2_test.py:14-26 (idx [[0,1,2],[1,2,3]], weight [[1,1,1],[2,2,2]]); that
+    test gradchecks the op, i.e. asserts backward == d(forward)/d(features); both are checked in closed form."""
+    feats = torch.tensor([[[1.0, 2.0, 3.0, 4.0], [-1.0, 0.5, 2.5, 8.0]]])
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32)
+    w = torch.tensor([[[1.0, 1.0, 1.0], [2.0, 2.0, 2.0]]])
+    out = oracle_ext.three_interpolate(feats, idx, w)
+    assert torch.equal(out, torch.tensor([[[6.0, 18.0], [2.0, 22.0]]]))
+    g = oracle_ext.three_interpolate_grad(torch.ones(1, 2, 2), idx, w, 4)
+    assert torch.equal(g, torch.tensor([[[1.0, 3.0, 3.0, 2.0], [1.0, 3.0, 3.0, 2.0]]]))
+    # the Jacobian is linear in the features: finite differences are exact up to rounding
+    eps = 0.5
+    for c in range(2):
+        for j in range(4):
+            f2 = feats.clone()
+            f2[0, c, j] += eps
+            num = (oracle_ext.three_interpolate(f2, idx, w) - out).sum() / eps
+            assert abs(float(num) - float(g[0, c, j])) < 1e-5
+
+
+def test_group_gather_and_grads_against_torch_indexing(oracle_ext):
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(2, 5, 40, generator=g)
+    idx = torch.randint(0, 40, (2, 7, 3), generator=g, dtype=torch.int32)
+    out = oracle_ext.group_points(pts, idx)
+    want = torch.gather(pts.unsqueeze(2).expand(-1, -1, 7, -1), 3, idx.long().unsqueeze(1).expand(-1, 5, -1, -1))
+    assert torch.equal(out, want)
+    go = torch.randn(2, 5, 7, 3, generator=g)
+    got = oracle_ext.group_points_grad(go, idx, 40)
+    ref = torch.zeros(2, 5, 40).scatter_add_(2, idx.long().view(2, 1, 21).expand(-1, 5, -1), go.view(2, 5, 21))
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-6)
+    i1 = torch.randint(0, 40, (2, 9), generator=g, dtype=torch.int32)
+    assert torch.equal(oracle_ext.gather_points(pts, i1), torch.gather(pts, 2, i1.long().unsqueeze(1).expand(-1, 5, -1)))
+    go = torch.randn(2, 5, 9, generator=g)
+    ref = torch.zeros(2, 5, 40).scatter_add_(2, i1.long().unsqueeze(1).expand(-1, 5, -1), go)
+    torch.testing.assert_close(oracle_ext.gather_points_grad(go, i1, 40), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_openmp_build_gives_identical_results():
+    from oracle.ext_cpu import OracleExt
+    a, b = OracleExt(openmp=False), OracleExt(openmp=True)
+    xyz = S.scene_batch(3, 3000, use_height=False, seed=2)
+    ia, ib = a.furthest_point_sampling(xyz, 200), b.furthest_point_sampling(xyz, 200)
+    assert torch.equal(ia, ib)
+    ctr = torch.gather(xyz, 1, ia.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    assert torch.equal(a.ball_query(ctr, xyz, 0.3, 16), b.ball_query(ctr, xyz, 0.3, 16))
+    da, ja = a.three_nn(xyz[:, :500].contiguous(), ctr)
+    db, jb = b.three_nn(xyz[:, :500].contiguous(), ctr)
+    assert torch.equal(da, db) and torch.equal(ja, jb)
+
+
+def test_oracle_rejects_wrong_dtypes(oracle_ext):
+    with pytest.raises(RuntimeError, match="int tensor"):
+        oracle_ext.gather_points(torch.rand(1, 3, 8), torch.zeros(1, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        oracle_ext.furthest_point_sampling(torch.rand(1, 3, 8).transpose(1, 2), 2)
