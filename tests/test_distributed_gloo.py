@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_q):
             loss.backward()
             bucket.all_reduce_mean()
             opt.step()
-        out_q.put((rank, [p.detach().clone() for p in model.parameters()], bucket.flat.clone()))
+        out_q.put((rank, [p.detach().numpy().copy() for p in model.parameters()], bucket.flat.numpy().copy()))
     finally:
         dist.destroy_process_group()
 
@@ -75,8 +75,8 @@ def test_two_ranks_match_single_process_full_batch():
         opt.step()
     for r in (0, 1):
         for a, b in zip(results[r][0], model.parameters()):
-            torch.testing.assert_close(a, b.detach(), rtol=1e-5, atol=1e-6)
-    assert torch.equal(results[0][1], results[1][1])  # both ranks hold the same reduced gradient bucket
+            torch.testing.assert_close(torch.from_numpy(a), b.detach(), rtol=1e-5, atol=1e-6)
+    assert (results[0][1] == results[1][1]).all()  # both ranks hold the same reduced gradient bucket
 
 
 def test_flat_bucket_views_and_zero():
