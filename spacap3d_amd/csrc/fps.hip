@@ -11,11 +11,13 @@
 //
 // Design (not a translation): the reference streams xyz and `temp` from global memory every round and
 // spends nine __syncthreads() per round on the tree.  Here one workgroup owns a scene, every lane
-// keeps the running minimum distance of its points in VGPRs for the whole kernel (and their
-// coordinates too when they fit), the arg-max is a DPP wave reduction on the value only, and the
-// index is recovered by a second, rare pass that only the wave(s) holding the maximum execute.
-// Two barriers per round.  Skipped / padded slots carry temp = -1: fminf(d, -1) = -1 keeps them
-// out of every arg-max exactly as the reference's `continue` does.
+// keeps the running minimum distance of its points in VGPRs for the whole kernel, the arg-max is a DPP
+// wave reduction on the value only, and the index is recovered by a second, rare pass that only the
+// wave(s) holding the maximum execute.  Two barriers per round.  Skipped / padded slots carry
+// temp = -1: fminf(d, -1) = -1 keeps them out of every arg-max exactly as the reference's `continue`.
+//   N <= 8 192   : coordinates in VGPRs too (fps_kernel)
+//   N <= 65 535  : Morton-bucketed scene, whole buckets skipped when provably unaffected (fps_bucket.inc)
+//   larger       : reference-style streaming with temp in the workspace (fps_generic_kernel)
 #include "common.hpp"
 
 #pragma clang fp contract(off)
@@ -23,6 +25,14 @@
 namespace {
 
 using namespace spacap;
+
+// v_min_f32 without the canonicalising v_max hipcc emits in front of fminf (operands are never sNaN here);
+// in IEEE mode it returns the non-NaN operand, i.e. the reference's fminf (sampling_gpu.cu:106).
+__device__ __forceinline__ float vmin_f32(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 __device__ __forceinline__ float sqdist(float x2, float y2, float z2, float x1, float y1, float z1) {
   const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
@@ -78,7 +88,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 #pragma unroll
     for (int i = 0; i < TPL; ++i) {
       const float d = sqdist(px[i], py[i], pz[i], x1, y1, z1);
-      t[i] = fminf(d, t[i]);
+      t[i] = vmin_f32(d, t[i]);
       // values are -1 or >= +0 and never NaN, so signed-integer order == float order
       lmax = max(lmax, __float_as_int(t[i]));
     }
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void fps_generic_kernel(const float *__restr
     int lmax = __float_as_int(-1.0f);
     for (int k = tid; k < N; k += BLOCK) {
       const float d = sqdist(xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2], x1, y1, z1);
-      const float d2 = fminf(d, temp[k]);
+      const float d2 = vmin_f32(d, temp[k]);
       temp[k] = d2;
       lmax = max(lmax, __float_as_int(d2));
     }
@@ -170,168 +180,24 @@ __global__ __launch_bounds__(BLOCK) void fps_generic_kernel(const float *__restr
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Large scenes (20 480 < N <= 40 960): one 1024-thread workgroup per scene cannot hold 40 points x
-// (x, y, z, temp) per lane in its 128 VGPRs, and re-reading xyz from L2 every round costs ~3 us/round
-// (480 KB at ~64 B/clk/CU).  So the lane's points are split three ways, in groups of four
-// consecutive points (one 16-byte access per coordinate plane):
-//   G_REG groups  coordinates in VGPRs for the whole kernel,
-//   G_LDS groups  coordinates in LDS ([group][plane][lane] float4: conflict-free ds_read_b128),
-//   G_STR groups  coordinates re-read every round from a structure-of-arrays copy of the scene in the
-//                 caller's workspace (coalesced buffer_load_dwordx4, one group prefetched ahead),
-// while every temp stays in VGPRs.  Point k belongs to group g = k / 4096, lane (k / 4) % 1024.
 using f32x4 = float __attribute__((ext_vector_type(4)));
-using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x4 sqdist4(f32x4 x, f32x4 y, f32x4 z, float x1, float y1, float z1) {
-  const f32x4 dx = x - x1, dy = y - y1, dz = z - z1;
-  return dx * dx + dy * dy + dz * dz;
-}
-
-__device__ __forceinline__ int update4(f32x4 &t, f32x4 d, int lmax) {
-  t.x = fminf(d.x, t.x); t.y = fminf(d.y, t.y); t.z = fminf(d.z, t.z); t.w = fminf(d.w, t.w);
-  lmax = max(lmax, max(__float_as_int(t.x), __float_as_int(t.y)));
-  return max(lmax, max(__float_as_int(t.z), __float_as_int(t.w)));
-}
-
-template <int G_REG, int G_LDS, int G_STR>
-__global__ __launch_bounds__(1024) void fps_hybrid_kernel(const float *__restrict__ xyz_all,
-                                                          float *__restrict__ ws_all, int N, int m, int lg,
-                                                          int32_t *__restrict__ idx_all) {
-  constexpr int BLOCK = 1024, NW = 16, G = G_REG + G_LDS + G_STR;
-  constexpr int NPAD = G * 4 * BLOCK;
-  __shared__ __attribute__((aligned(16))) f32x4 s_pts[(G_LDS > 0 ? G_LDS : 1) * 3 * BLOCK];
-  __shared__ int s_wmax[16];
-  __shared__ unsigned s_key[2];
-
-  const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * N * 3;
-  float *__restrict__ planes = ws_all + (size_t)blockIdx.x * 3 * NPAD;  // x[NPAD] y[NPAD] z[NPAD]
-  int32_t *__restrict__ idxs = idx_all + (size_t)blockIdx.x * m;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-
-  f32x4 t[G];
-  f32x4 rx[G_REG > 0 ? G_REG : 1], ry[G_REG > 0 ? G_REG : 1], rz[G_REG > 0 ? G_REG : 1];
-
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    const int k0 = (g * BLOCK + tid) * 4;
-    f32x4 x, y, z, tt;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u;
-      const int kk = k < N ? k : N - 1;
-      const float px = xyz[kk * 3 + 0], py = xyz[kk * 3 + 1], pz = xyz[kk * 3 + 2];
-      const float mag = (px * px) + (py * py) + (pz * pz);
-      const bool skip = (k >= N) || ((double)mag <= 1e-3);
-      x[u] = px; y[u] = py; z[u] = pz;
-      tt[u] = skip ? -1.0f : 1e10f;
-    }
-    t[g] = tt;
-    if (g < G_REG) {
-      rx[g] = x; ry[g] = y; rz[g] = z;
-    } else if (g < G_REG + G_LDS) {
-      const int l = g - G_REG;
-      s_pts[(l * 3 + 0) * BLOCK + tid] = x;
-      s_pts[(l * 3 + 1) * BLOCK + tid] = y;
-      s_pts[(l * 3 + 2) * BLOCK + tid] = z;
-    } else {
-      *reinterpret_cast<f32x4 *>(planes + 0 * NPAD + k0) = x;
-      *reinterpret_cast<f32x4 *>(planes + 1 * NPAD + k0) = y;
-      *reinterpret_cast<f32x4 *>(planes + 2 * NPAD + k0) = z;
-    }
-  }
-  if (tid == 0) {
-    idxs[0] = 0;
-    s_key[0] = 0xFFFFFFFFu;
-    s_key[1] = 0xFFFFFFFFu;
-  }
-  __threadfence_block();
-  __syncthreads();
-
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void *)planes, 0, 3 * NPAD * 4, 0x00020000);
-  const int voff = tid * 16;
-
-  int old = 0;
-  for (int j = 1; j < m; ++j) {
-    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
-    int lmax = __float_as_int(-1.0f);
-
-    f32x4 sx[2], sy[2], sz[2];
-    if (G_STR > 0) {  // first streamed group goes out before any arithmetic
-      const int soff = G_REG + G_LDS;
-      sx[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (0 * NPAD + soff * 4 * BLOCK) * 4, 0));
-      sy[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (1 * NPAD + soff * 4 * BLOCK) * 4, 0));
-      sz[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (2 * NPAD + soff * 4 * BLOCK) * 4, 0));
-    }
-#pragma unroll
-    for (int g = 0; g < G_REG; ++g) lmax = update4(t[g], sqdist4(rx[g], ry[g], rz[g], x1, y1, z1), lmax);
-#pragma unroll
-    for (int l = 0; l < G_LDS; ++l) {
-      const f32x4 x = s_pts[(l * 3 + 0) * BLOCK + tid];
-      const f32x4 y = s_pts[(l * 3 + 1) * BLOCK + tid];
-      const f32x4 z = s_pts[(l * 3 + 2) * BLOCK + tid];
-      lmax = update4(t[G_REG + l], sqdist4(x, y, z, x1, y1, z1), lmax);
-    }
-#pragma unroll
-    for (int q = 0; q < G_STR; ++q) {
-      if (q + 1 < G_STR) {
-        const int gq = G_REG + G_LDS + q + 1;
-        sx[(q + 1) & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (0 * NPAD + gq * 4 * BLOCK) * 4, 0));
-        sy[(q + 1) & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (1 * NPAD + gq * 4 * BLOCK) * 4, 0));
-        sz[(q + 1) & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (2 * NPAD + gq * 4 * BLOCK) * 4, 0));
-      }
-      asm volatile("" ::: "memory");
-      lmax = update4(t[G_REG + G_LDS + q], sqdist4(sx[q & 1], sy[q & 1], sz[q & 1], x1, y1, z1), lmax);
-    }
-
-    const int wmax = wave_max_i32(lmax);
-    if (lane == 0) s_wmax[wid] = wmax;
-    __syncthreads();
-    int M = s_wmax[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) M = max(M, s_wmax[w]);
-    if (wmax == M && M >= 0) {
-      unsigned key = 0xFFFFFFFFu;
-      int lgv = lg;
-      asm volatile("" : "+s"(lgv));  // keep the key arithmetic inside this rare branch (no hoist, no spill)
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned ki = fps_key((g * BLOCK + tid) * 4 + u, lgv);
-          key = (__float_as_int(t[g][u]) == M) ? min(key, ki) : key;
-        }
-      }
-      key = wave_min_u32(key);
-      if (lane == 0) atomicMin(&s_key[j & 1], key);
-    }
-    __syncthreads();
-    const unsigned key = s_key[j & 1];
-    if (tid == 0) s_key[(j + 1) & 1] = 0xFFFFFFFFu;
-    old = (M < 0) ? 0 : fps_unkey(key, lg);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (tid == 0) idxs[j] = old;
-  }
-}
+// Large scenes (8 192 < N <= 65 535): spatially bucketed kernel with exact pruning.
+#include "fps_bucket.inc"
 
 template <int BLOCK, int TPL>
 void launch_fps(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hipStream_t s) {
   hipLaunchKernelGGL((fps_kernel<BLOCK, TPL>), dim3(B), dim3(BLOCK), 0, s, xyz, N, m, lg, idx);
 }
 
-template <int G_REG, int G_LDS, int G_STR>
-void launch_fps_hybrid(const float *xyz, float *ws, int B, int N, int m, int lg, int32_t *idx, hipStream_t s) {
-  hipLaunchKernelGGL((fps_hybrid_kernel<G_REG, G_LDS, G_STR>), dim3(B), dim3(1024), 0, s, xyz, ws, N, m, lg, idx);
-}
-
 }  // namespace
 
-// Workspace: the structure-of-arrays copy used by the hybrid kernel (3 planes of 40 960 floats per
-// scene) or the reference-style temp array (N floats per scene) of the generic kernel.
+// Workspace: the bucket-ordered structure-of-arrays copy of the bucketed kernel (3 planes of ceil(N/4096)*4096
+// floats per scene) or the reference-style temp array (N floats per scene) of the generic kernel.
 extern "C" size_t spacap_fps_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
-  const size_t per_scene = (size_t)(N > 3 * 40960 ? N : 3 * 40960) * sizeof(float);
+  const size_t planes = N <= 65535 ? fps_bucket_workspace_floats(N) : 0;
+  const size_t per_scene = (planes > (size_t)N ? planes : (size_t)N) * sizeof(float);
   return (size_t)B * per_scene;
 }
 
@@ -360,21 +226,14 @@ extern "C" int spacap_fps_f32(const float *xyz, int B, int N, int m, void *works
   FPS_CASE(256, 8)
   FPS_CASE(1024, 4)
   FPS_CASE(1024, 8)
-  FPS_CASE(1024, 16)
-  FPS_CASE(1024, 20)
 #undef FPS_CASE
   SPACAP_REQUIRE(workspace, "spacap_fps_f32: workspace required for N=%d", N);
   float *ws = reinterpret_cast<float *>(workspace);
-#define FPS_HYB(GR, GL, GS)                                                \
-  if (N <= 4096 * ((GR) + (GL) + (GS))) {                                  \
-    launch_fps_hybrid<GR, GL, GS>(xyz, ws, B, N, m, lg, idx, s);           \
-    SPACAP_CHECK_LAUNCH("spacap_fps_f32(hybrid)");                         \
-    return SPACAP_OK;                                                      \
+  if (N <= 65535) {  // u16 slot -> index map in LDS
+    launch_fps_bucket(xyz, ws, B, N, m, lg, idx, s);
+    SPACAP_CHECK_LAUNCH("spacap_fps_f32(bucket)");
+    return SPACAP_OK;
   }
-  FPS_HYB(3, 3, 0)
-  FPS_HYB(3, 3, 2)
-  FPS_HYB(3, 3, 4)
-#undef FPS_HYB
   hipLaunchKernelGGL((fps_generic_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, ws, N, m, lg, idx);
   SPACAP_CHECK_LAUNCH("spacap_fps_f32(generic)");
   return SPACAP_OK;

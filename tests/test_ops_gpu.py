@@ -18,10 +18,11 @@ def _scene(n, seed, B=2):
     return S.scene_batch(B, n, use_height=False, seed=seed)  # (B, n, 3)
 
 
-FPS_CASES = [  # (N, m) -- every kernel variant: 1-wave, 256-thread, 1024-thread register, hybrid, generic
+FPS_CASES = [  # (N, m) -- every kernel variant: 1-wave, 256-thread, 1024-thread register, bucketed (NB 3..16), generic
     (37, 37), (64, 16), (100, 30), (128, 128), (300, 64), (512, 256), (700, 100), (1024, 256), (1024, 512),
-    (2048, 1024), (3000, 200), (4096, 512), (8192, 128), (10000, 256), (20000, 256), (24576, 64),
-    (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (80000, 96),
+    (2048, 1024), (3000, 200), (4096, 512), (8192, 128), (8193, 100), (10000, 256), (12288, 64), (16000, 300),
+    (20000, 256), (24576, 64),
+    (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (65535, 48), (65536, 48), (80000, 96),
 ]
 
 
@@ -159,3 +160,31 @@ def test_rejects_cpu_and_bad_dtypes(hip_ext):
         hip_ext.furthest_point_sampling(torch.rand(1, 3, 64, device=DEV).transpose(1, 2), 8)
     with pytest.raises(RuntimeError, match="int tensor"):
         hip_ext.gather_points(torch.rand(1, 3, 64, device=DEV), torch.zeros(1, 8, dtype=torch.int64, device=DEV))
+
+
+@pytest.mark.parametrize("kind", ["uniform_volume", "line", "all_duplicates", "two_clusters", "nan_inf"])
+def test_fps_bucketed_kernel_on_adversarial_layouts(hip_ext, oracle_ext, kind):
+    """The large-scene kernel skips whole buckets when that provably changes nothing; layouts that stress the
+    bounding-box test (degenerate boxes, huge extents, non-finite coordinates) must still be bit-exact."""
+    g = torch.Generator().manual_seed(5)
+    N, m = 30000, 300
+    if kind == "uniform_volume":
+        xyz = torch.rand(2, N, 3, generator=g) * 4
+    elif kind == "line":
+        xyz = torch.zeros(2, N, 3)
+        xyz[..., 0] = torch.rand(2, N, generator=g) * 100 + 1
+    elif kind == "all_duplicates":
+        xyz = torch.ones(2, N, 3) * 2.5
+        xyz[:, ::1000] += torch.rand(2, 30, 3, generator=g)
+    elif kind == "two_clusters":
+        xyz = torch.randn(2, N, 3, generator=g) * 0.05 + 1
+        xyz[:, N // 2:] += 1e4
+    else:
+        xyz = torch.rand(2, N, 3, generator=g) * 4 + 1
+        xyz[0, 17, 0] = float("nan")
+        xyz[0, 4000, 1] = float("inf")
+        xyz[1, 29999, 2] = float("-inf")
+    xyz = xyz.contiguous()
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    got = hip_ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
+    assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[0].tolist()}"
