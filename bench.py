@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CFG))
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the config's 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="sample inside the step instead of one step ahead")
     ap.add_argument("--cpu-sample", type=int, default=2, help="scenes in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -129,8 +130,11 @@ def main():
     # each rank owns its own shard of scenes (seed + rank), resident in HBM before the timed region
     data = synthetic_batch(per_gpu, cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
 
+    # Every step starts the furthest-point-sampling pyramid of the NEXT batch on a side stream (here the next
+    # batch is the same resident tensor, but it is recomputed every step: K timed steps = K pyramids).
+    nxt = None if args.no_prefetch else data
     for _ in range(max(1, args.warmup)):
-        trainer.step(data)
+        trainer.step(data, next_data=nxt)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -138,7 +142,7 @@ def main():
     fps_timer.on = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = trainer.step(data)
+        loss = trainer.step(data, next_data=nxt)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

@@ -84,10 +84,26 @@ int spacap_ball_query_f32(const float *new_xyz, const float *xyz, int B, int N, 
 /* group_points(points f32[B,C,N], idx i32[B,P,S]) -> f32[B,C,P,S]   (src/group_points.cpp:12-36) */
 int spacap_group_points_f32(const float *points, const int32_t *idx, int B, int C, int N, int P,
                             int S, float *out, spacap_stream_t stream);
-/* group_points_grad(grad_out f32[B,C,P,S], idx, n) -> f32[B,C,n]   (src/group_points.cpp:38-62);
- * grad_points is zero-filled here, then scatter-added. */
+/* group_points_grad(grad_out f32[B,C,P,S], idx, n) -> f32[B,C,n]   (src/group_points.cpp:38-62).
+ * With a workspace of spacap_group_points_grad_workspace_bytes() bytes (non-zero for C >= 16) the
+ * index is inverted and the gradient gathered in ascending (centre, sample) order: no float atomics,
+ * bitwise reproducible.  With workspace == NULL (or a zero size) grad_points is zero-filled and
+ * scatter-added with atomics as the reference does.  Every element of grad_points is written. */
+size_t spacap_group_points_grad_workspace_bytes(int B, int C, int N, int P, int S);
 int spacap_group_points_grad_f32(const float *grad_out, const int32_t *idx, int B, int C, int N,
-                                 int P, int S, float *grad_points, spacap_stream_t stream);
+                                 int P, int S, float *grad_points, void *workspace,
+                                 spacap_stream_t stream);
+
+/* ---- max over the samples of a group (replaces F.max_pool2d(x, [1, nsample]),
+ *      lib/pointnet2/pointnet2_modules.py:256-259) ------------------------------------------------ */
+
+/* x f32 [rows, S] dense (rows = B*C*npoint, S = nsample <= 256) -> out f32 [rows], arg u8 [rows] (index of
+ * the first maximum; a NaN wins, as in PyTorch's pooling). */
+int spacap_group_max_f32(const float *x, long rows, int S, float *out, uint8_t *arg,
+                         spacap_stream_t stream);
+/* grad_in[row, s] = (s == arg[row]) ? grad_out[row] : 0; every element of grad_in f32 [rows, S] is written. */
+int spacap_group_max_grad_f32(const float *grad_out, const uint8_t *arg, long rows, int S,
+                              float *grad_in, spacap_stream_t stream);
 
 /* ---- interpolation (replaces src/interpolate.cpp) -------------------------------------------- */
 

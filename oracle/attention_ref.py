@@ -50,3 +50,14 @@ class OracleBackend:
                   "group_points_grad"):
             setattr(self, n, getattr(self._ext, n))
         self.attention = attention
+
+    # max over the samples of a group: F.max_pool2d(x, [1, S]) of pointnet2_modules.py:256-259 (first maximum wins)
+    @staticmethod
+    def group_max(x):
+        v, i = torch.max(x, dim=3)
+        return v, i.to(torch.uint8)
+
+    @staticmethod
+    def group_max_grad(grad_out, arg, S):
+        gi = torch.zeros(*grad_out.shape, int(S), dtype=grad_out.dtype, device=grad_out.device)
+        return gi.scatter_(3, arg.long().unsqueeze(-1), grad_out.unsqueeze(-1))

@@ -35,7 +35,10 @@ SIGNATURES = {
     "spacap_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p]),
     "spacap_group_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
-    "spacap_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "spacap_group_points_grad_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
+    "spacap_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_group_max_f32": (_i, [_p, _l, _i, _p, _p, _p]),
+    "spacap_group_max_grad_f32": (_i, [_p, _p, _l, _i, _p, _p]),
     "spacap_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "spacap_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -20,6 +20,25 @@ import torch.nn.functional as F
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 
+SA_NPOINTS = (2048, 1024, 512, 256)  # backbone_module.py:29,38,47,56
+
+
+def sampling_pyramid(xyz, npoints=SA_NPOINTS):
+    """The four furthest-point-sampling index sets of the backbone, which depend on the input coordinates only
+    (SA_{l+1} samples the centres SA_l gathered): inds_l = FPS(xyz_{l-1}, npoint_l), xyz_l = xyz_{l-1}[inds_l].
+    Exactly what the four ``PointnetSAModuleVotes.forward`` calls compute (pointnet2_modules.py:237-242) --
+    factored out so a trainer can run it ahead of time on a side stream (the module accepts precomputed
+    ``inds``, pointnet2_modules.py:214,236-239)."""
+    from . import pointnet2_utils as pu
+    inds_all = []
+    cur = xyz
+    for n in npoints:
+        inds = pu.furthest_point_sample(cur, n)
+        inds_all.append(inds)
+        cur = pu.gather_operation(cur.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    return inds_all
+
+
 class Pointnet2Backbone(nn.Module):
     """4 set-abstraction + 2 feature-propagation layers (backbone_module.py:28-66)."""
 
@@ -45,13 +64,15 @@ class Pointnet2Backbone(nn.Module):
 
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
-        xyz, features, fps_inds = self.sa1(xyz, features)
+        # optional precomputed sampling pyramid (see sampling_pyramid); None -> each SA module samples itself
+        pyr = data_dict.get("fps_pyramid") or (None, None, None, None)
+        xyz, features, fps_inds = self.sa1(xyz, features, pyr[0])
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa2(xyz, features)
+        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1])
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa3(xyz, features)
+        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2])
         data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
-        xyz, features, fps_inds = self.sa4(xyz, features)
+        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3])
         data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
                             data_dict["sa4_features"])

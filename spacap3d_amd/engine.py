@@ -6,6 +6,7 @@ CUDA_LAUNCH_BLOCKING=1) and without logging / checkpointing (out of scope, SURVE
 import torch
 
 from . import synthetic as S
+from .detector import sampling_pyramid
 from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
 from .loss_helper import get_scene_cap_loss
 
@@ -19,7 +20,42 @@ class Trainer:
         self.lr, self.weight_decay = lr, weight_decay
         self.bucket = None
         self.optimizer = None
+        self.side_stream = None
         broadcast_parameters(model)
+
+    # -- sampling-pyramid prefetch ---------------------------------------------------------------------------
+    # The furthest-point sampling of the backbone is a chain of ~4 000 sequentially dependent rounds that
+    # occupies one CU per scene (8 of 256 CUs at cfg2) for ~5 ms and depends on the input coordinates only.
+    # prefetch() runs it for the NEXT batch on a side HIP stream while the current step's dense work fills the
+    # other CUs; step() then consumes the indices through the modules' `inds` argument.  Each step still
+    # computes exactly one pyramid; only its placement in time changes.
+    def prefetch(self, next_data):
+        pc = next_data["point_clouds"]
+        if not pc.is_cuda:
+            return
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=pc.device)
+        cur = torch.cuda.current_stream(pc.device)
+        self.side_stream.wait_stream(cur)
+        with torch.cuda.stream(self.side_stream), torch.no_grad():
+            pyr = sampling_pyramid(pc[..., :3].contiguous())
+            ev = torch.cuda.Event()
+            ev.record(self.side_stream)
+        next_data["_fps_prefetch"] = (pyr, ev)
+
+    @staticmethod
+    def _consume_prefetch(data_dict):
+        pre = data_dict.pop("_fps_prefetch", None)
+        if pre is None:
+            return data_dict
+        pyr, ev = pre
+        cur = torch.cuda.current_stream(pyr[0].device)
+        cur.wait_event(ev)
+        for t in pyr:
+            t.record_stream(cur)
+        d = dict(data_dict)
+        d["fps_pyramid"] = pyr
+        return d
 
     def loss(self, data_dict):
         d = self.model(dict(data_dict))
@@ -38,10 +74,14 @@ class Trainer:
         except (RuntimeError, TypeError):
             self.optimizer = torch.optim.Adam(used, **kw)
 
-    def step(self, data_dict):
-        """One full training step; returns the (device) loss tensor, no host sync."""
+    def step(self, data_dict, next_data=None):
+        """One full training step; returns the (device) loss tensor, no host sync.  ``next_data``: the batch of
+        the following step, whose sampling pyramid is started on the side stream first."""
         if self.bucket is None:
-            self._setup(data_dict)
+            self._setup({k: v for k, v in data_dict.items() if k != "_fps_prefetch"})
+        data_dict = self._consume_prefetch(data_dict)  # pops what the previous step prefetched for this batch
+        if next_data is not None:
+            self.prefetch(next_data)                   # may be the same dict object: order matters
         self.bucket.zero()
         d = self.loss(data_dict)
         d["loss"].backward()

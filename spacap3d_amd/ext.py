@@ -166,9 +166,38 @@ def group_points_grad(grad_out, idx, n):
     B, C, P, S = grad_out.shape
     with torch.cuda.device(grad_out.device):
         out = torch.empty(B, C, int(n), dtype=torch.float32, device=grad_out.device)
+        nws = int(lib.spacap_group_points_grad_workspace_bytes(B, C, int(n), P, S))
+        ws = torch.empty(nws, dtype=torch.uint8, device=grad_out.device) if nws else None
         check(lib.spacap_group_points_grad_f32(grad_out.data_ptr(), idx.data_ptr(), B, C, int(n), P, S,
-                                               out.data_ptr(), _stream(grad_out)), "group_points_grad")
+                                               out.data_ptr(), ws.data_ptr() if nws else None,
+                                               _stream(grad_out)), "group_points_grad")
     return out
+
+
+# ---- max over the samples of a group (F.max_pool2d(x, [1, nsample]) in pointnet2_modules.py:256-259) ----------
+def group_max(x):
+    """x f32 (B,C,P,S) contiguous -> (values f32 (B,C,P), arg u8 (B,C,P))."""
+    _chk_contig(x, "x"); _chk_float(x, "x"); _chk_gpu(x, "x")
+    B, C, P, S = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty(B, C, P, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, P, dtype=torch.uint8, device=x.device)
+        check(lib.spacap_group_max_f32(x.data_ptr(), B * C * P, S, out.data_ptr(), arg.data_ptr(), _stream(x)),
+              "group_max")
+    return out, arg
+
+
+def group_max_grad(grad_out, arg, S):
+    _chk_contig(grad_out, "grad_out"); _chk_float(grad_out, "grad_out"); _chk_gpu(grad_out, "grad_out")
+    _chk_contig(arg, "arg"); _chk_gpu(arg, "arg", grad_out)
+    if arg.dtype != torch.uint8:
+        raise RuntimeError("arg must be a uint8 tensor")
+    B, C, P = grad_out.shape
+    with torch.cuda.device(grad_out.device):
+        gi = torch.empty(B, C, P, int(S), dtype=torch.float32, device=grad_out.device)
+        check(lib.spacap_group_max_grad_f32(grad_out.data_ptr(), arg.data_ptr(), B * C * P, int(S), gi.data_ptr(),
+                                            _stream(grad_out)), "group_max_grad")
+    return gi
 
 
 LIB_PATH = _native.LIB_PATH

@@ -76,7 +76,7 @@ class PointnetSAModuleVotes(nn.Module):
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, C+3, npoint, nsample)
         new_features = self.mlp_module(grouped_features)                         # (B, mlp[-1], npoint, nsample)
-        new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)]).squeeze(-1)
+        new_features = pointnet2_utils.group_max(new_features)  # F.max_pool2d(x, [1, nsample]).squeeze(-1)
         return new_xyz, new_features, inds
 
 

@@ -97,6 +97,26 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class GroupMax(Function):
+    """max over the last (sample) dimension of a (B,C,npoint,nsample) tensor -- the
+    ``F.max_pool2d(x, kernel_size=[1, nsample])`` + ``squeeze(-1)`` of pointnet2_modules.py:256-271."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out, arg = ops().group_max(x.contiguous())
+        ctx.S = x.size(3)
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        return ops().group_max_grad(grad_out.contiguous(), arg, ctx.S)
+
+
+group_max = GroupMax.apply
+
+
 class BallQuery(Function):
     @staticmethod
     def forward(ctx, radius, nsample, xyz, new_xyz):

@@ -188,3 +188,35 @@ def test_fps_bucketed_kernel_on_adversarial_layouts(hip_ext, oracle_ext, kind):
     want = oracle_ext.furthest_point_sampling(xyz, m)
     got = hip_ext.furthest_point_sampling(xyz.to(DEV), m).cpu()
     assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[0].tolist()}"
+
+
+def test_group_points_grad_indexed_path_is_deterministic_and_matches_oracle_bitwise(hip_ext, oracle_ext):
+    """C >= 16 takes the inverted-index (gather) path: ascending (centre, sample) summation = the oracle's order."""
+    g = torch.Generator().manual_seed(3)
+    B, C, N, P, Sn = 2, 128, 2048, 1024, 32
+    idx = torch.randint(0, N, (B, P, Sn), generator=g, dtype=torch.int32)
+    idx[:, :, 5:] = idx[:, :, 4:5]  # ball-query style padding: long duplicate runs
+    go = torch.randn(B, C, P, Sn, generator=g)
+    want = oracle_ext.group_points_grad(go, idx, N)
+    a = hip_ext.group_points_grad(go.to(DEV), idx.to(DEV), N)
+    b = hip_ext.group_points_grad(go.to(DEV), idx.to(DEV), N)
+    assert torch.equal(a, b)
+    assert torch.equal(a.cpu(), want)
+
+
+@pytest.mark.parametrize("C,P,Sn", [(128, 2048, 64), (256, 1024, 32), (64, 512, 16), (5, 100, 7), (1, 2048, 64)])
+def test_group_max_matches_max_pool2d(hip_ext, C, P, Sn):
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(C + P)
+    x = torch.randn(2, C, P, Sn, generator=g)
+    x[:, :, :, 3:9] = x[:, :, :, 2:3]          # exact ties: the first maximum must win
+    x[0, 0, 0, 5] = float("nan")               # NaN wins, as in PyTorch's pooling
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, kernel_size=[1, Sn]).squeeze(-1)
+    w = torch.randn(2, C, P, generator=g)
+    (yr[~yr.isnan()] * w[~yr.isnan()]).sum().backward()
+    out, arg = hip_ext.group_max(x.to(DEV))
+    assert torch.equal(out.cpu().nan_to_num(123.0), yr.detach().nan_to_num(123.0))
+    w0 = w.clone(); w0[yr.isnan()] = 0
+    gi = hip_ext.group_max_grad(w0.to(DEV), arg, Sn).cpu()
+    assert torch.equal(gi, xr.grad)
