@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the config's 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="sample inside the step instead of one step ahead")
+    ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
+                                                 "relation head, 'caption' the whole captioner")
     ap.add_argument("--cpu-sample", type=int, default=2, help="scenes in the CPU-baseline sample")
     args = ap.parse_args()
 
@@ -126,7 +128,10 @@ def main():
     torch.manual_seed(0)
     model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"]).to(dev)
     model.train()
-    trainer = Trainer(model, S.mean_size_arr().numpy())
+    if args.ablate == "relation":
+        model.caption.check_relation = False
+        model.caption.model.encoder.layers[-1].self_attn.keep_value = False
+    trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"))
     # each rank owns its own shard of scenes (seed + rank), resident in HBM before the timed region
     data = synthetic_batch(per_gpu, cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
 
@@ -188,6 +193,8 @@ def main():
                        "allreduce_bytes": trainer.bucket.nbytes},
             "roofline": roof, "ops": ops, "final_loss": loss_val,
         }
+        if args.ablate:
+            line["metric"] += f" [ABLATION {args.ablate}: not the headline metric]"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
         print(json.dumps(line), flush=True)

@@ -165,6 +165,18 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
                        const float *d_out, const float *d_p, void *workspace, float *dq, float *dk,
                        float *dv, spacap_stream_t stream);
 
+/* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
+
+/* y = a * (x - mean) / (std_unbiased + eps) + b over the last dimension; x,y f32 [rows, D] dense, a,b f32 [D];
+ * stats f32 [rows, 2] = (mean, 1 / (std + eps)) is kept for backward. */
+int spacap_layernorm_fwd_f32(const float *x, const float *a, const float *b, long rows, int D, float eps,
+                             float *y, float *stats, spacap_stream_t stream);
+/* dx f32 [rows, D], da, db f32 [D] (every element written; fixed summation order, no atomics). */
+size_t spacap_layernorm_bwd_workspace_bytes(long rows, int D);
+int spacap_layernorm_bwd_f32(const float *x, const float *a, const float *stats, const float *dy, long rows,
+                             int D, float eps, float *dx, float *da, float *db, void *workspace,
+                             spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,13 @@ def relation_feature(p_attn, value):
     return (a * v).transpose(1, 2).transpose(2, 3).contiguous().view(B, K, K, H * D)
 
 
+def layer_norm(x, a, b, eps=1e-6):
+    """models/transformer_captioner.py:110-113, literally."""
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return a * (x - mean) / (std + eps) + b
+
+
 class OracleBackend:
     """`backend` object for spacap3d_amd.backend.use_backend(): oracle ops + torch attention, CPU tensors."""
 
@@ -50,6 +57,7 @@ class OracleBackend:
                   "group_points_grad"):
             setattr(self, n, getattr(self._ext, n))
         self.attention = attention
+        self.layer_norm = layer_norm
 
     # max over the samples of a group: F.max_pool2d(x, [1, S]) of pointnet2_modules.py:256-259 (first maximum wins)
     @staticmethod

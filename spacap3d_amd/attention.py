@@ -110,3 +110,46 @@ def attention(query, key, value, mask=None, dropout_p=0.0, training=False, need_
     seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p > 0.0 else 0
     out, second = FusedAttention.apply(query, key, value, m, msb, msq, bias, p, seed, need_p)
     return out, (second if need_p else None)
+
+
+class FusedLayerNorm(Function):
+    """a * (x - mean) / (std_unbiased + eps) + b  (models/transformer_captioner.py:102-113) in one launch
+    forward and two backward (spacap_layernorm_*_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        if not x.is_cuda:
+            raise RuntimeError("CPU not supported")
+        xc = x.contiguous()
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(xc)
+            stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+            check(lib.spacap_layernorm_fwd_f32(xc.data_ptr(), a.data_ptr(), b.data_ptr(), rows, D, float(eps),
+                                               y.data_ptr(), stats.data_ptr(),
+                                               torch.cuda.current_stream(x.device).cuda_stream), "spacap_layernorm_fwd_f32")
+        ctx.save_for_backward(xc, a, stats)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, a, stats = ctx.saved_tensors
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        dyc = dy.contiguous()
+        with torch.cuda.device(xc.device):
+            dx = torch.empty_like(xc)
+            da = torch.empty(D, dtype=torch.float32, device=xc.device)
+            db = torch.empty(D, dtype=torch.float32, device=xc.device)
+            ws = torch.empty(max(int(lib.spacap_layernorm_bwd_workspace_bytes(rows, D)), 16), dtype=torch.uint8,
+                             device=xc.device)
+            check(lib.spacap_layernorm_bwd_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(), rows, D,
+                                               ctx.eps, dx.data_ptr(), da.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                               torch.cuda.current_stream(xc.device).cuda_stream), "spacap_layernorm_bwd_f32")
+        return dx, da, db, None
+
+
+def layer_norm(x, a, b, eps=1e-6):
+    return FusedLayerNorm.apply(x, a, b, eps)

@@ -24,6 +24,7 @@ class HipBackend:
                   "group_points_grad", "group_max", "group_max_grad"):
             setattr(self, n, getattr(ext, n))
         self.attention = _att.attention
+        self.layer_norm = _att.layer_norm
 
 
 def ops():

@@ -144,3 +144,24 @@ def test_rejects_bad_arguments(att):
         att.attention(q, k, v)
     with pytest.raises(RuntimeError, match="d_k"):
         att.attention(q[..., :8].contiguous().to(DEV), k[..., :8].contiguous().to(DEV), v[..., :8].contiguous().to(DEV))
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 128), (8, 32, 128), (3, 7, 512), (1, 1, 128), (5, 130)])
+def test_fused_layernorm_matches_reference_formula(att, shape):
+    """models/transformer_captioner.py:102-113: unbiased std, eps added to std."""
+    g = torch.Generator().manual_seed(len(shape))
+    x = torch.randn(*shape, generator=g) * 3 + 1
+    a = torch.rand(shape[-1], generator=g) + 0.5
+    b = torch.randn(shape[-1], generator=g)
+    w = torch.randn(*shape, generator=g)
+    xr, ar, br = (t.clone().requires_grad_(True) for t in (x, a, b))
+    yr = ref.layer_norm(xr, ar, br)
+    (yr * w).sum().backward()
+    xg, ag, bg = (t.to(DEV).requires_grad_(True) for t in (x, a, b))
+    y = att.layer_norm(xg, ag, bg)
+    (y * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), rtol=1e-5, atol=1e-5)
+    for got, want in ((xg.grad, xr.grad), (ag.grad, ar.grad), (bg.grad, br.grad)):
+        assert float((got.cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-9) < 1e-4
+    y2 = att.layer_norm(xg, ag, bg)
+    assert torch.equal(y2, y)
