@@ -165,6 +165,30 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
                        const float *d_out, const float *d_p, void *workspace, float *dq, float *dk,
                        float *dv, spacap_stream_t stream);
 
+/* ---- train-mode BatchNorm + ReLU (+ max over the samples) of the shared MLPs ---------------------
+ * (replaces BatchNorm2d -> ReLU [-> F.max_pool2d] of lib/pointnet2/pytorch_utils.py:11-36 and
+ *  lib/pointnet2/pointnet2_modules.py:253-259, forward and backward).  z f32 [B,C,L] dense (L = npoint*nsample).
+ * `workspace`: spacap_bn_workspace_bytes(C) bytes, shared by the forward-statistics and backward calls. */
+size_t spacap_bn_workspace_bytes(int C);
+/* stats f32 [C,2] = (batch mean, 1/sqrt(biased var + eps)); running_mean/var (nullable pair) are updated with
+ * `momentum` and the unbiased variance, as torch.nn.BatchNorm does. */
+int spacap_bn_stats_f32(const float *z, int B, int C, long L, float eps, float momentum, float *running_mean,
+                        float *running_var, float *stats, void *workspace, spacap_stream_t stream);
+/* out[b,c,l] = relu((z - mean) * invstd * gamma + beta) */
+int spacap_bn_relu_apply_f32(const float *z, const float *stats, const float *gamma, const float *beta, int B,
+                             int C, long L, float *out, spacap_stream_t stream);
+/* same followed by the max over the S samples of every (b,c,p): out f32 [B,C,P], arg u8 [B,C,P]; S in {16,32,64,128} */
+int spacap_bn_relu_max_f32(const float *z, const float *stats, const float *gamma, const float *beta, int B, int C,
+                           int P, int S, float *out, uint8_t *arg, spacap_stream_t stream);
+/* backward of apply: dA f32 [B,C,L] -> dz f32 [B,C,L], dgamma, dbeta f32 [C] */
+int spacap_bn_relu_bwd_f32(const float *z, const float *stats, const float *gamma, const float *beta,
+                           const float *dA, int B, int C, long L, float *dz, float *dgamma, float *dbeta,
+                           void *workspace, spacap_stream_t stream);
+/* backward of apply+max: dP f32 [B,C,P], arg u8 [B,C,P] -> dz f32 [B,C,P*S], dgamma, dbeta f32 [C] */
+int spacap_bn_relu_max_bwd_f32(const float *z, const float *stats, const float *gamma, const float *beta,
+                               const float *dP, const uint8_t *arg, int B, int C, int P, int S, float *dz,
+                               float *dgamma, float *dbeta, void *workspace, spacap_stream_t stream);
+
 /* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
 
 /* y = a * (x - mean) / (std_unbiased + eps) + b over the last dimension; x,y f32 [rows, D] dense, a,b f32 [D];

@@ -44,6 +44,15 @@ def layer_norm(x, a, b, eps=1e-6):
     return a * (x - mean) / (std + eps) + b
 
 
+def bn_relu_train(z, bn, pool_S=None):
+    """BatchNorm (batch statistics) -> ReLU [-> max over the trailing samples] with stock torch ops: the tail of a
+    SharedMLP layer (lib/pointnet2/pytorch_utils.py:11-36) and the pooling of pointnet2_modules.py:256-259."""
+    y = F.relu(bn(z))
+    if pool_S:
+        y = F.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1)
+    return y
+
+
 class OracleBackend:
     """`backend` object for spacap3d_amd.backend.use_backend(): oracle ops + torch attention, CPU tensors."""
 
@@ -58,6 +67,7 @@ class OracleBackend:
             setattr(self, n, getattr(self._ext, n))
         self.attention = attention
         self.layer_norm = layer_norm
+        self.bn_relu_train = bn_relu_train
 
     # max over the samples of a group: F.max_pool2d(x, [1, S]) of pointnet2_modules.py:256-259 (first maximum wins)
     @staticmethod

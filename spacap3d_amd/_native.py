@@ -42,6 +42,12 @@ SIGNATURES = {
     "spacap_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "spacap_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_bn_workspace_bytes": (ctypes.c_size_t, [_i]),
+    "spacap_bn_stats_f32": (_i, [_p, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p]),
+    "spacap_bn_relu_apply_f32": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
+    "spacap_bn_relu_max_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_bn_relu_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _l, _p, _p, _p, _p, _p]),
+    "spacap_bn_relu_max_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),

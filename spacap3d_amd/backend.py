@@ -25,6 +25,8 @@ class HipBackend:
             setattr(self, n, getattr(ext, n))
         self.attention = _att.attention
         self.layer_norm = _att.layer_norm
+        from . import fused_bn as _fbn
+        self.bn_relu_train = _fbn.bn_relu_train
 
 
 def ops():

@@ -1,0 +1,85 @@
+"""Train-mode BatchNorm + ReLU (+ max over the samples of a group) as one autograd op on libspacap_hip.so.
+
+Counterpart of the tail of every ``SharedMLP`` layer of the reference (lib/pointnet2/pytorch_utils.py:11-36:
+``Conv2d(1x1) -> BatchNorm2d -> ReLU(inplace)``) and of the pooling that follows the last one
+(lib/pointnet2/pointnet2_modules.py:256-259).  See ``csrc/bn_relu.hip`` for the pass structure.
+"""
+import torch
+from torch.autograd import Function
+
+from ._native import check, lib
+
+
+def _ws(C, device):
+    return torch.empty(int(lib.spacap_bn_workspace_bytes(C)), dtype=torch.uint8, device=device)
+
+
+class BNReLU(Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, momentum, eps, pool_S):
+        if not z.is_cuda:
+            raise RuntimeError("CPU not supported")
+        z = z.contiguous()
+        B, C = z.shape[0], z.shape[1]
+        L = z.numel() // (B * C)
+        dev = z.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            stats = torch.empty(C, 2, dtype=torch.float32, device=dev)
+            ws = _ws(C, dev)
+            check(lib.spacap_bn_stats_f32(z.data_ptr(), B, C, L, float(eps), float(momentum),
+                                          running_mean.data_ptr() if running_mean is not None else None,
+                                          running_var.data_ptr() if running_var is not None else None,
+                                          stats.data_ptr(), ws.data_ptr(), st), "spacap_bn_stats_f32")
+            if pool_S:
+                S = int(pool_S)
+                P = L // S
+                out = torch.empty(B, C, P, dtype=torch.float32, device=dev)
+                arg = torch.empty(B, C, P, dtype=torch.uint8, device=dev)
+                check(lib.spacap_bn_relu_max_f32(z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B, C,
+                                                 P, S, out.data_ptr(), arg.data_ptr(), st), "spacap_bn_relu_max_f32")
+                ctx.save_for_backward(z, stats, gamma, beta, arg)
+            else:
+                out = torch.empty_like(z)
+                check(lib.spacap_bn_relu_apply_f32(z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B,
+                                                   C, L, out.data_ptr(), st), "spacap_bn_relu_apply_f32")
+                ctx.save_for_backward(z, stats, gamma, beta)
+        ctx.pool_S = int(pool_S) if pool_S else 0
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        z, stats, gamma, beta = ctx.saved_tensors[:4]
+        B, C = z.shape[0], z.shape[1]
+        L = z.numel() // (B * C)
+        dev = z.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        d_out = d_out.contiguous()
+        with torch.cuda.device(dev):
+            dz = torch.empty_like(z)
+            dg = torch.empty(C, dtype=torch.float32, device=dev)
+            db = torch.empty(C, dtype=torch.float32, device=dev)
+            ws = _ws(C, dev)
+            if ctx.pool_S:
+                arg = ctx.saved_tensors[4]
+                S = ctx.pool_S
+                check(lib.spacap_bn_relu_max_bwd_f32(z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                     d_out.data_ptr(), arg.data_ptr(), B, C, L // S, S, dz.data_ptr(),
+                                                     dg.data_ptr(), db.data_ptr(), ws.data_ptr(), st),
+                      "spacap_bn_relu_max_bwd_f32")
+            else:
+                check(lib.spacap_bn_relu_bwd_f32(z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                 d_out.data_ptr(), B, C, L, dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                 ws.data_ptr(), st), "spacap_bn_relu_bwd_f32")
+        return dz, dg, db, None, None, None, None, None
+
+
+def bn_relu_train(z, bn, pool_S=None):
+    """z (B,C,...) -> relu(batch_norm(z)) with batch statistics; with ``pool_S`` the trailing dimension (size
+    pool_S) is max-reduced as well ((B,C,P,S) -> (B,C,P)).  ``bn`` is the torch BatchNorm module whose
+    parameters / running statistics are used and updated (momentum semantics of torch.nn.BatchNorm)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BNReLU.apply(z, bn.weight, bn.bias, rm, rv, momentum, bn.eps, pool_S)

@@ -39,6 +39,20 @@ class _ConvBNReLU2d(nn.Sequential):
         if bn:
             self.add_module("bn", _BN2d(cout))
         self.add_module("activation", nn.ReLU(inplace=True))
+        self.has_bn = bn
+
+    def forward(self, x, pool=False):
+        """conv -> BN -> ReLU; in training mode the BN -> ReLU (-> max over the last dim when ``pool``) tail is one
+        fused op of the backend.  Eval mode (running statistics) uses the stock modules."""
+        z = self.conv(x)
+        if self.has_bn and self.training:
+            from .backend import ops
+            S = z.size(3) if pool else None
+            if not pool or S in (16, 32, 64, 128):
+                return ops().bn_relu_train(z, self.bn.bn, pool_S=S)
+            return pointnet2_utils.group_max(ops().bn_relu_train(z, self.bn.bn))
+        y = self.activation(self.bn(z) if self.has_bn else z)
+        return pointnet2_utils.group_max(y) if pool else y
 
 
 class SharedMLP(nn.Sequential):
@@ -46,6 +60,13 @@ class SharedMLP(nn.Sequential):
         super().__init__()
         for i in range(len(args) - 1):
             self.add_module(f"layer{i}", _ConvBNReLU2d(args[i], args[i + 1], bn))
+
+    def forward(self, x, pool=False):
+        """``pool``: also take the max over the last (sample) dimension after the final layer, fused into it."""
+        layers = list(self.children())
+        for i, layer in enumerate(layers):
+            x = layer(x, pool=(pool and i == len(layers) - 1))
+        return x
 
 
 class PointnetSAModuleVotes(nn.Module):
@@ -75,8 +96,8 @@ class PointnetSAModuleVotes(nn.Module):
             assert inds.shape[1] == self.npoint
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, C+3, npoint, nsample)
-        new_features = self.mlp_module(grouped_features)                         # (B, mlp[-1], npoint, nsample)
-        new_features = pointnet2_utils.group_max(new_features)  # F.max_pool2d(x, [1, nsample]).squeeze(-1)
+        # SharedMLP + F.max_pool2d(x, [1, nsample]).squeeze(-1)  (pointnet2_modules.py:253-271)
+        new_features = self.mlp_module(grouped_features, pool=True)             # (B, mlp[-1], npoint)
         return new_xyz, new_features, inds
 
 

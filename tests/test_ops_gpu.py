@@ -220,3 +220,39 @@ def test_group_max_matches_max_pool2d(hip_ext, C, P, Sn):
     w0 = w.clone(); w0[yr.isnan()] = 0
     gi = hip_ext.group_max_grad(w0.to(DEV), arg, Sn).cpu()
     assert torch.equal(gi, xr.grad)
+
+
+@pytest.mark.parametrize("B,C,P,Sn,pool", [(4, 64, 512, 64, False), (4, 128, 256, 64, True), (2, 256, 128, 16, True),
+                                           (3, 37, 50, 32, True), (2, 16, 33, 7, False), (8, 128, 2048, 1, False)])
+def test_fused_bn_relu_max_matches_torch(hip_ext, B, C, P, Sn, pool):
+    """BatchNorm2d(train) -> ReLU [-> max_pool2d([1,S])] : values, gradients (z, gamma, beta) and running statistics."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from spacap3d_amd.fused_bn import bn_relu_train
+    g = torch.Generator().manual_seed(B * C + P)
+    z = torch.randn(B, C, P, Sn, generator=g) * 2 + 0.5
+    w = torch.randn(B, C, P, generator=g) if pool else torch.randn(B, C, P, Sn, generator=g)
+    bn_r = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_r.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn_r.weight[0] = -0.7  # a negative scale reverses the order inside the group
+        bn_r.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    bn_g = nn.BatchNorm2d(C)
+    bn_g.load_state_dict(bn_r.state_dict())
+    bn_g = bn_g.to(DEV)
+    zr = z.clone().requires_grad_(True)
+    yr = F.relu(bn_r(zr))
+    if pool:
+        yr = F.max_pool2d(yr, kernel_size=[1, Sn]).squeeze(-1)
+    (yr * w).sum().backward()
+    zg = z.to(DEV).requires_grad_(True)
+    yg = bn_relu_train(zg, bn_g, pool_S=Sn if pool else None)
+    (yg * w.to(DEV)).sum().backward()
+    torch.testing.assert_close(yg.detach().cpu(), yr.detach(), rtol=1e-4, atol=1e-5)
+    for got, want, name in ((zg.grad, zr.grad, "dz"), (bn_g.weight.grad, bn_r.weight.grad, "dgamma"),
+                            (bn_g.bias.grad, bn_r.bias.grad, "dbeta")):
+        err = float((got.cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 2e-4, (name, err)
+    torch.testing.assert_close(bn_g.running_mean.cpu(), bn_r.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_g.running_var.cpu(), bn_r.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_g.num_batches_tracked) == int(bn_r.num_batches_tracked) == 1
