@@ -135,7 +135,9 @@ int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
  *          strides (bias_sb, bias_sh, bias_sq), keys contiguous.  The reference adds no bias
  *          (SURVEY.md fact 1); the argument exists for the spatial-relation bias of north_star.
  *  dropout_p in [0,1): keep-probability 1-p, kept entries scaled by 1/(1-p); the mask is a
- *          counter hash of (seed, b, h, q, k) so backward regenerates it.
+ *          counter hash of (seed, b, h, q, k) so backward regenerates it.  seed_dev (nullable) points
+ *          to a device-resident 64-bit word mixed into the seed at run time, so that a captured
+ *          hipGraph draws a fresh mask on every replay (the host-side `seed` is frozen in the graph).
  *  out     f32 [B,Lq,h,d_k] dense (i.e. already in the layout of `x.transpose(1,2).contiguous()`,
  *          models/transformer_captioner.py:68)
  *  p_out   f32 [B,h,Lq,Lk] dense or NULL: the post-dropout attention matrix the reference returns
@@ -147,8 +149,8 @@ int spacap_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb
                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                        const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
-                       int d_k, float scale, float dropout_p, uint64_t seed, float *out,
-                       float *p_out, float *stats, spacap_stream_t stream);
+                       int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                       float *out, float *p_out, float *stats, spacap_stream_t stream);
 
 /* Backward of the above (two launches, no atomics, bitwise reproducible).  d_out f32 [B,Lq,h,d_k]
  * dense; d_p f32 [B,h,Lq,Lk] dense or NULL is the gradient w.r.t. the returned post-dropout p_attn
@@ -161,9 +163,9 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                        const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
-                       int d_k, float scale, float dropout_p, uint64_t seed, const float *stats,
-                       const float *d_out, const float *d_p, void *workspace, float *dq, float *dk,
-                       float *dv, spacap_stream_t stream);
+                       int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                       const float *stats, const float *d_out, const float *d_p, void *workspace,
+                       float *dq, float *dk, float *dv, spacap_stream_t stream);
 
 /* ---- train-mode BatchNorm + ReLU (+ max over the samples) of the shared MLPs ---------------------
  * (replaces BatchNorm2d -> ReLU [-> F.max_pool2d] of lib/pointnet2/pytorch_utils.py:11-36 and

@@ -40,6 +40,34 @@ def _prep_mask(mask, B, Lq, Lk):
     return m, m.stride(0), (0 if m.size(1) == 1 else m.stride(1))
 
 
+# ---- dropout randomness ----------------------------------------------------------------------------------
+# The keep mask is a counter hash of (seed, element).  `seed` is a host integer drawn per call from a Python
+# counter seeded by torch's CPU generator; it would be frozen inside a captured hipGraph, so a device-resident
+# word (`_RNG_STATE[device]`, bumped once per training step by an in-graph add) is mixed in by the kernel.
+_RNG_STATE = {}
+_CALL_COUNTER = [None]
+
+
+def rng_state(device):
+    st = _RNG_STATE.get(device)
+    if st is None:
+        st = torch.zeros(1, dtype=torch.int64, device=device)
+        _RNG_STATE[device] = st
+    return st
+
+
+def advance_rng(device):
+    """Call once per step (captured into the step's graph): every attention call then sees new dropout masks."""
+    rng_state(device).add_(1)
+
+
+def _next_seed():
+    if _CALL_COUNTER[0] is None:
+        _CALL_COUNTER[0] = int(torch.randint(0, 2 ** 31, (1,), device="cpu").item()) << 20
+    _CALL_COUNTER[0] += 1
+    return _CALL_COUNTER[0]
+
+
 class FusedAttention(Function):
     @staticmethod
     def forward(ctx, q, k, v, mask_u8, mask_sb, mask_sq, bias, dropout_p, seed, need_p):
@@ -64,6 +92,7 @@ class FusedAttention(Function):
                 mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq,
                 bias.data_ptr() if bias is not None else None, *bs,
                 B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed),
+                rng_state(q.device).data_ptr() if dropout_p > 0.0 else None,
                 out.data_ptr(), p.data_ptr() if need_p else None, lse.data_ptr(),
                 torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_fwd_f32")
         ctx.save_for_backward(q, k, v, mask_u8, bias, lse)
@@ -93,7 +122,8 @@ class FusedAttention(Function):
                 q.data_ptr(), k.data_ptr(), v.data_ptr(), *_strides3(q), *_strides3(k), *_strides3(v),
                 mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq,
                 bias.data_ptr() if bias is not None else None, *bs,
-                B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed), lse.data_ptr(),
+                B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed),
+                rng_state(q.device).data_ptr() if dropout_p > 0.0 else None, lse.data_ptr(),
                 d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None, ws.data_ptr(),
                 dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(),
                 torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_bwd_f32")
@@ -107,7 +137,7 @@ def attention(query, key, value, mask=None, dropout_p=0.0, training=False, need_
     Lk = key.shape[2]
     m, msb, msq = _prep_mask(mask, B, Lq, Lk)
     p = float(dropout_p) if training else 0.0
-    seed = int(torch.randint(0, 2 ** 62, (1,), device="cpu").item()) if p > 0.0 else 0
+    seed = _next_seed() if p > 0.0 else 0
     out, second = FusedAttention.apply(query, key, value, m, msb, msq, bias, p, seed, need_p)
     return out, (second if need_p else None)
 

@@ -43,6 +43,7 @@ struct MhaArgs {
   float scale, keep_scale;  // keep_scale = 1 / (1 - p)
   unsigned drop_thresh;     // drop iff hash < drop_thresh ; 0 = no dropout
   unsigned long long seed;
+  const unsigned long long *seed_dev;  // optional device-resident word added to `seed` (hipGraph replays)
   float *out, *p_out, *stats;       // forward outputs
   const float *d_out, *d_p;         // backward inputs
   float *dq, *dk, *dv, *delta;      // backward outputs / scratch
@@ -50,7 +51,8 @@ struct MhaArgs {
 
 __device__ __forceinline__ bool keep_elem(const MhaArgs &A, int b, int hh, int q, int key) {
   if (A.drop_thresh == 0u) return true;
-  unsigned long long x = ((((unsigned long long)b * A.h + hh) * A.Lq + q) * (unsigned long long)A.Lk + key) ^ A.seed;
+  const unsigned long long sd = A.seed + (A.seed_dev ? *A.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+  unsigned long long x = ((((unsigned long long)b * A.h + hh) * A.Lq + q) * (unsigned long long)A.Lk + key) ^ sd;
   x += 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
@@ -357,7 +359,7 @@ int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, cons
               long q_sh, long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
               const uint8_t *mask, long mask_sb, long mask_sq, const float *bias, long bias_sb, long bias_sh,
               long bias_sq, int B, int h, int Lq, int Lk, int d_k, float scale, float dropout_p,
-              uint64_t seed) {
+              uint64_t seed, const uint64_t *seed_dev) {
   SPACAP_REQUIRE(B >= 0 && h >= 1 && Lq >= 0 && Lk >= 1, "%s: bad sizes B=%d h=%d Lq=%d Lk=%d", what, B, h, Lq, Lk);
   SPACAP_REQUIRE(d_k == 16 || d_k == 32 || d_k == 64, "%s: d_k=%d unsupported (16, 32, 64)", what, d_k);
   SPACAP_REQUIRE(Lk <= 512, "%s: Lk=%d > 512 unsupported", what, Lk);
@@ -375,6 +377,7 @@ int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, cons
   A.keep_scale = 1.0f / (1.0f - dropout_p);
   A.drop_thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
   A.seed = seed;
+  A.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   A.out = A.p_out = A.stats = nullptr;
   A.d_out = A.d_p = nullptr;
   A.dq = A.dk = A.dv = A.delta = nullptr;
@@ -412,11 +415,11 @@ extern "C" int spacap_mha_fwd_f32(const float *q, const float *k, const float *v
                                   long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                                   const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                                   long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
-                                  int d_k, float scale, float dropout_p, uint64_t seed, float *out,
-                                  float *p_out, float *stats, spacap_stream_t stream) {
+                                  int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                                  float *out, float *p_out, float *stats, spacap_stream_t stream) {
   MhaArgs A;
   int rc = fill_args(A, "spacap_mha_fwd_f32", q, k, v, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, mask,
-                     mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed);
+                     mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed, seed_dev);
   if (rc) return rc;
   if (B == 0 || Lq == 0) return SPACAP_OK;
   SPACAP_REQUIRE(out && stats, "spacap_mha_fwd_f32: null output");
@@ -433,12 +436,12 @@ extern "C" int spacap_mha_bwd_f32(const float *q, const float *k, const float *v
                                   long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
                                   const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
                                   long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
-                                  int d_k, float scale, float dropout_p, uint64_t seed, const float *stats,
-                                  const float *d_out, const float *d_p, void *workspace, float *dq, float *dk,
-                                  float *dv, spacap_stream_t stream) {
+                                  int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                                  const float *stats, const float *d_out, const float *d_p, void *workspace,
+                                  float *dq, float *dk, float *dv, spacap_stream_t stream) {
   MhaArgs A;
   int rc = fill_args(A, "spacap_mha_bwd_f32", q, k, v, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, mask,
-                     mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed);
+                     mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed, seed_dev);
   if (rc) return rc;
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(dq && dk && dv, "spacap_mha_bwd_f32: null output");

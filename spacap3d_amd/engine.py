@@ -21,6 +21,11 @@ class Trainer:
         self.bucket = None
         self.optimizer = None
         self.side_stream = None
+        self.graph = None          # captured hipGraph of one training step (see enable_graph)
+        self.graph_error = None
+        self._static = None
+        self._static_loss = None
+        self._eager_steps = 0
         broadcast_parameters(model)
 
     # -- sampling-pyramid prefetch ---------------------------------------------------------------------------
@@ -70,24 +75,109 @@ class Trainer:
         self.bucket = FlatGradBucket(used)
         kw = dict(lr=self.lr, weight_decay=self.weight_decay)
         try:
-            self.optimizer = torch.optim.Adam(used, fused=used[0].is_cuda, **kw)
+            self.optimizer = torch.optim.Adam(used, fused=used[0].is_cuda, capturable=used[0].is_cuda, **kw)
         except (RuntimeError, TypeError):
             self.optimizer = torch.optim.Adam(used, **kw)
+
+    def _core(self, data_dict, with_optimizer=True):
+        """zero grads -> forward -> loss -> backward [-> all-reduce -> Adam]; no host sync, capturable."""
+        pc = data_dict["point_clouds"]
+        if pc.is_cuda:
+            from .attention import advance_rng
+            advance_rng(pc.device)  # new attention-dropout masks every step, also under graph replay
+        self.bucket.zero()
+        d = self.loss(data_dict)
+        d["loss"].backward()
+        if with_optimizer:
+            self.bucket.all_reduce_mean()
+            self.optimizer.step()
+        return d["loss"].detach()
+
+    # -- hipGraph mode ------------------------------------------------------------------------------------------
+    # One training step is ~1 900 kernel launches, most of them microseconds long (Transformer, loss); eager
+    # PyTorch needs ~13 us of host time per launch, which caps the step at ~25 ms whatever the GPU does.  The
+    # step (zero-grad, forward, loss, backward, Adam) is therefore captured once into a hipGraph over static
+    # input buffers and replayed; per step the host then only copies the batch (and the prefetched sampling
+    # pyramid) into the static buffers, launches the graph, and starts the next pyramid on the side stream.
+    # With more than one rank the gradient all-reduce and Adam stay outside the graph (RCCL calls are not
+    # captured); single-rank runs capture them too.
+    def enable_graph(self, example, warmup=3):
+        """Capture the step for batches shaped like ``example`` (which must carry a prefetched pyramid if
+        prefetching is used).  Falls back to eager mode (and records why) if capture fails."""
+        import torch.distributed as dist
+        dev = example["point_clouds"].device
+        if dev.type != "cuda":
+            return False
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self._graph_with_opt = (world == 1)
+        try:
+            if self.bucket is None:
+                self._setup({k: v for k, v in example.items() if k != "_fps_prefetch"})
+            ex = self._consume_prefetch(dict(example))
+            static = {}
+            for k, v in ex.items():
+                if k == "fps_pyramid":
+                    static[k] = [t.clone() for t in v]
+                elif torch.is_tensor(v):
+                    static[k] = v.clone()
+            # Autograd's AccumulateGrad nodes remember the stream they were created on; the warm-up below and the
+            # capture must therefore share ONE side stream, and nothing may keep an older graph (created on the
+            # default stream) alive -- the attention modules stash graph-attached tensors (`attn`, `value`).
+            for mod in self.model.modules():
+                if hasattr(mod, "attn") and hasattr(mod, "keep_value"):
+                    mod.attn, mod.value = None, None
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    self._core(static, self._graph_with_opt)
+                    if not self._graph_with_opt:
+                        self.bucket.all_reduce_mean()
+                        self.optimizer.step()
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                loss = self._core(static, self._graph_with_opt)
+            self.graph, self._static, self._static_loss = g, static, loss
+            return True
+        except Exception as e:  # noqa: BLE001 -- any capture failure means "stay eager"
+            self.graph, self._static, self._static_loss = None, None, None
+            import traceback
+            self.graph_error = f"{type(e).__name__}: {str(e)[:300]}\n" + "".join(traceback.format_tb(e.__traceback__)[-6:])
+            torch.cuda.synchronize(dev)
+            return False
+
+    def _graph_step(self, data_dict, next_data):
+        pre = data_dict.pop("_fps_prefetch", None)
+        if pre is not None:
+            pyr, ev = pre
+            torch.cuda.current_stream(pyr[0].device).wait_event(ev)
+            for dst, src in zip(self._static["fps_pyramid"], pyr):
+                dst.copy_(src, non_blocking=True)
+                src.record_stream(torch.cuda.current_stream(src.device))
+        for k, dst in self._static.items():
+            if k != "fps_pyramid" and k in data_dict and data_dict[k] is not dst:
+                dst.copy_(data_dict[k], non_blocking=True)
+        if next_data is not None:
+            self.prefetch(next_data)
+        self.graph.replay()
+        if not self._graph_with_opt:
+            self.bucket.all_reduce_mean()
+            self.optimizer.step()
+        return self._static_loss
 
     def step(self, data_dict, next_data=None):
         """One full training step; returns the (device) loss tensor, no host sync.  ``next_data``: the batch of
         the following step, whose sampling pyramid is started on the side stream first."""
+        if self.graph is not None:
+            return self._graph_step(data_dict, next_data)
         if self.bucket is None:
             self._setup({k: v for k, v in data_dict.items() if k != "_fps_prefetch"})
         data_dict = self._consume_prefetch(data_dict)  # pops what the previous step prefetched for this batch
         if next_data is not None:
             self.prefetch(next_data)                   # may be the same dict object: order matters
-        self.bucket.zero()
-        d = self.loss(data_dict)
-        d["loss"].backward()
-        self.bucket.all_reduce_mean()
-        self.optimizer.step()
-        return d["loss"].detach()
+        return self._core(data_dict)
 
 
 def synthetic_batch(batch: int, n_points: int, device, seed: int = 0, vocab: int = 3001, use_color=False,

@@ -22,6 +22,20 @@ GT_VOTE_FACTOR = 3
 OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]
 
 
+_CONST = {}
+
+
+def _const(key, device, build):
+    """Device-resident constants are built once per device (a host -> device copy is not allowed while a
+    hipGraph is being captured; the eager warm-up step populates this cache)."""
+    k = (key, str(device))
+    t = _CONST.get(k)
+    if t is None:
+        t = build().to(device)
+        _CONST[k] = t
+    return t
+
+
 def huber_loss(error, delta=1.0):
     abs_error = torch.abs(error)
     quadratic = torch.clamp(abs_error, max=delta)
@@ -67,7 +81,7 @@ def compute_objectness_loss(d):
     near = euclid < NEAR_THRESHOLD
     objectness_label = near.long()
     objectness_mask = (near | (euclid > FAR_THRESHOLD)).float()
-    w = torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=torch.float32, device=agg.device)
+    w = _const("objectness_w", agg.device, lambda: torch.tensor(OBJECTNESS_CLS_WEIGHTS, dtype=torch.float32))
     loss = F.cross_entropy(d["objectness_scores"].transpose(2, 1), objectness_label, weight=w, reduction="none")
     loss = torch.sum(loss * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
     return loss, objectness_label, objectness_mask, ind1
@@ -99,7 +113,8 @@ def compute_box_and_sem_cls_loss(d, num_heading_bin, num_size_cluster, mean_size
     size_residual_label = torch.gather(d["size_residual_label"], 1, oa.unsqueeze(-1).expand(-1, -1, 3))
     size_one_hot = F.one_hot(size_class_label, num_size_cluster).float().unsqueeze(-1)  # (B,K,NS,1)
     pred_size_res_norm = torch.sum(d["size_residuals_normalized"] * size_one_hot, 2)
-    msa = torch.as_tensor(mean_size_arr, dtype=torch.float32, device=pred_center.device).unsqueeze(0).unsqueeze(0)
+    msa = _const(("msa", id(mean_size_arr)), pred_center.device,
+                 lambda: torch.as_tensor(mean_size_arr, dtype=torch.float32).clone()).unsqueeze(0).unsqueeze(0)
     mean_size_label = torch.sum(size_one_hot * msa, 2)
     size_residual_label_normalized = size_residual_label / mean_size_label
     sr = torch.mean(huber_loss(pred_size_res_norm - size_residual_label_normalized, delta=1.0), -1)
@@ -154,7 +169,7 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         num_heading_bin, num_size_cluster, mean_size_arr = (config.num_heading_bin, config.num_size_cluster,
                                                             config.mean_size_arr)
     dev = d["seed_xyz"].device
-    zero = torch.zeros((), device=dev)
+    zero = _const("zero", dev, lambda: torch.zeros(()))
 
     vote_loss = compute_vote_loss(d)
     objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)

@@ -132,10 +132,12 @@ def test_dropout_invariants(att):
     (torch.matmul(pd, v2) * w).sum().backward()
     for a, b in ((qg.grad, q2.grad), (kg.grad, k2.grad), (vg.grad, v2.grad)):
         assert float((a - b).abs().max()) / float(b.abs().max()) < 2e-4
-    # a different seed gives a different mask
-    torch.manual_seed(124)
+    # the next call draws a different mask, and so does the same call after the per-step device counter moved
     _, p2 = att.attention(qg, kg, vg, dropout_p=0.1, training=True, need_p=True)
     assert not torch.equal(p2 != 0, kept)
+    att.advance_rng(qg.device)
+    _, p3 = att.attention(qg, kg, vg, dropout_p=0.1, training=True, need_p=True)
+    assert not torch.equal(p3 != 0, p2 != 0)
 
 
 def test_rejects_bad_arguments(att):

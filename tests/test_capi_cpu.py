@@ -45,7 +45,7 @@ def test_argument_validation_needs_no_device():
     assert lib.spacap_fps_workspace_bytes(8, 40000) >= 8 * 40000 * 4
     assert lib.spacap_mha_bwd_workspace_bytes(8, 8, 256) == 8 * 8 * 256 * 4
     z = [0] * 9
-    assert lib.spacap_mha_fwd_f32(None, None, None, *z, None, 0, 0, None, 0, 0, 0, 1, 8, 16, 16, 24, 0.25, 0.0, 0,
+    assert lib.spacap_mha_fwd_f32(None, None, None, *z, None, 0, 0, None, 0, 0, 0, 1, 8, 16, 16, 24, 0.25, 0.0, 0, None,
                                   None, None, None, None) == -1
     assert b"d_k=24" in lib.spacap_last_error()
 
