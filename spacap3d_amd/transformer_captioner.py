@@ -38,6 +38,38 @@ def attention(query, key, value, mask=None, dropout=None, need_p=True):
     return ops().attention(query, key, value, mask=mask, dropout_p=p, training=training, need_p=need_p)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T + b for inputs with very many rows (the relation head runs its MLP on B*K*K = 524 288 pair
+    features).  Forward and dX are ordinary GEMMs; the weight gradient dW = G^T X reduces over all rows into a
+    128 x 128 output, which the BLAS heuristics run as a handful of tiles with no split over K (1.08 ms per
+    layer on MI355X); here the rows are cut into 64 slabs, multiplied as one batched GEMM and summed
+    (0.15 ms, fixed summation order)."""
+
+    SLABS = 64
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        rows, S = g2.shape[0], _TallLinear.SLABS
+        dx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        if rows % S == 0 and rows >= 64 * S:
+            dw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
+        else:
+            dw = g2.t() @ x2
+        return dx, dw, g2.sum(0)
+
+
+def tall_linear(x, lin):
+    return _TallLinear.apply(x, lin.weight, lin.bias)
+
+
 class MultiHeadedAttention(nn.Module):
     def __init__(self, h, d_model, dropout=0.1, keep_value=False, store_attn=None):
         super().__init__()
@@ -342,7 +374,10 @@ class TransformerDecoderModel(nn.Module):
         ep["pred_ious"] = (target_ious.squeeze(1) * good).sum() / n_good.clamp(min=1)
         ep["good_bbox_masks"] = good
         if self.check_relation:
-            ep["relation_pred"] = self.relation_proposal(self.relation_feature())
+            rp = self.relation_proposal  # Linear-ReLU-Linear-ReLU-Linear (:319-326)
+            hid = F.relu(tall_linear(self.relation_feature(), rp[0]))
+            hid = F.relu(tall_linear(hid, rp[2]))
+            ep["relation_pred"] = tall_linear(hid, rp[4])
         return ep
 
     def forward_eval(self, ep):
