@@ -12,9 +12,11 @@ head on, attention dropout 0.1 as in the reference) -- fp32, inputs resident in 
 are sharded by rank (weak scaling); rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      the dominant native kernel (SA1 furthest-point sampling, N -> 2048): algorithmic bytes
+  roofline      the dominant hand-written kernel (SA1 furthest-point sampling, N -> 2048): algorithmic bytes
                 B*(m-1)*N*20 (SURVEY.md section 8d streamed-traffic model) / its average duration measured with
-                events on the launch stream inside the timed steps, against 8 TB/s HBM.
+                events on the stream it is launched on (the prefetch side stream, i.e. while it shares the chip with
+                the dense kernels of the step) inside the timed steps, against 8 TB/s HBM; `isolated_ms` is the same
+                launch alone on an idle chip.
   cpu_baseline  the same training step on the host CPU (this repo's host code on device "cpu" driving the CPU
                 oracle ops, oracle/) on a bounded sample; rank 0, N = 1 only.
   ops           FPS and ball_query Mpts/s at the SA1 shape (the second half of BASELINE.json's metric).
@@ -174,17 +176,20 @@ def main():
         B, N, m = per_gpu, cfg["n_points"], 2048
         fps_ms = fps_timer.mean_ms()
         fps_bytes = B * (m - 1) * N * 20  # 12 B xyz + 4 B temp read + 4 B temp write per point-update
-        roof = {"bound": "hbm", "kernel": "fps_hybrid_kernel (SA1 furthest point sampling, N->2048)",
+        roof = {"bound": "hbm", "kernel": "fps_bucket_kernel<10> (SA1 furthest point sampling, 40000 -> 2048, runs on the prefetch side stream)",
                 "achieved": fps_bytes / (fps_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                 "frac": fps_bytes / (fps_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                 "launch_ms": fps_ms, "launches_timed": len(fps_timer.events),
                 "algorithmic_bytes_per_launch": fps_bytes}
+        roof_fill = roof
         # isolated SA1-shaped op rates (second half of the BASELINE metric)
         xyz = data["point_clouds"][..., :3].contiguous()
         t_fps = time_op(lambda: fps_timer.fn(xyz, m))
         inds = fps_timer.fn(xyz, m)
         new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         t_bq = time_op(lambda: be.ball_query(new_xyz, xyz, 0.2, 64))
+        roof_fill["isolated_ms"] = t_fps
+        roof_fill["isolated_frac"] = fps_bytes / (t_fps * 1e-3) / 1e9 / 8000.0
         ops = {"fps_Mpts_s": B * N / t_fps * 1e-3, "fps_ms": t_fps, "fps_Gupdates_s": B * N * (m - 1) / t_fps * 1e-6,
                "ball_query_Mpts_s": B * N / t_bq * 1e-3, "ball_query_ms": t_bq,
                "ball_query_Gpairs_s": B * m * N / t_bq * 1e-6}

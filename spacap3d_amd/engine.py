@@ -72,7 +72,9 @@ class Trainer:
         bucket and build Adam over exactly those (scripts/train.py:262: Adam lr 1e-3, weight_decay 1e-5)."""
         d = self.loss(data_dict)
         used = used_parameters(self.model, d["loss"])
-        self.bucket = FlatGradBucket(used)
+        # gradients are assigned by autograd (no per-parameter accumulate kernels) and packed into the flat
+        # bucket only when there is something to all-reduce
+        self.bucket = FlatGradBucket(used, views=False)
         kw = dict(lr=self.lr, weight_decay=self.weight_decay)
         try:
             self.optimizer = torch.optim.Adam(used, fused=used[0].is_cuda, capturable=used[0].is_cuda, **kw)

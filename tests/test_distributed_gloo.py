@@ -98,3 +98,18 @@ def test_shard_scenes_partitions_the_batch():
     assert seen == list(range(64))
     with pytest.raises(AssertionError):
         shard_scenes(10, 0, 4)
+
+
+def test_flat_bucket_pack_mode_matches_view_mode():
+    """views=False: autograd assigns gradients, pack() gathers them; same flat content as the view mode."""
+    a, b = _make_model(3), _make_model(3)
+    ba, bb = FlatGradBucket(a.parameters(), views=True), FlatGradBucket(b.parameters(), views=False)
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(1))
+    for m, bk in ((a, ba), (b, bb)):
+        bk.zero()
+        m(x).square().sum().backward()
+        bk.pack()
+    assert torch.equal(ba.flat, bb.flat)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bb.params, bb.views))
+    bb.zero()
+    assert all(p.grad is None for p in bb.params)
