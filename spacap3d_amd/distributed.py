@@ -86,19 +86,25 @@ class FlatGradBucket:
             for p in self.params:
                 p.grad = None
 
-    def pack(self):
-        """views=False only: copy the freshly produced gradients into the flat buffer (one foreach copy)."""
+    def pack(self, sources=None):
+        """views=False only: copy the freshly produced gradients into the flat buffer (one foreach copy) and point
+        ``p.grad`` at the flat views.  ``sources``: the tensors holding the new gradients when they are not
+        ``p.grad`` any more (a replayed hipGraph keeps writing into the tensors autograd allocated at capture)."""
         if self.views_mode:
             return
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
+        if sources is None:
+            sources = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, list(sources))
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self):
-        """The step's single collective.  No-op in a single process."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.pack()
+    def all_reduce_mean(self, sources=None, force_pack=False):
+        """The step's single collective.  No-op in a single process (unless ``force_pack``, used by tests to
+        exercise the multi-rank code path on one GPU)."""
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi or force_pack:
+            self.pack(sources)
+        if multi:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
 

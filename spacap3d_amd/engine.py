@@ -13,7 +13,7 @@ from .loss_helper import get_scene_cap_loss
 
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 use_relation: bool = True):
+                 use_relation: bool = True, split_optimizer: bool = False):
         self.model = model
         self.mean_size_arr = mean_size_arr
         self.use_relation = use_relation
@@ -26,6 +26,9 @@ class Trainer:
         self._static = None
         self._static_loss = None
         self._eager_steps = 0
+        self._graph_grads = None
+        # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
+        self.split_optimizer = split_optimizer
         broadcast_parameters(model)
 
     # -- sampling-pyramid prefetch ---------------------------------------------------------------------------
@@ -91,7 +94,7 @@ class Trainer:
         d = self.loss(data_dict)
         d["loss"].backward()
         if with_optimizer:
-            self.bucket.all_reduce_mean()
+            self.bucket.all_reduce_mean(force_pack=self.split_optimizer)
             self.optimizer.step()
         return d["loss"].detach()
 
@@ -111,7 +114,7 @@ class Trainer:
         if dev.type != "cuda":
             return False
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self._graph_with_opt = (world == 1)
+        self._graph_with_opt = (world == 1) and not self.split_optimizer
         try:
             if self.bucket is None:
                 self._setup({k: v for k, v in example.items() if k != "_fps_prefetch"})
@@ -134,7 +137,7 @@ class Trainer:
                 for _ in range(warmup):
                     self._core(static, self._graph_with_opt)
                     if not self._graph_with_opt:
-                        self.bucket.all_reduce_mean()
+                        self.bucket.all_reduce_mean(force_pack=self.split_optimizer)
                         self.optimizer.step()
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
@@ -142,6 +145,8 @@ class Trainer:
             with torch.cuda.graph(g, stream=s):
                 loss = self._core(static, self._graph_with_opt)
             self.graph, self._static, self._static_loss = g, static, loss
+            # the tensors autograd assigned as gradients during capture: every replay rewrites them in place
+            self._graph_grads = [p.grad for p in self.bucket.params]
             return True
         except Exception as e:  # noqa: BLE001 -- any capture failure means "stay eager"
             self.graph, self._static, self._static_loss = None, None, None
@@ -165,7 +170,7 @@ class Trainer:
             self.prefetch(next_data)
         self.graph.replay()
         if not self._graph_with_opt:
-            self.bucket.all_reduce_mean()
+            self.bucket.all_reduce_mean(sources=self._graph_grads, force_pack=self.split_optimizer)
             self.optimizer.step()
         return self._static_loss
 
