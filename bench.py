@@ -178,7 +178,11 @@ def main():
         fps_bytes = B * (m - 1) * N * 20  # 12 B xyz + 4 B temp read + 4 B temp write per point-update
         roof = {"bound": "hbm", "kernel": "fps_bucket_kernel<10> (SA1 furthest point sampling, 40000 -> 2048, runs on the prefetch side stream)",
                 "achieved": fps_bytes / (fps_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": fps_bytes / (fps_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                "frac": fps_bytes / (fps_ms * 1e-3) / 1e9 / 8000.0,
+                # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_fps_*.csv: FETCH_SIZE 4037 KB,
+                # doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE 3904 KB); cannot be collected
+                # from inside this process.  It is 0.1 % of the algorithmic bytes: the kernel is on-chip resident.
+                "traffic": (2 * 4037 + 3904) * 1024 if (B, N) == (8, 40000) else None,
                 "launch_ms": fps_ms, "launches_timed": len(fps_timer.events),
                 "algorithmic_bytes_per_launch": fps_bytes}
         roof_fill = roof
