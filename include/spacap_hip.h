@@ -191,6 +191,18 @@ int spacap_bn_relu_max_bwd_f32(const float *z, const float *stats, const float *
                                const float *dP, const uint8_t *arg, int B, int C, int P, int S, float *dz,
                                float *dgamma, float *dbeta, void *workspace, spacap_stream_t stream);
 
+/* ---- pairwise relation feature (replaces models/transformer_captioner.py:393-396) ---------------
+ * R[b,i,j,h*D+d] = P[b,h,i,j] * V[b,h,j,d].  P f32 [B,H,K,K] dense (the post-dropout attention matrix of the
+ * last encoder layer), V f32 logical [B,H,K,D] with element strides (v_sb, v_sh, v_sl), last dim contiguous;
+ * R f32 [B,K,K,H*D] dense.  D a power of two in 4..64, H*D <= 1024 with 256 % (H*D/4) == 0. */
+int spacap_relation_feature_fwd_f32(const float *P, const float *V, long v_sb, long v_sh, long v_sl, int B,
+                                    int H, int K, int D, float *R, spacap_stream_t stream);
+/* dR f32 [B,K,K,H*D] -> dP f32 [B,H,K,K] dense, dV f32 [B,K,H,D] dense (the layout of the value projection
+ * before `.transpose(1,2)`); every element written, fixed summation order. */
+int spacap_relation_feature_bwd_f32(const float *dR, const float *P, const float *V, long v_sb, long v_sh,
+                                    long v_sl, int B, int H, int K, int D, float *dP, float *dV,
+                                    spacap_stream_t stream);
+
 /* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
 
 /* y = a * (x - mean) / (std_unbiased + eps) + b over the last dimension; x,y f32 [rows, D] dense, a,b f32 [D];

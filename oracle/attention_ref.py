@@ -67,6 +67,7 @@ class OracleBackend:
             setattr(self, n, getattr(self._ext, n))
         self.attention = attention
         self.layer_norm = layer_norm
+        self.relation_feature = relation_feature
         self.bn_relu_train = bn_relu_train
 
     # max over the samples of a group: F.max_pool2d(x, [1, S]) of pointnet2_modules.py:256-259 (first maximum wins)

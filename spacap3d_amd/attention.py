@@ -183,3 +183,42 @@ class FusedLayerNorm(Function):
 
 def layer_norm(x, a, b, eps=1e-6):
     return FusedLayerNorm.apply(x, a, b, eps)
+
+
+class RelationFeature(Function):
+    """R[b,i,j,h*D+d] = P[b,h,i,j] * V[b,h,j,d]  (models/transformer_captioner.py:393-396) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, P, V):
+        if not P.is_cuda:
+            raise RuntimeError("CPU not supported")
+        P = P.contiguous()
+        if V.stride(3) != 1 or any(s % 4 for s in V.stride()[:3]) or V.data_ptr() % 16:
+            V = V.contiguous()
+        B, H, K, D = V.shape
+        with torch.cuda.device(P.device):
+            R = torch.empty(B, K, K, H * D, dtype=torch.float32, device=P.device)
+            check(lib.spacap_relation_feature_fwd_f32(P.data_ptr(), V.data_ptr(), V.stride(0), V.stride(1), V.stride(2),
+                                                      B, H, K, D, R.data_ptr(),
+                                                      torch.cuda.current_stream(P.device).cuda_stream),
+                  "spacap_relation_feature_fwd_f32")
+        ctx.save_for_backward(P, V)
+        return R
+
+    @staticmethod
+    def backward(ctx, dR):
+        P, V = ctx.saved_tensors
+        B, H, K, D = V.shape
+        dR = dR.contiguous()
+        with torch.cuda.device(P.device):
+            dP = torch.empty_like(P)
+            dV = torch.empty(B, K, H, D, dtype=torch.float32, device=P.device)
+            check(lib.spacap_relation_feature_bwd_f32(dR.data_ptr(), P.data_ptr(), V.data_ptr(), V.stride(0), V.stride(1),
+                                                      V.stride(2), B, H, K, D, dP.data_ptr(), dV.data_ptr(),
+                                                      torch.cuda.current_stream(P.device).cuda_stream),
+                  "spacap_relation_feature_bwd_f32")
+        return dP, dV.transpose(1, 2)
+
+
+def relation_feature(P, V):
+    return RelationFeature.apply(P, V)

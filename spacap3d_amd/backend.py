@@ -25,6 +25,7 @@ class HipBackend:
             setattr(self, n, getattr(ext, n))
         self.attention = _att.attention
         self.layer_norm = _att.layer_norm
+        self.relation_feature = _att.relation_feature
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
 

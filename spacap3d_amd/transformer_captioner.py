@@ -351,10 +351,7 @@ class TransformerDecoderModel(nn.Module):
     def relation_feature(self):
         """R[b,i,j,h*16+d] = P[b,h,i,j] * V[b,h,j,d] of the last encoder layer (:393-396)."""
         sa = self.model.encoder.layers[-1].self_attn
-        P, V = sa.attn, sa.value                      # (B,h,K,K), (B,h,K,d_k)
-        B, H, K, _ = P.shape
-        R = P.unsqueeze(-1) * V.unsqueeze(-3)         # (B,h,K,K,d_k)
-        return R.permute(0, 2, 3, 1, 4).reshape(B, K, K, H * V.shape[-1])
+        return ops().relation_feature(sa.attn, sa.value)   # (B,h,K,K), (B,h,K,d_k) -> (B,K,K,h*d_k)
 
     def forward_train(self, ep):
         src = ep["aggregated_vote_features"]

@@ -167,3 +167,21 @@ def test_fused_layernorm_matches_reference_formula(att, shape):
         assert float((got.cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-9) < 1e-4
     y2 = att.layer_norm(xg, ag, bg)
     assert torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("B,H,K,D", [(2, 8, 256, 16), (1, 8, 64, 16), (2, 32, 40, 16), (1, 4, 33, 32)])
+def test_relation_feature_matches_reference_chain(att, B, H, K, D):
+    """models/transformer_captioner.py:393-396 (repeat / product / transposes / view) and its autograd backward."""
+    g = torch.Generator().manual_seed(K)
+    P = torch.rand(B, H, K, K, generator=g)
+    V = torch.randn(B, K, H, D, generator=g).transpose(1, 2)  # the strided view the model passes
+    w = torch.randn(B, K, K, H * D, generator=g)
+    Pr, Vr = P.clone().requires_grad_(True), V.clone().requires_grad_(True)
+    Rr = ref.relation_feature(Pr, Vr)
+    (Rr * w).sum().backward()
+    Pg, Vg = P.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
+    R = att.relation_feature(Pg, Vg)
+    (R * w.to(DEV)).sum().backward()
+    assert torch.equal(R.detach().cpu(), Rr.detach())  # one fp32 product per element: exact
+    for got, want in ((Pg.grad, Pr.grad), (Vg.grad, Vr.grad)):
+        assert float((got.cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
