@@ -16,7 +16,7 @@
 // wave(s) holding the maximum execute.  Two barriers per round.  Skipped / padded slots carry
 // temp = -1: fminf(d, -1) = -1 keeps them out of every arg-max exactly as the reference's `continue`.
 //   N <= 8 192   : coordinates in VGPRs too (fps_kernel)
-//   N <= 65 535  : Morton-bucketed scene, whole buckets skipped when provably unaffected (fps_bucket.inc)
+//   N <= 81 920  : Morton-bucketed scene, whole buckets skipped when provably unaffected (fps_bucket.inc)
 //   larger       : reference-style streaming with temp in the workspace (fps_generic_kernel)
 #include "common.hpp"
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void fps_generic_kernel(const float *__restr
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-// Large scenes (8 192 < N <= 65 535): spatially bucketed kernel with exact pruning.
+// Large scenes (8 192 < N <= 81 920): spatially bucketed kernel with exact pruning.
 #include "fps_bucket.inc"
 
 template <int BLOCK, int TPL>
@@ -196,7 +196,7 @@ void launch_fps(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hip
 // floats per scene) or the reference-style temp array (N floats per scene) of the generic kernel.
 extern "C" size_t spacap_fps_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
-  const size_t planes = N <= 65535 ? fps_bucket_workspace_floats(N) : 0;
+  const size_t planes = N <= 81920 ? fps_bucket_workspace_floats(N) : 0;
   const size_t per_scene = (planes > (size_t)N ? planes : (size_t)N) * sizeof(float);
   return (size_t)B * per_scene;
 }
@@ -229,7 +229,7 @@ extern "C" int spacap_fps_f32(const float *xyz, int B, int N, int m, void *works
 #undef FPS_CASE
   SPACAP_REQUIRE(workspace, "spacap_fps_f32: workspace required for N=%d", N);
   float *ws = reinterpret_cast<float *>(workspace);
-  if (N <= 65535) {  // u16 slot -> index map in LDS
+  if (N <= 81920) {  // bucketed kernel: index map as u16 in LDS up to 65 535 points, in the workspace beyond
     launch_fps_bucket(xyz, ws, B, N, m, lg, idx, s);
     SPACAP_CHECK_LAUNCH("spacap_fps_f32(bucket)");
     return SPACAP_OK;

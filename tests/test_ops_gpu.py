@@ -22,7 +22,7 @@ FPS_CASES = [  # (N, m) -- every kernel variant: 1-wave, 256-thread, 1024-thread
     (37, 37), (64, 16), (100, 30), (128, 128), (300, 64), (512, 256), (700, 100), (1024, 256), (1024, 512),
     (2048, 1024), (3000, 200), (4096, 512), (8192, 128), (8193, 100), (10000, 256), (12288, 64), (16000, 300),
     (20000, 256), (24576, 64),
-    (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (65535, 48), (65536, 48), (80000, 96),
+    (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (65535, 48), (65536, 48), (70000, 200), (80000, 96), (81920, 40), (81921, 24),
 ]
 
 
