@@ -98,6 +98,22 @@ class MultiHeadedAttention(nn.Module):
         return self.linears[-1](x)
 
 
+    def forward_incremental(self, x_new, cache, mask=None):
+        """Self-attention for the newest token(s) only: project q/k/v of ``x_new`` (B, t_new, d), append k/v to
+        ``cache`` (a dict holding 'k' and 'v' of the previous positions), attend over everything cached.  ``mask``
+        (B, t_new, t_total) is only needed when several new tokens are fed at once (the first step)."""
+        nb = x_new.size(0)
+        q, k, v = [l(x_new).view(nb, -1, self.h, self.d_k).transpose(1, 2) for l in self.linears[:3]]
+        if cache.get("k") is not None:
+            k = torch.cat([cache["k"], k], dim=2)
+            v = torch.cat([cache["v"], v], dim=2)
+        cache["k"], cache["v"] = k, v
+        m = mask.unsqueeze(1) if mask is not None else None
+        x, _ = attention(q, k.contiguous(), v.contiguous(), mask=m, dropout=self.dropout, need_p=False)
+        x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
+        return self.linears[-1](x)
+
+
 class PositionwiseFeedForward(nn.Module):
     def __init__(self, d_model, d_ff, dropout=0.1):
         super().__init__()
@@ -232,6 +248,19 @@ class DecoderLayer(nn.Module):
         if not self.early_guide:
             x = self.sublayer[1](x, lambda y: self.src_attn(y, m, m, src_mask))
         return self.sublayer[2](x, self.feed_forward)
+
+
+def decode_incremental(decoder, x_new, caches, memory=None, src_mask=None, mask=None):
+    """Run ``x_new`` (B, t_new, d) -- the positions not seen yet -- through the decoder stack, reusing the cached
+    keys / values of earlier positions (one dict per layer).  Pre-LN layers with a causal mask make this exactly
+    the last rows of the full recomputation the reference performs at every step (:435-438)."""
+    x = x_new
+    for layer, cache in zip(decoder.layers, caches):
+        x = x + layer.sublayer[0].dropout(layer.self_attn.forward_incremental(layer.sublayer[0].norm(x), cache, mask))
+        if not layer.early_guide:
+            x = layer.sublayer[1](x, lambda y: layer.src_attn(y, memory, memory, src_mask))
+        x = layer.sublayer[2](x, layer.feed_forward)
+    return decoder.norm(x)
 
 
 class _Identity(nn.Module):
@@ -377,9 +406,12 @@ class TransformerDecoderModel(nn.Module):
             ep["relation_pred"] = tall_linear(hid, rp[4])
         return ep
 
-    def forward_eval(self, ep):
-        """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder at every
-        one of the 31 steps; the encoder output does not depend on the words, so it is computed once."""
+    def forward_eval(self, ep, use_cache=True):
+        """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder AND the whole
+        decoder prefix at each of the 31 steps; the encoder output does not depend on the words (computed once),
+        and with ``use_cache`` the decoder keeps the keys / values of earlier positions so that each step only
+        processes the newest token (16x fewer token-layer evaluations).  ``use_cache=False`` recomputes the prefix
+        as the reference does (kept for parity tests)."""
         obj_features = ep["aggregated_vote_features"]
         B, K, _ = obj_features.shape
         src_pos = self._src_pos(ep)
@@ -396,12 +428,39 @@ class TransformerDecoderModel(nn.Module):
             memory = self.model.encode(src, src_pos, src_mask)
         obj_flat = obj_features.reshape(B * K, -1)
         ys = torch.full((B * K, 1), self.word_to_idx["sos"], dtype=torch.long, device=obj_features.device)
-        for _ in range(MAX_DES_LEN + 1):
-            L = ys.size(1) + 1 if self.early_guide else ys.size(1)
-            out = self.model(src, ys, src_mask, subsequent_mask(L, device=ys.device),
-                             obj_flat.unsqueeze(1), src_pos=src_pos, memory=memory)
-            prob = self.model.generator(out[:, -1, :])
-            next_word = prob.argmax(dim=-1)
+        if not use_cache:
+            for _ in range(MAX_DES_LEN + 1):
+                L = ys.size(1) + 1 if self.early_guide else ys.size(1)
+                out = self.model(src, ys, src_mask, subsequent_mask(L, device=ys.device),
+                                 obj_flat.unsqueeze(1), src_pos=src_pos, memory=memory)
+                next_word = self.model.generator(out[:, -1, :]).argmax(dim=-1)
+                ys = torch.cat([ys, next_word.unsqueeze(1)], dim=1)
+            ep["lang_cap"] = ys[:, 1:].view(B, K, -1)
+            return ep
+        # -- cached path -----------------------------------------------------------------------------------
+        dec = self.model.decoder
+        caches = [dict() for _ in dec.layers]
+        if memory.shape[0] != B * K:  # encoder ran once per scene: the indicator adds that proposal's memory row
+            indicator = obj_flat.unsqueeze(1) + memory.reshape(B * K, -1).unsqueeze(1)
+            dec_memory = None
+        else:
+            indicator, dec_memory = obj_flat.unsqueeze(1), memory
+        embed, pos = self.model.tgt_embed[0], self.model.tgt_embed[1]
+        if self.early_guide:
+            # positions: 0 = object indicator, 1.. = words (sinusoid added to the words only, as tgt_embed does)
+            x_new = torch.cat((indicator, pos.dropout(embed(ys) + pos.pe[:, :1])), dim=1)
+            mask = subsequent_mask(2, device=ys.device).expand(B * K, -1, -1)
+            cross_mem, cross_mask = dec_memory, src_mask
+        else:
+            x_new = pos.dropout(embed(ys) + pos.pe[:, :1])
+            mask = None
+            cross_mem, cross_mask = indicator, None  # late guide: cross-attention over the 1-token indicator (:266)
+        for step in range(MAX_DES_LEN + 1):
+            out = decode_incremental(dec, x_new, caches, memory=cross_mem, src_mask=cross_mask, mask=mask)
+            next_word = self.model.generator(out[:, -1, :]).argmax(dim=-1)
             ys = torch.cat([ys, next_word.unsqueeze(1)], dim=1)
+            t = ys.size(1) - 1  # index of the newest word within the word sequence
+            x_new = pos.dropout(embed(next_word.unsqueeze(1)) + pos.pe[:, t:t + 1])
+            mask = None
         ep["lang_cap"] = ys[:, 1:].view(B, K, -1)
         return ep

@@ -145,6 +145,10 @@ def test_eval_greedy_decoding_matches_reference(kind):
     assert caps.shape == ev["lang_cap"].shape
     # greedy arg-max chains: identical unless two words tie to within float noise (none do on this fixture)
     assert (caps == ev["lang_cap"]).mean() > 0.999
+    # the same captions must come out of the reference-style loop that recomputes the whole prefix at every step
+    with backend.use_backend(be), torch.no_grad():
+        d2 = model.caption.forward_eval(dict(d), use_cache=False)
+    assert (d2["lang_cap"].cpu().numpy() == ev["lang_cap"]).mean() > 0.999
 
 
 @pytest.mark.parametrize("kind", LEGS)
