@@ -203,6 +203,20 @@ int spacap_relation_feature_bwd_f32(const float *dR, const float *P, const float
                                     long v_sl, int B, int H, int K, int D, float *dP, float *dV,
                                     spacap_stream_t stream);
 
+/* First layer of the relation MLP fused with the feature (models/transformer_captioner.py:319-326,393-397):
+ *   H1[b,i,j,o] = relu(b1[o] + sum_h P[b,h,i,j] * U[b,j,h,o]),  U[b,j,h,o] = sum_d V[b,h,j,d] * W1[o,h*D+d]
+ * (= relu(R W1^T + b1) without ever forming R).  P f32 [B,H,K,K], U f32 [B,K,H,C], b1 f32 [C], H1 f32 [B,K,K,C],
+ * all dense; H in {4,8,16,32}, C in {16,32,64,128,256}. */
+int spacap_relation_l1_fwd_f32(const float *P, const float *U, const float *b1, int B, int H, int K, int C,
+                               float *H1, spacap_stream_t stream);
+/* dH1, H1 f32 [B,K,K,C] -> dP f32 [B,H,K,K]; dU_part f32 [spacap_relation_l1_isplit(), B,K,H,C] and
+ * db_part f32 [spacap_relation_l1_blocks(B,K,C), C] are partial sums (per query chunk / per workgroup) that the
+ * caller adds up in order. */
+int spacap_relation_l1_isplit(void);
+int spacap_relation_l1_blocks(int B, int K, int C);
+int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, const float *P, const float *U, int B, int H,
+                               int K, int C, float *dP, float *dU, float *db_part, spacap_stream_t stream);
+
 /* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
 
 /* y = a * (x - mean) / (std_unbiased + eps) + b over the last dimension; x,y f32 [rows, D] dense, a,b f32 [D];

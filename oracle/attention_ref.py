@@ -53,6 +53,11 @@ def bn_relu_train(z, bn, pool_S=None):
     return y
 
 
+def relation_layer1(P, V, weight, bias):
+    """relu(Linear(relation_feature(P, V))) as the reference computes it (:393-397 + first two modules of :319-326)."""
+    return F.relu(F.linear(relation_feature(P, V), weight, bias))
+
+
 class OracleBackend:
     """`backend` object for spacap3d_amd.backend.use_backend(): oracle ops + torch attention, CPU tensors."""
 
@@ -68,6 +73,7 @@ class OracleBackend:
         self.attention = attention
         self.layer_norm = layer_norm
         self.relation_feature = relation_feature
+        self.relation_layer1 = relation_layer1
         self.bn_relu_train = bn_relu_train
 
     # max over the samples of a group: F.max_pool2d(x, [1, S]) of pointnet2_modules.py:256-259 (first maximum wins)

@@ -50,6 +50,10 @@ SIGNATURES = {
     "spacap_bn_relu_max_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_relation_feature_fwd_f32": (_i, [_p, _p, _l, _l, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_feature_bwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_relation_l1_isplit": (_i, []),
+    "spacap_relation_l1_blocks": (_i, [_i, _i, _i]),
+    "spacap_relation_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_relation_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),

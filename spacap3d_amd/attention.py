@@ -222,3 +222,45 @@ class RelationFeature(Function):
 
 def relation_feature(P, V):
     return RelationFeature.apply(P, V)
+
+
+class RelationLayer1(Function):
+    """relu(b1 + sum_h P[b,h,i,j] * U[b,j,h,:])  -- see csrc/relation.hip."""
+
+    @staticmethod
+    def forward(ctx, P, U, b1):
+        P, U = P.contiguous(), U.contiguous()
+        B, H, K, _ = P.shape
+        C = U.shape[-1]
+        with torch.cuda.device(P.device):
+            H1 = torch.empty(B, K, K, C, dtype=torch.float32, device=P.device)
+            check(lib.spacap_relation_l1_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), B, H, K, C, H1.data_ptr(),
+                                                 torch.cuda.current_stream(P.device).cuda_stream), "spacap_relation_l1_fwd_f32")
+        ctx.save_for_backward(P, U, H1)
+        return H1
+
+    @staticmethod
+    def backward(ctx, dH1):
+        P, U, H1 = ctx.saved_tensors
+        B, H, K, _ = P.shape
+        C = U.shape[-1]
+        dH1 = dH1.contiguous()
+        with torch.cuda.device(P.device):
+            dP = torch.empty_like(P)
+            dU = torch.empty(int(lib.spacap_relation_l1_isplit()), *U.shape, dtype=torch.float32, device=P.device)
+            part = torch.empty(int(lib.spacap_relation_l1_blocks(B, K, C)), C, dtype=torch.float32, device=P.device)
+            check(lib.spacap_relation_l1_bwd_f32(dH1.data_ptr(), H1.data_ptr(), P.data_ptr(), U.data_ptr(), B, H, K, C,
+                                                 dP.data_ptr(), dU.data_ptr(), part.data_ptr(),
+                                                 torch.cuda.current_stream(P.device).cuda_stream), "spacap_relation_l1_bwd_f32")
+        return dP, dU.sum(0), part.sum(0)
+
+
+def relation_layer1(P, V, weight, bias):
+    """First Linear + ReLU of the relation MLP applied to the relation feature of (P, V), without forming the feature:
+    P (B,h,K,K), V (B,h,K,d) (any strides), weight (C, h*d), bias (C) -> (B,K,K,C)."""
+    if not P.is_cuda:
+        raise RuntimeError("CPU not supported")
+    B, H, K, D = V.shape
+    C = weight.shape[0]
+    U = torch.einsum("bhjd,ohd->bjho", V, weight.view(C, H, D))  # (B,K,H,C): tiny, autograd gives dV and dW1
+    return RelationLayer1.apply(P, U, bias)

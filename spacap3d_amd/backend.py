@@ -26,6 +26,7 @@ class HipBackend:
         self.attention = _att.attention
         self.layer_norm = _att.layer_norm
         self.relation_feature = _att.relation_feature
+        self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
 

@@ -95,3 +95,159 @@ extern "C" int spacap_relation_feature_bwd_f32(const float *dR, const float *P, 
   SPACAP_CHECK_LAUNCH("spacap_relation_feature_bwd_f32");
   return SPACAP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// First layer of the relation MLP, fused with the feature:   H1 = relu(R W1^T + b1),  R = P (x) V
+// (models/transformer_captioner.py:319-326,393-397).  Because R[b,i,j,h*D+d] = P[b,h,i,j] * V[b,h,j,d],
+//     H1[b,i,j,o] = relu(b1[o] + sum_h P[b,h,i,j] * U[b,j,h,o]),     U[b,j,h,o] = sum_d V[b,h,j,d] * W1[o,h*D+d]
+// so the 268 MB feature tensor never exists and the layer needs H (= 8) multiply-adds per output instead of H*D
+// (= 128).  U (B,K,H,C: 8 MB) is a tiny batched GEMM done by the caller (whose autograd also turns dU into dV, dW1).
+// One workgroup owns 256 / (C/4) key columns j and walks all queries i: U stays in registers, P is the only
+// per-pair input (8 floats), H1 is written once; the backward reads dH1 and H1 once and produces dP, dU (register
+// accumulation over i) and per-workgroup partial sums of db1 -- fixed summation order, no atomics.
+namespace {
+
+template <int H>
+__global__ __launch_bounds__(256) void relation_l1_fwd_kernel(const float *__restrict__ P, const float *__restrict__ U,
+                                                              const float *__restrict__ b1, int K, int C,
+                                                              float *__restrict__ H1) {
+  const int C4 = C / 4, RPI = 256 / C4;
+  const int b = blockIdx.y;
+  const int c4 = threadIdx.x % C4, jj = threadIdx.x / C4;
+  const int j = blockIdx.x * RPI + jj;
+  const bool ok = j < K;
+  const int jc = ok ? j : K - 1;
+  f32x4 u[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+    u[h] = *reinterpret_cast<const f32x4 *>(U + (((size_t)b * K + jc) * H + h) * C + c4 * 4);
+  const f32x4 bias = *reinterpret_cast<const f32x4 *>(b1 + c4 * 4);
+  const float *pcol = P + ((size_t)b * H * K) * K + jc;
+  float *out = H1 + ((size_t)b * K * K + jc) * C + c4 * 4;
+  const int ichunk = (K + gridDim.z - 1) / gridDim.z, ibeg = blockIdx.z * ichunk, iend = min(K, ibeg + ichunk);
+  for (int i = ibeg; i < iend; ++i) {
+    f32x4 acc = bias;
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc += u[h] * pcol[((size_t)h * K + i) * K];
+    acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    if (ok) *reinterpret_cast<f32x4 *>(out + (size_t)i * K * C) = acc;
+  }
+}
+
+// Backward.  Thread (jj, c4) keeps U[b, j, :, 4 c4 .. 4 c4 + 3] in registers and walks the queries i in batches of
+// NBI = 256 / (RPI * H): per (i, h) it forms its 4-term piece of dP[b,h,i,j] = sum_o g[o] * U[j,h,o]; the C/4 pieces of
+// one output are added through LDS (one row per output, padded against bank conflicts) by the thread that owns that
+// output -- 256 outputs per batch, one per thread -- instead of 5 shuffle steps per head and query.
+template <int H>
+__global__ __launch_bounds__(256) void relation_l1_bwd_kernel(const float *__restrict__ dH1, const float *__restrict__ H1,
+                                                              const float *__restrict__ P, const float *__restrict__ U,
+                                                              int K, int C, float *__restrict__ dP,
+                                                              float *__restrict__ dU, float *__restrict__ db_part) {
+  extern __shared__ float s_mem[];  // [256][C4 + 1] partial dots, then [RPI][C] for db
+  const int C4 = C / 4, RPI = 256 / C4, NBI = 256 / (RPI * H), LD = C4 + 1;
+  const int b = blockIdx.y;
+  const int c4 = threadIdx.x % C4, jj = threadIdx.x / C4;
+  const int j = blockIdx.x * RPI + jj;
+  const bool ok = j < K;
+  const int jc = ok ? j : K - 1;
+  f32x4 u[H], du[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    u[h] = *reinterpret_cast<const f32x4 *>(U + (((size_t)b * K + jc) * H + h) * C + c4 * 4);
+    du[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 db = {0.f, 0.f, 0.f, 0.f};
+  const float *pcol = P + ((size_t)b * H * K) * K + jc;
+  const size_t base = ((size_t)b * K * K + jc) * C + c4 * 4;
+  // the output this thread finishes in the reduction phase: (ii, jj2, h2)
+  const int o_h = threadIdx.x % H, o_jj = (threadIdx.x / H) % RPI, o_ii = threadIdx.x / (H * RPI);
+  const int o_j = blockIdx.x * RPI + o_jj;
+  // the queries are cut into gridDim.z chunks (more workgroups in flight to hide the strided reads); every chunk
+  // writes its own partial dU / db, summed by the caller in chunk order
+  const int ichunk = (K + gridDim.z - 1) / gridDim.z, ibeg = blockIdx.z * ichunk, iend = min(K, ibeg + ichunk);
+  for (int i0 = ibeg; i0 < iend; i0 += NBI) {
+#pragma unroll 4
+    for (int ii = 0; ii < NBI; ++ii) {
+      const int i = i0 + ii;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (ok && i < iend) {
+        const size_t off = base + (size_t)i * K * C;
+        g = *reinterpret_cast<const f32x4 *>(dH1 + off);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(H1 + off);
+        g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+      }
+      db += g;
+      const int ic = i < iend ? i : iend - 1;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        du[h] += g * pcol[((size_t)h * K + ic) * K];
+        s_mem[((ii * RPI + jj) * H + h) * LD + c4] = g.x * u[h].x + g.y * u[h].y + g.z * u[h].z + g.w * u[h].w;
+      }
+    }
+    __syncthreads();
+    {
+      const float *row = s_mem + threadIdx.x * LD;
+      float s = 0.f;
+      for (int q = 0; q < C4; ++q) s += row[q];
+      const int i = i0 + o_ii;
+      if (o_ii < NBI && i < iend && o_j < K) dP[(((size_t)b * H + o_h) * K + i) * K + o_j] = s;
+    }
+    __syncthreads();
+  }
+  if (ok) {
+    float *duo = dU + (size_t)blockIdx.z * gridDim.y * K * H * C;  // partial of this i-chunk: [z][B][K][H][C]
+#pragma unroll
+    for (int h = 0; h < H; ++h) *reinterpret_cast<f32x4 *>(duo + (((size_t)b * K + j) * H + h) * C + c4 * 4) = du[h];
+  }
+  *reinterpret_cast<f32x4 *>(&s_mem[jj * C + c4 * 4]) = db;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float s = 0.f;
+    for (int r = 0; r < RPI; ++r) s += s_mem[r * C + threadIdx.x];
+    db_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C + threadIdx.x] = s;
+  }
+}
+
+bool l1_shape_ok(int H, int K, int C) {
+  return (H == 4 || H == 8 || H == 16 || H == 32) && K >= 1 && C % 4 == 0 && C >= 16 && C <= 256 && 256 % (C / 4) == 0 &&
+         (C / 4) <= 64 && (256 / (C / 4)) * H <= 256;
+}
+
+}  // namespace
+
+constexpr int L1_ISPLIT = 4;  // query chunks per key tile in the backward (partial dU / db per chunk)
+extern "C" int spacap_relation_l1_isplit(void) { return L1_ISPLIT; }
+extern "C" int spacap_relation_l1_blocks(int B, int K, int C) {
+  return L1_ISPLIT * B * ((K + 256 / (C / 4) - 1) / (256 / (C / 4)));
+}
+
+extern "C" int spacap_relation_l1_fwd_f32(const float *P, const float *U, const float *b1, int B, int H, int K, int C,
+                                          float *H1, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && l1_shape_ok(H, K, C), "spacap_relation_l1_fwd_f32: unsupported shape H=%d K=%d C=%d", H, K, C);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(P && U && b1 && H1 && B <= 65535, "spacap_relation_l1_fwd_f32: null pointer");
+  const int RPI = 256 / (C / 4);
+  dim3 grid((K + RPI - 1) / RPI, B, 4);
+  hipStream_t s = spacap::as_stream(stream);
+#define L1F(HV) if (H == HV) hipLaunchKernelGGL((relation_l1_fwd_kernel<HV>), grid, dim3(256), 0, s, P, U, b1, K, C, H1);
+  L1F(4) L1F(8) L1F(16) L1F(32)
+#undef L1F
+  SPACAP_CHECK_LAUNCH("spacap_relation_l1_fwd_f32");
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, const float *P, const float *U, int B, int H,
+                                          int K, int C, float *dP, float *dU, float *db_part, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && l1_shape_ok(H, K, C), "spacap_relation_l1_bwd_f32: unsupported shape H=%d K=%d C=%d", H, K, C);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(dH1 && H1 && P && U && dP && dU && db_part && B <= 65535, "spacap_relation_l1_bwd_f32: null pointer");
+  const int RPI = 256 / (C / 4);
+  dim3 grid((K + RPI - 1) / RPI, B, L1_ISPLIT);
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t lds = sizeof(float) * (256 * (C / 4 + 1) > RPI * C ? 256 * (C / 4 + 1) : RPI * C);
+#define L1B(HV) if (H == HV) hipLaunchKernelGGL((relation_l1_bwd_kernel<HV>), grid, dim3(256), lds, s, dH1, H1, P, U, K, C, dP, dU, db_part);
+  L1B(4) L1B(8) L1B(16) L1B(32)
+#undef L1B
+  SPACAP_CHECK_LAUNCH("spacap_relation_l1_bwd_f32");
+  return SPACAP_OK;
+}

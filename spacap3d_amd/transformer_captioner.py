@@ -401,7 +401,9 @@ class TransformerDecoderModel(nn.Module):
         ep["good_bbox_masks"] = good
         if self.check_relation:
             rp = self.relation_proposal  # Linear-ReLU-Linear-ReLU-Linear (:319-326)
-            hid = F.relu(tall_linear(self.relation_feature(), rp[0]))
+            sa = self.model.encoder.layers[-1].self_attn
+            # feature (P (x) V) + first Linear + ReLU in one kernel: the (B,K,K,128) feature is never formed
+            hid = ops().relation_layer1(sa.attn, sa.value, rp[0].weight, rp[0].bias)
             hid = F.relu(tall_linear(hid, rp[2]))
             ep["relation_pred"] = tall_linear(hid, rp[4])
         return ep

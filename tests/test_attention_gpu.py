@@ -185,3 +185,27 @@ def test_relation_feature_matches_reference_chain(att, B, H, K, D):
     assert torch.equal(R.detach().cpu(), Rr.detach())  # one fp32 product per element: exact
     for got, want in ((Pg.grad, Pr.grad), (Vg.grad, Vr.grad)):
         assert float((got.cpu() - want).abs().max()) / float(want.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,K,D", [(2, 8, 256, 16), (1, 8, 50, 16), (1, 4, 33, 32), (2, 32, 24, 4)])
+def test_fused_relation_layer1_matches_feature_linear_relu(att, B, H, K, D):
+    """relu(Linear(P (x) V)) of models/transformer_captioner.py:393-397,319-321 without forming the feature."""
+    g = torch.Generator().manual_seed(K + H)
+    C = H * D
+    P = torch.rand(B, H, K, K, generator=g)
+    V = torch.randn(B, K, H, D, generator=g).transpose(1, 2)
+    W = torch.randn(C, C, generator=g) / C ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    w = torch.randn(B, K, K, C, generator=g)
+    gpu = [t.to(DEV).requires_grad_(True) for t in (P, V, W, b)]
+    y = att.relation_layer1(*gpu)
+    (y * w.to(DEV)).sum().backward()
+    # fp64 reference; the ReLU mask is taken from the kernel's own output so that pre-activations within rounding
+    # error of zero (different summation order: H multiply-adds here, H*D in the reference) do not flip gradients
+    refs = [t.double().clone().requires_grad_(True) for t in (P, V, W, b)]
+    pre = torch.nn.functional.linear(ref.relation_feature(refs[0], refs[1]), refs[2], refs[3])
+    torch.testing.assert_close(y.detach().cpu().double(), torch.relu(pre.detach()), rtol=1e-4, atol=1e-5)
+    ((pre * (y.detach().cpu() > 0).double()) * w.double()).sum().backward()
+    for got, want, name in zip(gpu, refs, "PVWb"):
+        err = float((got.grad.cpu().double() - want.grad).abs().max()) / (float(want.grad.abs().max()) + 1e-12)
+        assert err < 1e-4, (name, err)
