@@ -229,6 +229,58 @@ int spacap_layernorm_bwd_f32(const float *x, const float *a, const float *stats,
                              int D, float eps, float *dx, float *da, float *db, void *workspace,
                              spacap_stream_t stream);
 
+/* ---- Shared MLP of a set-abstraction module, point-major layout, training mode --------------------------------
+ * Replaces the per-module chain QueryAndGroup -> SharedMLP([Conv2d 1x1 -> BatchNorm2d -> ReLU] x 3) -> max_pool2d
+ * (lib/pointnet2/pointnet2_modules.py:241-259, lib/pointnet2/pytorch_utils.py:11-36) for the training step.
+ * Rows r = (b, centre n, sample s), R = B*N*S; activations z_k are f32 [R, C_k] dense; G = B*N groups.
+ * stats f32 [C,4] = (mean, 1/sqrt(var+eps), gamma/sqrt(var+eps), beta); coef f32 [C,4] = (g, k0, k1, -) with
+ * dz = g*dy + k0 - k1*z.  part: f64 [spacap_sa_nparts(), 2, C] partial sums (workspace, fully overwritten). */
+int spacap_sa_nparts(void);
+int spacap_sa_nslabs(void);
+/* 1 when (C1, C2, C3) has kernels: (64,64,128), (128,128,128), (128,128,256). */
+int spacap_sa_mlp_supported(int C1, int C2, int C3);
+/* z1[r,:] = Y[b,idx[r],:] + W1[:,0:3] (xyz[b,idx[r]] - new_xyz[b,n]) / rdiv + W1[:,3] feat[b,idx[r]].
+ * Y f32 [B,Np,C1] or NULL, feat f32 [B,Np] or NULL, xyz f32 [B,Np,3], new_xyz f32 [B,N,3], idx i32 [B,N,S],
+ * W1 f32 rows of ldw floats; C1 in {64,128}. */
+int spacap_sa_l1_fwd_f32(const float *Y, const float *feat, const float *xyz, const float *new_xyz,
+                         const int32_t *idx, const float *W1, int ldw, float rdiv, int B, int Np, int N, int S,
+                         int C1, float *z1, double *part, spacap_stream_t stream);
+/* part -> stats; running_mean / running_var (may be NULL) get torch's momentum update (unbiased variance). */
+int spacap_sa_bn_finalize_f32(const double *part, int C, long count, float eps, float momentum, const float *gamma,
+                              const float *beta, float *running_mean, float *running_var, float *stats,
+                              spacap_stream_t stream);
+/* zout = relu(bn(zin)) W^T, W f32 [Cout, Cin]; part receives the sums of zout. */
+int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const float *W, long R, int Cin, int Cout,
+                          float *zout, double *part, spacap_stream_t stream);
+/* out[g,c] = max_s relu(bn(z[g*S+s,c])) (first maximum), arg u8 [G,C]. */
+int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out, uint8_t *arg,
+                           spacap_stream_t stream);
+/* dym = (out > 0) ? dout : 0; part receives (sum dy, sum dy*xhat) of the pooled layer. */
+int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z,
+                           const float *stats, long G, int S, int C, float *dym, double *part,
+                           spacap_stream_t stream);
+/* part -> coef, dgamma, dbeta of a layer (stats = that layer's forward statistics). */
+int spacap_sa_bwd_finalize_f32(const double *part, int C, long count, const float *stats, float *coef,
+                               float *dgamma, float *dbeta, spacap_stream_t stream);
+/* dy_prev = (dz_k W_k) * [relu'(bn(z_prev))], W_k f32 [CK, CP]; dy = dense [R,CK] gradient when arg == NULL, else
+ * the masked pooled gradient [R/S, CK] with its arg-max map.  part receives the BN sums of dy_prev. */
+int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
+                        const float *Wk, const float *zp, const float *st_p, long R, int CK, int CP, float *dyp,
+                        double *part, spacap_stream_t stream);
+/* partW f32 [spacap_sa_nslabs(), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
+int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
+                        const float *zp, const float *st_p, long R, int CK, int CP, float *partW,
+                        spacap_stream_t stream);
+/* dy1 <- dz1 in place; partW f32 [spacap_sa_nparts(), C1, 4] partial dW1 (rel x, y, z, inline feature);
+ * drel f32 [R,3] (d loss / d (xyz[idx] - new_xyz)) or NULL. */
+int spacap_sa_l1_bwd_f32(float *dy1, const float *z1, const float *coef, const float *feat, const float *xyz,
+                         const float *new_xyz, const int32_t *idx, const float *W1, int ldw, float rdiv, int B,
+                         int Np, int N, int S, int C1, float *partW, float *drel, spacap_stream_t stream);
+/* out[b,p,:] = sum over rows r = (b,e), e < E, with idx[b,e] = p of dz[r,:] in ascending r (inverted index). */
+size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E);
+int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
+                               void *workspace, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

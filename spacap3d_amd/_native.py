@@ -54,6 +54,20 @@ SIGNATURES = {
     "spacap_relation_l1_blocks": (_i, [_i, _i, _i]),
     "spacap_relation_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "spacap_sa_nparts": (_i, []),
+    "spacap_sa_nslabs": (_i, []),
+    "spacap_sa_mlp_supported": (_i, [_i, _i, _i]),
+    "spacap_sa_l1_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_bn_finalize_f32": (_i, [_p, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "spacap_sa_mid_fwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_pool_fwd_f32": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_bwd_finalize_f32": (_i, [_p, _i, _l, _p, _p, _p, _p, _p]),
+    "spacap_sa_dgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_wgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p, _p]),
+    "spacap_sa_l1_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_rows_scatter_workspace_bytes": (ctypes.c_size_t, [_i, _i, _l]),
+    "spacap_sa_rows_scatter_f32": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),

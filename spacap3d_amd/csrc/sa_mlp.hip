@@ -1,0 +1,791 @@
+// Shared MLP of a set-abstraction module in point-major ("rows") layout, training mode, for gfx950 (MI355X).
+//
+// Replaces, for the training step, the chain the reference runs per SA module
+// (lib/pointnet2/pointnet2_modules.py:241-259: QueryAndGroup -> SharedMLP -> max_pool2d, with SharedMLP =
+// [Conv2d 1x1 -> BatchNorm2d -> ReLU] x 3, lib/pointnet2/pytorch_utils.py:11-36) on (B, C, npoint, nsample)
+// tensors.  Same mathematics (fp32, batch statistics over all B*npoint*nsample positions, biased variance,
+// eps inside the square root, first-maximum pooling), different data flow:
+//
+//   * rows r = (b, centre, sample) are the slow index, channels the fast one: every pass over an activation is one
+//     contiguous stream, the 1x1 convolutions are row-major GEMMs on the matrix cores (v_mfma_f32_16x16x4_f32,
+//     fp32 in / fp32 accumulate), and no NCHW <-> NHWC transposes exist;
+//   * the first layer commutes with the grouping gather:  W1 [rel_xyz ; f(idx)] = Wx rel_xyz + (Wf f)(idx), so
+//     Wf f is computed once per SOURCE point (8..16x fewer rows than grouped positions) and layer 1 is a gather
+//     of that product plus a 3-term update (sa_l1_fwd_kernel);
+//   * only the pre-activation z_k of every layer is stored; BatchNorm + ReLU of layer k are applied while the
+//     tile is staged into LDS for layer k+1 (and again in the backward), and each layer's batch statistics are
+//     accumulated in the epilogue of the GEMM that produces it -- one write and one read per activation in the
+//     forward pass instead of write + 3 reads + write;
+//   * the backward of max-pool -> ReLU -> BN is evaluated on the fly from (masked pooled gradient, argmax, z_k)
+//     while staging the GEMM operands: dz_k = g dy + k0 - k1 z_k with per-channel constants (sa_bwd_finalize).
+//
+// Weights stay in registers for the whole kernel (each wave owns 16*NT output channels); the activation tile
+// (64 rows) goes through LDS with a 4-word row padding, which makes the MFMA operand reads conflict-free.
+// All reductions (statistics, weight gradients) are two-stage with a fixed order: no float atomics.
+#include <hipcub/hipcub.hpp>
+
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int TM = 64;      // rows per tile of the forward / data-gradient GEMMs
+constexpr int TW = 32;      // rows per tile of the weight-gradient GEMM
+constexpr int NPART = 1024; // partial-sum rows (= persistent workgroups) of every statistics reduction
+constexpr int NSLAB = 256;  // row slabs of the weight-gradient GEMM
+
+// stats row of a layer: {mean, 1/sqrt(var+eps), gamma/sqrt(var+eps), beta}
+// coef  row of a layer (backward): {g, k0, k1, -}:  dz = g*dy + k0 - k1*z
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// ---- layer 1 forward --------------------------------------------------------------------------------------
+// z1[r, :] = Y[b, idx[r], :] + W1[:, 0:3] rel(r) + W1[:, 3] feat[b, idx[r]]      (Y and feat optional)
+// rel(r) = (xyz[b, idx[r]] - new_xyz[b, n]) / rdiv
+template <int C1>
+__global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict__ Y, const float *__restrict__ feat,
+                                                        const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                        const int32_t *__restrict__ idx, const float *__restrict__ W1,
+                                                        int ldw, float rdiv, int Np, int N, int S, long R,
+                                                        float *__restrict__ z1, double *__restrict__ part) {
+  constexpr int C4 = C1 / 4, RP = 256 / C4;
+  __shared__ float s_red[2][RP][C1];
+  const int tid = threadIdx.x, c4 = tid % C4, rs = tid / C4;
+  f32x4 wx, wy, wz, wf = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *w = W1 + (size_t)(c4 * 4 + u) * ldw;
+    wx[u] = w[0], wy[u] = w[1], wz[u] = w[2];
+    if (feat) wf[u] = w[3];
+  }
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  const long NS = (long)N * S;
+  for (long r = (long)blockIdx.x * RP + rs; r < R; r += (long)gridDim.x * RP) {
+    const long b = r / NS, g = r / S;
+    const int p = idx[r];
+    const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)g * 3;
+    const float rx = (q[0] - c[0]) / rdiv, ry = (q[1] - c[1]) / rdiv, rz = (q[2] - c[2]) / rdiv;
+    f32x4 z = wx * rx + wy * ry + wz * rz;
+    if (feat) z += wf * feat[(size_t)b * Np + p];
+    if (Y) z += ld4(Y + ((size_t)b * Np + p) * C1 + c4 * 4);
+    st4(z1 + (size_t)r * C1 + c4 * 4, z);
+    sum += z;
+    sq += z * z;
+  }
+  st4(&s_red[0][rs][c4 * 4], sum);
+  st4(&s_red[1][rs][c4 * 4], sq);
+  __syncthreads();
+  if (tid < 2 * C1) {
+    const int k = tid / C1, c = tid % C1;
+    double a = 0.0;
+    for (int i = 0; i < RP; ++i) a += (double)s_red[k][i][c];
+    part[((size_t)blockIdx.x * 2 + k) * C1 + c] = a;
+  }
+}
+
+// ---- statistics finalisation --------------------------------------------------------------------------------
+// part [NPART][2][C] (sum, sum of squares) -> stats [C][4]; optional running-statistics update (torch semantics)
+__global__ __launch_bounds__(256) void sa_bn_finalize_kernel(const double *__restrict__ part, int nparts, int C,
+                                                             double M, float eps, float momentum,
+                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ running_mean,
+                                                             float *__restrict__ running_var, float *__restrict__ stats) {
+  // workgroup = 8 channels x {sum, sq} x 16 slabs of partial rows
+  __shared__ double s[16][16];
+  const int tid = threadIdx.x, col = tid & 15, slab = tid >> 4;
+  const int k = col >> 3, c = blockIdx.x * 8 + (col & 7);
+  double a = 0.0;
+  if (c < C)
+    for (int p = slab; p < nparts; p += 16) a += part[((size_t)p * 2 + k) * C + c];
+  s[slab][col] = a;
+  __syncthreads();
+  if (tid < 8 && c < C) {
+    double sm = 0.0, q = 0.0;
+    for (int i = 0; i < 16; ++i) sm += s[i][tid], q += s[i][tid + 8];
+    const double mean = sm / M;
+    double var = q / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    stats[c * 4 + 0] = (float)mean;
+    stats[c * 4 + 1] = istd;
+    stats[c * 4 + 2] = gamma[c] * istd;
+    stats[c * 4 + 3] = beta[c];
+    if (running_mean) {
+      const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+// part [NPART][2][C] (sum dy, sum dy*xhat) -> coef [C][4], dgamma, dbeta
+__global__ __launch_bounds__(256) void sa_bwd_finalize_kernel(const double *__restrict__ part, int nparts, int C,
+                                                              double M, const float *__restrict__ stats,
+                                                              float *__restrict__ coef, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+  __shared__ double s[16][16];
+  const int tid = threadIdx.x, col = tid & 15, slab = tid >> 4;
+  const int k = col >> 3, c = blockIdx.x * 8 + (col & 7);
+  double a = 0.0;
+  if (c < C)
+    for (int p = slab; p < nparts; p += 16) a += part[((size_t)p * 2 + k) * C + c];
+  s[slab][col] = a;
+  __syncthreads();
+  if (tid < 8 && c < C) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < 16; ++i) s1 += s[i][tid], s2 += s[i][tid + 8];
+    const float mean = stats[c * 4], istd = stats[c * 4 + 1], g = stats[c * 4 + 2];
+    const float a1 = (float)(s1 / M), b1 = (float)(s2 / M);
+    const float k1 = g * b1 * istd;
+    coef[c * 4 + 0] = g;
+    coef[c * 4 + 1] = k1 * mean - g * a1;
+    coef[c * 4 + 2] = k1;
+    coef[c * 4 + 3] = 0.f;
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+  }
+}
+
+// ---- middle layers forward: zout = relu(bn(zin)) W^T, statistics of zout -------------------------------------
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
+                                                         const float *__restrict__ W, int Cout, long R,
+                                                         float *__restrict__ zout, double *__restrict__ part) {
+  constexpr int LD = CIN + 4, KS = CIN / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  extern __shared__ __attribute__((aligned(16))) float s_a[];  // [TM][LD]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.y * 64 * NT + w * 16 * NT;
+  float wf[NT][KS];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[j][ks] = W[(size_t)(cb + 16 * j + l15) * CIN + ks * 4 + lg];
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 mean, sc, be;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+    mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+  }
+  f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TM - 1) / TM;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * TM;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) {
+        const f32x4 v = ld4(zin + (size_t)(row0 + row) * CIN + c4 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = fmaxf((v[u] - mean[u]) * sc[u] + be[u], 0.f);
+      }
+      st4(&s_a[row * LD + c4 * 4], a);
+    }
+    __syncthreads();
+    f32x4 acc[TM / 16][NT];
+#pragma unroll
+    for (int mt = 0; mt < TM / 16; ++mt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < TM / 16; ++mt) {
+        const float b = s_a[(mt * 16 + l15) * LD + ks * 4 + lg];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < TM / 16; ++mt) {
+      const long grow = row0 + mt * 16 + l15;
+      if (grow < R) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          st4(zout + (size_t)grow * Cout + cb + 16 * j + 4 * lg, acc[mt][j]);
+          ssum[j] += acc[mt][j];
+          ssq[j] += acc[mt][j] * acc[mt][j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = ssum[j][u], q = ssq[j][u];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      if (l15 == 0) {
+        const int c = cb + 16 * j + 4 * lg + u;
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)a;
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)q;
+      }
+    }
+}
+
+// ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
+__global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ st,
+                                                          long G, int S, int C, float *__restrict__ out,
+                                                          uint8_t *__restrict__ arg) {
+  const int C4 = C / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * C4) return;
+  const long g = i / C4;
+  const int c4 = (int)(i % C4);
+  f32x4 mean, sc, be;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = st + (size_t)(c4 * 4 + u) * 4;
+    mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+  }
+  f32x4 best = {-1.f, -1.f, -1.f, -1.f};
+  int bi[4] = {0, 0, 0, 0};
+  const float *p = z + ((size_t)g * S) * C + c4 * 4;
+#pragma unroll 4
+  for (int s = 0; s < S; ++s, p += C) {
+    const f32x4 v = ld4(p);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = fmaxf((v[u] - mean[u]) * sc[u] + be[u], 0.f);
+      if (a > best[u]) best[u] = a, bi[u] = s;
+    }
+  }
+  st4(out + (size_t)g * C + c4 * 4, best);
+  *reinterpret_cast<uchar4 *>(arg + (size_t)g * C + c4 * 4) =
+      make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+}
+
+// ---- pooling backward, pass 1: masked gradient dym = (out > 0) ? dout : 0 and the BN sums over the arg-max rows
+__global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out,
+                                                          const uint8_t *__restrict__ arg, const float *__restrict__ z,
+                                                          const float *__restrict__ st, long G, int S, int C,
+                                                          float *__restrict__ dym, double *__restrict__ part) {
+  __shared__ float s_red[2][256];
+  const int tid = threadIdx.x;
+  const int c = tid % C;           // C in {64, 128, 256}: 256 / C groups per pass
+  const int gs = tid / C, GP = 256 / C;
+  const float mean = st[c * 4], istd = st[c * 4 + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (long g = (long)blockIdx.x * GP + gs; g < G; g += (long)gridDim.x * GP) {
+    const size_t o = (size_t)g * C + c;
+    const float dy = out[o] > 0.f ? dout[o] : 0.f;
+    dym[o] = dy;
+    const float zz = z[((size_t)g * S + arg[o]) * C + c];
+    s1 += dy;
+    s2 += dy * ((zz - mean) * istd);
+  }
+  s_red[0][tid] = s1, s_red[1][tid] = s2;
+  __syncthreads();
+  if (tid < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < GP; ++i) a += (double)s_red[0][i * C + tid], b += (double)s_red[1][i * C + tid];
+    part[((size_t)blockIdx.x * 2 + 0) * C + tid] = a;
+    part[((size_t)blockIdx.x * 2 + 1) * C + tid] = b;
+  }
+}
+
+// dz of the current tile element group (4 channels) from the dense or the pooled gradient source
+template <bool POOLED>
+__device__ __forceinline__ f32x4 load_dz(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
+                                         const float *__restrict__ zk, long grow, int CK, int c0, f32x4 g, f32x4 k0,
+                                         f32x4 k1) {
+  const f32x4 z = ld4(zk + (size_t)grow * CK + c0);
+  f32x4 d;
+  if (POOLED) {
+    const long grp = grow / S;
+    const int s = (int)(grow - grp * S);
+    const f32x4 dm = ld4(dy + (size_t)grp * CK + c0);
+    const uchar4 a = *reinterpret_cast<const uchar4 *>(arg + (size_t)grp * CK + c0);
+    d[0] = a.x == s ? dm[0] : 0.f;
+    d[1] = a.y == s ? dm[1] : 0.f;
+    d[2] = a.z == s ? dm[2] : 0.f;
+    d[3] = a.w == s ? dm[3] : 0.f;
+  } else {
+    d = ld4(dy + (size_t)grow * CK + c0);
+  }
+  return g * d + k0 - k1 * z;
+}
+
+// ---- data gradient: dy_prev = (dz_k W_k) * [a_prev > 0], and the BN sums of dy_prev -----------------------------
+template <int CK, int NT, bool POOLED>
+__global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
+                                                       const float *__restrict__ zk, const float *__restrict__ coef,
+                                                       const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
+                                                       const float *__restrict__ st_p, long R, float *__restrict__ dyp,
+                                                       double *__restrict__ part) {
+  constexpr int LD = CK + 4, KS = CK / 4, C4 = CK / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  extern __shared__ __attribute__((aligned(16))) float s_a[];  // [TM][LD]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int cb = blockIdx.y * 64 * NT + w * 16 * NT;
+  float wf[NT][KS];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wf[j][ks] = Wk[(size_t)(ks * 4 + lg) * CP + cb + 16 * j + l15];
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 g, k0, k1;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = coef + (size_t)(c4 * 4 + u) * 4;
+    g[u] = s[0], k0[u] = s[1], k1[u] = s[2];
+  }
+  f32x4 pm[NT], pi[NT], ps[NT], pb[NT], s1[NT], s2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *s = st_p + (size_t)(cb + 16 * j + 4 * lg + u) * 4;
+      pm[j][u] = s[0], pi[j][u] = s[1], ps[j][u] = s[2], pb[j][u] = s[3];
+    }
+    s1[j] = s2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long ntiles = (R + TM - 1) / TM;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * TM;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) a = load_dz<POOLED>(dy, arg, S, zk, row0 + row, CK, c4 * 4, g, k0, k1);
+      st4(&s_a[row * LD + c4 * 4], a);
+    }
+    __syncthreads();
+    f32x4 acc[TM / 16][NT];
+#pragma unroll
+    for (int mt = 0; mt < TM / 16; ++mt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int mt = 0; mt < TM / 16; ++mt) {
+        const float b = s_a[(mt * 16 + l15) * LD + ks * 4 + lg];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < TM / 16; ++mt) {
+      const long grow = row0 + mt * 16 + l15;
+      if (grow < R) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const size_t o = (size_t)grow * CP + cb + 16 * j + 4 * lg;
+          const f32x4 z = ld4(zp + o);
+          f32x4 d;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float pre = (z[u] - pm[j][u]) * ps[j][u] + pb[j][u];
+            d[u] = pre > 0.f ? acc[mt][j][u] : 0.f;
+            s1[j][u] += d[u];
+            s2[j][u] += d[u] * ((z[u] - pm[j][u]) * pi[j][u]);
+          }
+          st4(dyp + o, d);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = s1[j][u], q = s2[j][u];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      if (l15 == 0) {
+        const int c = cb + 16 * j + 4 * lg + u;
+        part[((size_t)blockIdx.x * 2 + 0) * CP + c] = (double)a;
+        part[((size_t)blockIdx.x * 2 + 1) * CP + c] = (double)q;
+      }
+    }
+}
+
+// ---- weight gradient: dW_k[ck, cp] = sum_r dz_k[r, ck] a_prev[r, cp]; one partial per row slab -----------------
+template <int CKB, int CP, bool POOLED>
+__global__ __launch_bounds__(256) void sa_wgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
+                                                       const float *__restrict__ zk, const float *__restrict__ coef, int CK,
+                                                       const float *__restrict__ zp, const float *__restrict__ st_p, long R,
+                                                       float *__restrict__ partW) {
+  constexpr int LDZ = CKB + 16, LDA = CP + 16;
+  constexpr int MT = CKB / 64, NTT = CP / 16;           // m-tiles per wave, n-tiles
+  constexpr int Z4 = CKB / 4, A4 = CP / 4;
+  constexpr int NVZ = TW * Z4 / 256, NVA = TW * A4 / 256, RZ = 256 / Z4, RA = 256 / A4;
+  __shared__ __attribute__((aligned(16))) float s_dz[TW * LDZ];
+  __shared__ __attribute__((aligned(16))) float s_a[TW * LDA];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int ckb0 = blockIdx.y * CKB;
+  const int z4 = tid % Z4, zr0 = tid / Z4, a4 = tid % A4, ar0 = tid / A4;
+  f32x4 g, k0, k1, pm, ps, pb;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = coef + (size_t)(ckb0 + z4 * 4 + u) * 4;
+    g[u] = s[0], k0[u] = s[1], k1[u] = s[2];
+    const float *q = st_p + (size_t)(a4 * 4 + u) * 4;
+    pm[u] = q[0], ps[u] = q[2], pb[u] = q[3];
+  }
+  f32x4 acc[MT][NTT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TW - 1) / TW;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * TW;
+#pragma unroll
+    for (int i = 0; i < NVZ; ++i) {
+      const int row = zr0 + i * RZ;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) a = load_dz<POOLED>(dy, arg, S, zk, row0 + row, CK, ckb0 + z4 * 4, g, k0, k1);
+      st4(&s_dz[row * LDZ + z4 * 4], a);
+    }
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      const int row = ar0 + i * RA;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) {
+        const f32x4 v = ld4(zp + (size_t)(row0 + row) * CP + a4 * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = fmaxf((v[u] - pm[u]) * ps[u] + pb[u], 0.f);
+      }
+      st4(&s_a[row * LDA + a4 * 4], a);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TW / 4; ++ks) {
+      float af[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = s_dz[(ks * 4 + lg) * LDZ + (w * MT + m) * 16 + l15];
+#pragma unroll
+      for (int n = 0; n < NTT; ++n) {
+        const float b = s_a[(ks * 4 + lg) * LDA + n * 16 + l15];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m][n] = MFMA16(af[m], b, acc[m][n]);
+      }
+    }
+    __syncthreads();
+  }
+  float *o = partW + ((size_t)blockIdx.x * CK + ckb0) * CP;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NTT; ++n)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[(size_t)((w * MT + m) * 16 + 4 * lg + u) * CP + n * 16 + l15] = acc[m][n][u];
+}
+
+// ---- layer 1 backward: dz1 (in place over dy1), dW1 partials [NPART][C1][4], optional d rel [R][3] -------------
+template <int C1>
+__global__ __launch_bounds__(256) void sa_l1_bwd_kernel(float *__restrict__ dy1, const float *__restrict__ z1,
+                                                        const float *__restrict__ coef, const float *__restrict__ feat,
+                                                        const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                        const int32_t *__restrict__ idx, const float *__restrict__ W1,
+                                                        int ldw, float rdiv, int Np, int N, int S, long R,
+                                                        float *__restrict__ partW, float *__restrict__ drel) {
+  constexpr int C4 = C1 / 4, RP = 256 / C4;
+  __shared__ float s_red[4][RP][C1];
+  const int tid = threadIdx.x, c4 = tid % C4, rs = tid / C4;
+  f32x4 g, k0, k1, wx, wy, wz;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = coef + (size_t)(c4 * 4 + u) * 4;
+    g[u] = s[0], k0[u] = s[1], k1[u] = s[2];
+    const float *w = W1 + (size_t)(c4 * 4 + u) * ldw;
+    wx[u] = w[0], wy[u] = w[1], wz[u] = w[2];
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ax = zero, ay = zero, az = zero, af = zero;
+  const long NS = (long)N * S;
+  for (long r0 = (long)blockIdx.x * RP; r0 < R; r0 += (long)gridDim.x * RP) {
+    const long r = r0 + rs;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (r < R) {
+      const long b = r / NS, gi = r / S;
+      const int p = idx[r];
+      const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)gi * 3;
+      const float rx = (q[0] - c[0]) / rdiv, ry = (q[1] - c[1]) / rdiv, rz = (q[2] - c[2]) / rdiv;
+      const size_t o = (size_t)r * C1 + c4 * 4;
+      const f32x4 dz = g * ld4(dy1 + o) + k0 - k1 * ld4(z1 + o);
+      st4(dy1 + o, dz);
+      ax += dz * rx, ay += dz * ry, az += dz * rz;
+      if (feat) af += dz * feat[(size_t)b * Np + p];
+      if (drel) {
+        px = dz[0] * wx[0] + dz[1] * wx[1] + dz[2] * wx[2] + dz[3] * wx[3];
+        py = dz[0] * wy[0] + dz[1] * wy[1] + dz[2] * wy[2] + dz[3] * wy[3];
+        pz = dz[0] * wz[0] + dz[1] * wz[1] + dz[2] * wz[2] + dz[3] * wz[3];
+      }
+    }
+    if (drel) {  // sum over the C4 lanes that share the row (C4 = 16 or 32, aligned inside the wave)
+#pragma unroll
+      for (int o = 1; o < C4; o <<= 1) px += __shfl_xor(px, o), py += __shfl_xor(py, o), pz += __shfl_xor(pz, o);
+      if (c4 == 0 && r < R) drel[r * 3] = px / rdiv, drel[r * 3 + 1] = py / rdiv, drel[r * 3 + 2] = pz / rdiv;
+    }
+  }
+  st4(&s_red[0][rs][c4 * 4], ax);
+  st4(&s_red[1][rs][c4 * 4], ay);
+  st4(&s_red[2][rs][c4 * 4], az);
+  st4(&s_red[3][rs][c4 * 4], af);
+  __syncthreads();
+  for (int e = tid; e < 4 * C1; e += 256) {
+    const int c = e / 4, k = e % 4;
+    float a = 0.f;
+    for (int i = 0; i < RP; ++i) a += s_red[k][i][c];
+    partW[((size_t)blockIdx.x * C1 + c) * 4 + k] = a;
+  }
+}
+
+// ---- rows -> source points: dY[b, p, :] = sum over the rows r with idx[r] = p of dz1[r, :] --------------------
+__global__ __launch_bounds__(256) void rows_keys_kernel(const int32_t *__restrict__ idx, int Np, long E, long total,
+                                                        unsigned *__restrict__ keys, int *__restrict__ vals) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  keys[i] = (unsigned)((i / E) * Np + idx[i]);
+  vals[i] = (int)i;
+}
+
+__global__ __launch_bounds__(256) void rows_offsets_kernel(const unsigned *__restrict__ sorted, long total, long K,
+                                                           int *__restrict__ off) {
+  const long k = (long)blockIdx.x * 256 + threadIdx.x;
+  if (k > K) return;
+  long lo = 0, hi = total;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if ((long)sorted[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  off[k] = (int)lo;
+}
+
+__global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float *__restrict__ dz, const int *__restrict__ off,
+                                                              const int *__restrict__ order, long K, int C,
+                                                              float *__restrict__ out) {
+  const int C4 = C / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * C4) return;
+  const long k = i / C4;
+  const int c4 = (int)(i % C4);
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  const int beg = off[k], end = off[k + 1];
+  for (int p = beg; p < end; ++p) a += ld4(dz + (size_t)order[p] * C + c4 * 4);
+  st4(out + (size_t)k * C + c4 * 4, a);
+}
+
+struct RowsLayout {
+  size_t total, K, keys_in, keys_out, vals_in, vals_out, off, cub, cub_bytes, bytes;
+  int bits;
+};
+bool rows_layout(int B, int Np, long E, RowsLayout &L) {
+  if (B <= 0 || Np <= 0 || E <= 0) return false;
+  L.total = (size_t)B * E;
+  L.K = (size_t)B * Np;
+  if (L.K >= (1ull << 31) || L.total >= (1ull << 31)) return false;
+  L.bits = 1;
+  while ((1ull << L.bits) < L.K) ++L.bits;
+  size_t cub = 0;
+  if (hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                         (const int *)nullptr, (int *)nullptr, (int)L.total, 0, L.bits,
+                                         (hipStream_t)0) != hipSuccess)
+    cub = 0;
+  (void)hipGetLastError();
+  if (cub == 0) cub = 16 * L.total + (1 << 20);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  size_t o = 0;
+  L.keys_in = o; o += up(4 * L.total);
+  L.keys_out = o; o += up(4 * L.total);
+  L.vals_in = o; o += up(4 * L.total);
+  L.vals_out = o; o += up(4 * L.total);
+  L.off = o; o += up(4 * (L.K + 1));
+  L.cub = o; L.cub_bytes = cub; o += up(cub);
+  L.bytes = o;
+  return true;
+}
+
+inline unsigned nblocks(long work, int per) {
+  long g = (work + per - 1) / per;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+// ===========================================================================================================
+extern "C" int spacap_sa_nparts(void) { return NPART; }
+extern "C" int spacap_sa_nslabs(void) { return NSLAB; }
+
+extern "C" int spacap_sa_mlp_supported(int C1, int C2, int C3) {
+  const bool sa1 = (C1 == 64 && C2 == 64 && C3 == 128);
+  const bool big = (C1 == 128 && C2 == 128 && (C3 == 128 || C3 == 256));
+  return (sa1 || big) ? 1 : 0;
+}
+
+extern "C" int spacap_sa_l1_fwd_f32(const float *Y, const float *feat, const float *xyz, const float *new_xyz,
+                                    const int32_t *idx, const float *W1, int ldw, float rdiv, int B, int Np, int N,
+                                    int S, int C1, float *z1, double *part, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_fwd_f32";
+  SPACAP_REQUIRE(B >= 1 && Np >= 1 && N >= 1 && S >= 1 && S <= 255, "%s: bad sizes", what);
+  SPACAP_REQUIRE(C1 == 64 || C1 == 128, "%s: C1=%d unsupported", what, C1);
+  SPACAP_REQUIRE(xyz && new_xyz && idx && W1 && z1 && part && ldw >= (feat ? 4 : 3) && rdiv > 0.f, "%s: bad arguments", what);
+  const long R = (long)B * N * S;
+  hipStream_t s = spacap::as_stream(stream);
+  if (C1 == 64)
+    hipLaunchKernelGGL((sa_l1_fwd_kernel<64>), dim3(NPART), dim3(256), 0, s, Y, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, z1, part);
+  else
+    hipLaunchKernelGGL((sa_l1_fwd_kernel<128>), dim3(NPART), dim3(256), 0, s, Y, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, z1, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_bn_finalize_f32(const double *part, int C, long count, float eps, float momentum,
+                                         const float *gamma, const float *beta, float *running_mean,
+                                         float *running_var, float *stats, spacap_stream_t stream) {
+  const char *what = "spacap_sa_bn_finalize_f32";
+  SPACAP_REQUIRE(part && gamma && beta && stats && C >= 1 && count >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, spacap::as_stream(stream), part, NPART, C,
+                     (double)count, eps, momentum, gamma, beta, running_mean, running_var, stats);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_bwd_finalize_f32(const double *part, int C, long count, const float *stats, float *coef,
+                                          float *dgamma, float *dbeta, spacap_stream_t stream) {
+  const char *what = "spacap_sa_bwd_finalize_f32";
+  SPACAP_REQUIRE(part && stats && coef && dgamma && dbeta && C >= 1 && count >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, spacap::as_stream(stream), part, NPART, C,
+                     (double)count, stats, coef, dgamma, dbeta);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const float *W, long R, int Cin, int Cout,
+                                     float *zout, double *part, spacap_stream_t stream) {
+  const char *what = "spacap_sa_mid_fwd_f32";
+  SPACAP_REQUIRE(zin && st_in && W && zout && part && R >= 1, "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t lds = (size_t)TM * (Cin + 4) * sizeof(float);
+  if (Cin == 64 && Cout == 64)
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<64, 1>), dim3(NPART, 1), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
+  else if (Cin == 64 && Cout % 128 == 0)
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<64, 2>), dim3(NPART, Cout / 128), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
+  else if (Cin == 128 && Cout % 128 == 0)
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2>), dim3(NPART, Cout / 128), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
+  else
+    SPACAP_REQUIRE(false, "%s: (Cin=%d, Cout=%d) unsupported", what, Cin, Cout);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out,
+                                      uint8_t *arg, spacap_stream_t stream) {
+  const char *what = "spacap_sa_pool_fwd_f32";
+  SPACAP_REQUIRE(z && stats && out && arg && G >= 1 && S >= 1 && S <= 255 && C % 4 == 0, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_pool_fwd_kernel, dim3(nblocks(G * (C / 4), 256)), dim3(256), 0, spacap::as_stream(stream), z, stats,
+                     G, S, C, out, arg);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z,
+                                      const float *stats, long G, int S, int C, float *dym, double *part,
+                                      spacap_stream_t stream) {
+  const char *what = "spacap_sa_pool_bwd_f32";
+  SPACAP_REQUIRE(dout && out && arg && z && stats && dym && part && G >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(C == 64 || C == 128 || C == 256, "%s: C=%d unsupported", what, C);
+  hipLaunchKernelGGL(sa_pool_bwd_kernel, dim3(NPART), dim3(256), 0, spacap::as_stream(stream), dout, out, arg, z, stats, G,
+                     S, C, dym, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// dy: dense [R, CK] when arg == NULL, else the masked pooled gradient [R / S, CK] with its arg-max map
+extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
+                                   const float *Wk, const float *zp, const float *st_p, long R, int CK, int CP,
+                                   float *dyp, double *part, spacap_stream_t stream) {
+  const char *what = "spacap_sa_dgrad_f32";
+  SPACAP_REQUIRE(dy && zk && coef && Wk && zp && st_p && dyp && part && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t lds = (size_t)TM * (CK + 4) * sizeof(float);
+#define DG(CKV, NTV, PV, GY)                                                                                         \
+  if (lds > 65536)                                                                                                   \
+    SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_dgrad_kernel<CKV, NTV, PV>),             \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what);              \
+  hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV>), dim3(NPART, GY), dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part)
+  if (arg && CK == 128 && CP == 64) { DG(128, 1, true, 1); }
+  else if (arg && CK == 256 && CP == 128) { DG(256, 1, true, 2); }
+  else if (arg && CK == 128 && CP == 128) { DG(128, 2, true, 1); }
+  else if (!arg && CK == 64 && CP == 64) { DG(64, 1, false, 1); }
+  else if (!arg && CK == 128 && CP == 128) { DG(128, 2, false, 1); }
+  else SPACAP_REQUIRE(false, "%s: (CK=%d, CP=%d, pooled=%d) unsupported", what, CK, CP, arg ? 1 : 0);
+#undef DG
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// partW: [spacap_sa_nslabs()][CK][CP] partial weight gradients, summed by the caller in slab order
+extern "C" int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
+                                   const float *zp, const float *st_p, long R, int CK, int CP, float *partW,
+                                   spacap_stream_t stream) {
+  const char *what = "spacap_sa_wgrad_f32";
+  SPACAP_REQUIRE(dy && zk && coef && zp && st_p && partW && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
+  hipStream_t s = spacap::as_stream(stream);
+#define WG(CKB, CPV, PV) \
+  hipLaunchKernelGGL((sa_wgrad_kernel<CKB, CPV, PV>), dim3(NSLAB, CK / CKB), dim3(256), 0, s, dy, arg, S, zk, coef, CK, zp, st_p, R, partW)
+  if (arg && CK % 128 == 0 && CP == 64) WG(128, 64, true);
+  else if (arg && CK % 128 == 0 && CP == 128) WG(128, 128, true);
+  else if (!arg && CK == 64 && CP == 64) WG(64, 64, false);
+  else if (!arg && CK == 128 && CP == 128) WG(128, 128, false);
+  else SPACAP_REQUIRE(false, "%s: (CK=%d, CP=%d, pooled=%d) unsupported", what, CK, CP, arg ? 1 : 0);
+#undef WG
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// dy1 is overwritten with dz1; partW [spacap_sa_nparts()][C1][4] (columns: rel x, y, z, inline feature)
+extern "C" int spacap_sa_l1_bwd_f32(float *dy1, const float *z1, const float *coef, const float *feat, const float *xyz,
+                                    const float *new_xyz, const int32_t *idx, const float *W1, int ldw, float rdiv, int B,
+                                    int Np, int N, int S, int C1, float *partW, float *drel, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_bwd_f32";
+  SPACAP_REQUIRE(dy1 && z1 && coef && xyz && new_xyz && idx && W1 && partW && rdiv > 0.f, "%s: bad arguments", what);
+  SPACAP_REQUIRE(C1 == 64 || C1 == 128, "%s: C1=%d unsupported", what, C1);
+  const long R = (long)B * N * S;
+  hipStream_t s = spacap::as_stream(stream);
+  if (C1 == 64)
+    hipLaunchKernelGGL((sa_l1_bwd_kernel<64>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel);
+  else
+    hipLaunchKernelGGL((sa_l1_bwd_kernel<128>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E) {
+  RowsLayout L;
+  return rows_layout(B, Np, E, L) ? L.bytes : 0;
+}
+
+// out[b, p, :] = sum of dz[r, :] over the rows r = (b, e) with idx[b, e] = p, ascending r (E = rows per scene)
+extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
+                                          void *workspace, spacap_stream_t stream) {
+  const char *what = "spacap_sa_rows_scatter_f32";
+  RowsLayout L;
+  SPACAP_REQUIRE(dz && idx && out && workspace && C % 4 == 0 && rows_layout(B, Np, E, L), "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  char *ws = reinterpret_cast<char *>(workspace);
+  unsigned *keys_in = reinterpret_cast<unsigned *>(ws + L.keys_in), *keys_out = reinterpret_cast<unsigned *>(ws + L.keys_out);
+  int *vals_in = reinterpret_cast<int *>(ws + L.vals_in), *vals_out = reinterpret_cast<int *>(ws + L.vals_out);
+  int *off = reinterpret_cast<int *>(ws + L.off);
+  hipLaunchKernelGGL(rows_keys_kernel, dim3(nblocks((long)L.total, 256)), dim3(256), 0, s, idx, Np, E, (long)L.total, keys_in, vals_in);
+  size_t cub_bytes = L.cub_bytes;
+  SPACAP_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, keys_in, keys_out, vals_in, vals_out,
+                                                      (int)L.total, 0, L.bits, s), what);
+  hipLaunchKernelGGL(rows_offsets_kernel, dim3(nblocks((long)L.K + 1, 256)), dim3(256), 0, s, keys_out, (long)L.total, (long)L.K, off);
+  hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(nblocks((long)L.K * (C / 4), 256)), dim3(256), 0, s, dz, off, vals_out, (long)L.K, C, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

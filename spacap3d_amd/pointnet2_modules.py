@@ -95,7 +95,16 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             assert inds.shape[1] == self.npoint
         new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
-        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features)  # (B, C+3, npoint, nsample)
+        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if self.training:
+            # training step: grouping + SharedMLP + pooling as one point-major op of the backend (sa_mlp.py)
+            from .backend import ops
+            fused = getattr(ops(), "sa_mlp_train", None)
+            out = fused(xyz, new_xyz, features, idx, self.mlp_module, self.radius if self.normalize_xyz else 1.0,
+                        self.use_xyz) if fused is not None else None
+            if out is not None:
+                return new_xyz, out, inds
+        grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=idx)  # (B, C+3, npoint, nsample)
         # SharedMLP + F.max_pool2d(x, [1, nsample]).squeeze(-1)  (pointnet2_modules.py:253-271)
         new_features = self.mlp_module(grouped_features, pool=True)             # (B, mlp[-1], npoint)
         return new_xyz, new_features, inds

@@ -1,0 +1,181 @@
+"""Training-mode shared MLP of a set-abstraction module on libspacap_hip.so, point-major layout.
+
+One autograd op for what the reference runs per SA module as QueryAndGroup -> SharedMLP -> max_pool2d
+(lib/pointnet2/pointnet2_modules.py:241-259; SharedMLP = [Conv2d 1x1 -> BatchNorm2d -> ReLU] x 3,
+lib/pointnet2/pytorch_utils.py:11-36).  See ``csrc/sa_mlp.hip`` for the kernels and the data flow.
+The grouping indices come from ``ball_query`` as before; eval mode and MLP shapes without kernels keep using
+the per-operator path (``QueryAndGroup`` + ``SharedMLP``), which is also HIP.
+"""
+import torch
+from torch.autograd import Function
+
+from ._native import check, lib
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _SAMLP(Function):
+    """inputs: xyz (B,Np,3), new_xyz (B,N,3), idx (B,N,S) int32, feat (B,Np) or None [inline 1-channel feature],
+    Y (B,Np,C1) or None [features already multiplied by W1[:,3:]], W1 (C1, 3 or 4), W2 (C2,C1), W3 (C3,C2),
+    gamma/beta x3, then the three BatchNorm modules (running statistics are updated in place) and rdiv.
+    output: (B,N,C3) pooled features."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, idx, feat, Y, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv):
+        dev = xyz.device
+        B, Np, _ = xyz.shape
+        N, S = idx.shape[1], idx.shape[2]
+        C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+        R, G = B * N * S, B * N
+        st = torch.cuda.current_stream(dev).cuda_stream
+        f32 = dict(dtype=torch.float32, device=dev)
+        xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+        W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
+        feat = feat.contiguous() if feat is not None else None
+        Y = Y.contiguous() if Y is not None else None
+        nparts = int(lib.spacap_sa_nparts())
+        with torch.cuda.device(dev):
+            part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
+            stats = [torch.empty(c, 4, **f32) for c in (C1, C2, C3)]
+            z1 = torch.empty(R, C1, **f32)
+            z2 = torch.empty(R, C2, **f32)
+            z3 = torch.empty(R, C3, **f32)
+
+            def finalize(k, C, gamma, beta):
+                bn = bns[k]
+                mom = 0.0 if bn.momentum is None else float(bn.momentum)
+                track = bn.track_running_stats and bn.running_mean is not None
+                if track and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                check(lib.spacap_sa_bn_finalize_f32(part.data_ptr(), C, R, float(bn.eps), mom, gamma.data_ptr(),
+                                                    beta.data_ptr(), _ptr(bn.running_mean if track else None),
+                                                    _ptr(bn.running_var if track else None), stats[k].data_ptr(), st),
+                      "spacap_sa_bn_finalize_f32")
+
+            check(lib.spacap_sa_l1_fwd_f32(_ptr(Y), _ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+                                           W1c.data_ptr(), W1c.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(),
+                                           part.data_ptr(), st), "spacap_sa_l1_fwd_f32")
+            finalize(0, C1, g1, b1)
+            check(lib.spacap_sa_mid_fwd_f32(z1.data_ptr(), stats[0].data_ptr(), W2c.data_ptr(), R, C1, C2, z2.data_ptr(),
+                                            part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+            finalize(1, C2, g2, b2)
+            check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), R, C2, C3, z3.data_ptr(),
+                                            part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+            finalize(2, C3, g3, b3)
+            out = torch.empty(B, N, C3, **f32)
+            arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
+            check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
+                                             st), "spacap_sa_pool_fwd_f32")
+        ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg)
+        ctx.rdiv = float(rdiv)
+        ctx.has_Y = Y is not None
+        ctx.need_xyz = xyz.requires_grad or new_xyz.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xyz, new_xyz, idx, feat, W1, W2, W3, z1, z2, z3, st1, st2, st3, out, arg = ctx.saved_tensors
+        dev = xyz.device
+        B, Np, _ = xyz.shape
+        N, S = idx.shape[1], idx.shape[2]
+        C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+        R, G = B * N * S, B * N
+        st = torch.cuda.current_stream(dev).cuda_stream
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = dout.contiguous()
+        nparts, nslabs = int(lib.spacap_sa_nparts()), int(lib.spacap_sa_nslabs())
+        with torch.cuda.device(dev):
+            part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
+            coef = [torch.empty(c, 4, **f32) for c in (C1, C2, C3)]
+            dg = [torch.empty(c, **f32) for c in (C1, C2, C3)]
+            db = [torch.empty(c, **f32) for c in (C1, C2, C3)]
+
+            def finalize(k, C, stats):
+                check(lib.spacap_sa_bwd_finalize_f32(part.data_ptr(), C, R, stats.data_ptr(), coef[k].data_ptr(),
+                                                     dg[k].data_ptr(), db[k].data_ptr(), st), "spacap_sa_bwd_finalize_f32")
+
+            # pooled layer: masked gradient + BN sums over the arg-max rows
+            dym = torch.empty(G, C3, **f32)
+            check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), z3.data_ptr(), st3.data_ptr(),
+                                             G, S, C3, dym.data_ptr(), part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
+            finalize(2, C3, st3)
+            # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
+            pw = torch.empty(nslabs, C3, C2, **f32)
+            check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                          z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+            dW3 = pw.sum(0)
+            dy2 = torch.empty(R, C2, **f32)
+            check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                          W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
+                                          part.data_ptr(), st), "spacap_sa_dgrad_f32")
+            finalize(1, C2, st2)
+            # layer 2
+            pw = torch.empty(nslabs, C2, C1, **f32)
+            check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
+                                          st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+            dW2 = pw.sum(0)
+            dy1 = torch.empty(R, C1, **f32)
+            check(lib.spacap_sa_dgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
+                                          z1.data_ptr(), st1.data_ptr(), R, C2, C1, dy1.data_ptr(), part.data_ptr(), st),
+                  "spacap_sa_dgrad_f32")
+            del dy2
+            finalize(0, C1, st1)
+            # layer 1: dz1 in place, dW1 partials, optional gradient of the relative coordinates
+            pw1 = torch.empty(nparts, C1, 4, **f32)
+            drel = torch.empty(R, 3, **f32) if ctx.need_xyz else None
+            check(lib.spacap_sa_l1_bwd_f32(dy1.data_ptr(), z1.data_ptr(), coef[0].data_ptr(), _ptr(feat), xyz.data_ptr(),
+                                           new_xyz.data_ptr(), idx.data_ptr(), W1.data_ptr(), W1.shape[1], ctx.rdiv, B, Np,
+                                           N, S, C1, pw1.data_ptr(), _ptr(drel), st), "spacap_sa_l1_bwd_f32")
+            dW1 = pw1.sum(0)[:, :W1.shape[1]].contiguous()
+            dY = None
+            if ctx.has_Y and ctx.needs_input_grad[4]:
+                ws = torch.empty(int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S)), dtype=torch.uint8, device=dev)
+                dY = torch.empty(B, Np, C1, **f32)
+                check(lib.spacap_sa_rows_scatter_f32(dy1.data_ptr(), idx.data_ptr(), B, Np, N * S, C1, dY.data_ptr(),
+                                                     ws.data_ptr(), st), "spacap_sa_rows_scatter_f32")
+            dxyz = dnew = None
+            if drel is not None:
+                d3 = drel.view(B, N * S, 3)
+                if ctx.needs_input_grad[0]:
+                    dxyz = torch.zeros(B, Np, 3, **f32)
+                    dxyz.scatter_add_(1, idx.view(B, N * S, 1).expand(-1, -1, 3).long(), d3)
+                if ctx.needs_input_grad[1]:
+                    dnew = -drel.view(B, N, S, 3).sum(2)
+        return (dxyz, dnew, None, None, dY, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
+
+
+def supported(mlp_module, nsample):
+    layers = list(mlp_module.children())
+    if len(layers) != 3 or not all(getattr(l, "has_bn", False) for l in layers):
+        return False
+    c = [l.conv.out_channels for l in layers]
+    return bool(lib.spacap_sa_mlp_supported(*c)) and 1 <= nsample <= 255
+
+
+def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
+    """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N).  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
+    updated.  Returns None when this MLP has no fused kernels (the caller then uses the per-operator path)."""
+    if not use_xyz or not xyz.is_cuda or not supported(mlp_module, idx.shape[2]):
+        return None
+    l1, l2, l3 = list(mlp_module.children())
+    W1 = l1.conv.weight.view(l1.conv.out_channels, -1)
+    Cf = W1.shape[1] - 3
+    feat = Y = None
+    if features is not None:
+        assert features.shape[1] == Cf
+        if Cf == 1 and not features.requires_grad:
+            feat, W1a = features.reshape(features.shape[0], -1), W1          # inline: no (B,Np,C1) product needed
+        else:
+            # the first layer commutes with the gather: multiply once per source point
+            Y = torch.matmul(features.transpose(1, 2), W1[:, 3:].t())
+            W1a = W1[:, :3]
+    else:
+        assert Cf == 0
+        W1a = W1
+    bns = [l.bn.bn for l in (l1, l2, l3)]
+    out = _SAMLP.apply(xyz, new_xyz, idx, feat, Y, W1a, l2.conv.weight.view(l2.conv.out_channels, -1),
+                       l3.conv.weight.view(l3.conv.out_channels, -1), bns[0].weight, bns[0].bias, bns[1].weight,
+                       bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv)
+    return out.transpose(1, 2).contiguous()

@@ -63,7 +63,9 @@ class _TallLinear(torch.autograd.Function):
             dw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
         else:
             dw = g2.t() @ x2
-        return dx, dw, g2.sum(0)
+        # column sums of a very tall, narrow matrix: torch's reduction takes 0.66 ms for 524 288 x 9; two stages 17 us
+        db = g2.view(1024, rows // 1024, -1).sum(1).sum(0) if rows % 1024 == 0 and rows >= 65536 else g2.sum(0)
+        return dx, dw, db
 
 
 def tall_linear(x, lin):

@@ -1,0 +1,147 @@
+"""The fused point-major SA shared-MLP (spacap3d_amd/sa_mlp.py, csrc/sa_mlp.hip) against the per-operator path
+(QueryAndGroup -> Conv2d 1x1 -> BN -> ReLU -> max over samples: the reference's own structure,
+lib/pointnet2/pointnet2_modules.py:241-259) evaluated in float64 on the CPU with torch, on identical inputs and
+grouping indices.  Tolerance: fp32 re-association (the GEMMs run on the matrix cores with a different summation
+order; the first layer is evaluated as gather(W f) instead of W gather(f))."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from spacap3d_amd import backend
+from spacap3d_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _reference(sa, xyz, new_xyz, feats, idx, dout, rdiv):
+    """float64 restatement of grouping + SharedMLP (train-mode BN) + max on the CPU; returns out and gradients."""
+    xyz = xyz.double().cpu().requires_grad_(True)
+    new_xyz = new_xyz.double().cpu().requires_grad_(True)
+    feats = feats.double().cpu().requires_grad_(True) if feats is not None else None
+    idx = idx.cpu().long()
+    B, N, Sn = idx.shape
+    bi = torch.arange(B).view(B, 1, 1).expand(-1, N, Sn)
+    gx = (xyz[bi, idx] - new_xyz.unsqueeze(2)) / rdiv                     # (B,N,S,3)
+    x = gx
+    if feats is not None:
+        x = torch.cat([gx, feats.transpose(1, 2)[bi, idx]], dim=-1)       # (B,N,S,3+Cf)
+    params = []
+    for layer in sa.mlp_module.children():
+        W = layer.conv.weight.detach().double().cpu().view(layer.conv.out_channels, -1).requires_grad_(True)
+        g = layer.bn.bn.weight.detach().double().cpu().requires_grad_(True)
+        b = layer.bn.bn.bias.detach().double().cpu().requires_grad_(True)
+        z = x @ W.t()
+        m = z.mean(dim=(0, 1, 2))
+        v = z.var(dim=(0, 1, 2), unbiased=False)
+        x = F.relu((z - m) / torch.sqrt(v + layer.bn.bn.eps) * g + b)
+        params += [W, g, b]
+    out = x.max(dim=2).values.permute(0, 2, 1)                            # (B,C3,N)
+    (out * dout.double().cpu()).sum().backward()
+    return out.detach(), xyz.grad, new_xyz.grad, (feats.grad if feats is not None else None), [p.grad for p in params]
+
+
+CASES = [
+    # name, Np, N, S, Cf, mlp, radius, normalize, xyz_grad
+    ("sa1", 3000, 256, 64, 1, [1, 64, 64, 128], 0.4, True, False),
+    ("sa2", 1024, 256, 32, 128, [128, 128, 128, 256], 0.8, True, False),
+    ("sa3", 512, 128, 16, 256, [256, 128, 128, 256], 1.2, True, False),
+    ("vote_agg", 512, 64, 16, 128, [128, 128, 128, 128], 0.6, True, True),
+    ("sa1_unnormalised_ragged", 1500, 101, 48, 1, [1, 64, 64, 128], 0.5, False, False),
+]
+
+
+@pytest.mark.parametrize("name,Np,N,Sn,Cf,mlp,radius,normalize,xyz_grad", CASES)
+def test_fused_sa_mlp_matches_float64_reference(name, Np, N, Sn, Cf, mlp, radius, normalize, xyz_grad):
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    from spacap3d_amd import pointnet2_utils as PU
+    torch.manual_seed(sum(map(ord, name)))
+    B = 2
+    sa = PointnetSAModuleVotes(npoint=N, radius=radius, nsample=Sn, mlp=list(mlp), use_xyz=True,
+                               normalize_xyz=normalize).to(DEV).train()
+    for layer in sa.mlp_module.children():   # non-trivial affine parameters, some negative gammas
+        layer.bn.bn.weight.data.uniform_(-1.0, 1.5)
+        layer.bn.bn.bias.data.uniform_(-0.3, 0.3)
+    xyz = S.scene_batch(B, Np, use_height=False, seed=7).to(DEV)
+    feats = torch.randn(B, Cf, Np, device=DEV)
+    if Cf > 1:
+        feats = F.relu(feats)
+    xyz_in = xyz.clone().requires_grad_(xyz_grad)
+    feats_in = feats.clone().requires_grad_(Cf > 1)
+    rm0 = [l.bn.bn.running_mean.clone() for l in sa.mlp_module.children()]
+    new_xyz, out, inds = sa(xyz_in, feats_in)
+    assert out.shape == (B, mlp[-1], N) and out.is_contiguous()
+    dout = torch.randn_like(out)
+    (out * dout).sum().backward()
+    idx = PU.ball_query(radius, Sn, xyz, new_xyz.detach())
+    rdiv = radius if normalize else 1.0
+    # reference: new_xyz is a gather of xyz; its gradient flows back into xyz (only checked when xyz needs grad)
+    want, dxyz, dnew, dfeat, dparams = _reference(sa, xyz, new_xyz.detach(), feats, idx, dout, rdiv)
+
+    def close(a, b, what, rtol=2e-4):
+        a, b = a.detach().double().cpu().numpy(), b.numpy()
+        scale = np.abs(b).max() + 1e-12
+        err = np.abs(a - b).max() / scale
+        assert err < rtol, f"{name}/{what}: max err {err:.3e} of scale {scale:.3e}"
+
+    close(out, want, "out")
+    got = []
+    for layer in sa.mlp_module.children():
+        got += [layer.conv.weight.grad.view(layer.conv.out_channels, -1), layer.bn.bn.weight.grad, layer.bn.bn.bias.grad]
+    for i, (g, w) in enumerate(zip(got, dparams)):
+        close(g, w, f"param{i}", rtol=1e-3)
+    if Cf > 1:
+        close(feats_in.grad, dfeat, "dfeat", rtol=1e-3)
+    if xyz_grad:
+        # d/dxyz = direct term + the term through new_xyz = xyz[inds]
+        full = dxyz.clone()
+        full.scatter_add_(1, inds.cpu().long().unsqueeze(-1).expand(-1, -1, 3), dnew)
+        close(xyz_in.grad, full, "dxyz", rtol=1e-3)
+    # running statistics moved (momentum update happened once per layer)
+    for l, r0 in zip(sa.mlp_module.children(), rm0):
+        assert not torch.equal(l.bn.bn.running_mean, r0)
+        assert int(l.bn.bn.num_batches_tracked) == 1
+
+
+def test_fused_and_per_operator_paths_agree_including_running_stats():
+    """Same module, same inputs, fused op switched off for the second run."""
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(3)
+    sa = PointnetSAModuleVotes(npoint=128, radius=0.8, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    xyz = S.scene_batch(2, 1024, use_height=False, seed=1).to(DEV)
+    feats = F.relu(torch.randn(2, 128, 1024, device=DEV))
+    fa = feats.clone().requires_grad_(True)
+    fb = feats.clone().requires_grad_(True)
+    _, oa, _ = sa(xyz, fa)
+    hip = backend.ops()
+    saved = hip.sa_mlp_train
+    try:
+        hip.sa_mlp_train = None
+        _, ob, _ = sb(xyz, fb)
+    finally:
+        hip.sa_mlp_train = saved
+    w = torch.randn_like(oa)
+    (oa * w).sum().backward()
+    (ob * w).sum().backward()
+    assert torch.allclose(oa, ob, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(fa.grad, fb.grad, rtol=1e-3, atol=1e-4 * float(fb.grad.abs().max()))
+    for la, lb in zip(sa.mlp_module.children(), sb.mlp_module.children()):
+        assert torch.allclose(la.bn.bn.running_mean, lb.bn.bn.running_mean, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(la.bn.bn.running_var, lb.bn.bn.running_var, rtol=1e-4, atol=1e-6)
+        ga, gb = la.conv.weight.grad, lb.conv.weight.grad
+        assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-4 * float(gb.abs().max()))
+
+
+def test_unsupported_mlp_uses_the_per_operator_path():
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    from spacap3d_amd import sa_mlp
+    sa = PointnetSAModuleVotes(npoint=32, radius=0.4, nsample=16, mlp=[6, 16, 32], use_xyz=True).to(DEV).train()
+    assert not sa_mlp.supported(sa.mlp_module, 16)
+    xyz = S.scene_batch(1, 256, use_height=False, seed=1).to(DEV)
+    _, out, _ = sa(xyz, torch.randn(1, 6, 256, device=DEV))
+    assert out.shape == (1, 32, 32)
