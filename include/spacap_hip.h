@@ -236,7 +236,7 @@ int spacap_layernorm_bwd_f32(const float *x, const float *a, const float *stats,
  * stats f32 [C,4] = (mean, 1/sqrt(var+eps), gamma/sqrt(var+eps), beta); coef f32 [C,4] = (g, k0, k1, -) with
  * dz = g*dy + k0 - k1*z.  part: f64 [spacap_sa_nparts(), 2, C] partial sums (workspace, fully overwritten). */
 int spacap_sa_nparts(void);
-int spacap_sa_nslabs(void);
+int spacap_sa_wgrad_slabs(long R, int CK, int CP, int pooled);
 /* 1 when (C1, C2, C3) has kernels: (64,64,128), (128,128,128), (128,128,256). */
 int spacap_sa_mlp_supported(int C1, int C2, int C3);
 /* z1[r,:] = Y[b,idx[r],:] + W1[:,0:3] (xyz[b,idx[r]] - new_xyz[b,n]) / rdiv + W1[:,3] feat[b,idx[r]].
@@ -267,7 +267,7 @@ int spacap_sa_bwd_finalize_f32(const double *part, int C, long count, const floa
 int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *Wk, const float *zp, const float *st_p, long R, int CK, int CP, float *dyp,
                         double *part, spacap_stream_t stream);
-/* partW f32 [spacap_sa_nslabs(), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
+/* partW f32 [spacap_sa_wgrad_slabs(R,CK,CP,arg != NULL), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
 int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *zp, const float *st_p, long R, int CK, int CP, float *partW,
                         spacap_stream_t stream);

@@ -55,7 +55,7 @@ SIGNATURES = {
     "spacap_relation_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_nparts": (_i, []),
-    "spacap_sa_nslabs": (_i, []),
+    "spacap_sa_wgrad_slabs": (_i, [_l, _i, _i, _i]),
     "spacap_sa_mlp_supported": (_i, [_i, _i, _i]),
     "spacap_sa_l1_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p]),
     "spacap_sa_bn_finalize_f32": (_i, [_p, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),

@@ -24,6 +24,8 @@
 // All reductions (statistics, weight gradients) are two-stage with a fixed order: no float atomics.
 #include <hipcub/hipcub.hpp>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -34,7 +36,6 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 constexpr int TM = 64;      // rows per tile of the forward / data-gradient GEMMs
 constexpr int TW = 32;      // rows per tile of the weight-gradient GEMM
 constexpr int NPART = 1024; // partial-sum rows (= persistent workgroups) of every statistics reduction
-constexpr int NSLAB = 256;  // row slabs of the weight-gradient GEMM
 
 // stats row of a layer: {mean, 1/sqrt(var+eps), gamma/sqrt(var+eps), beta}
 // coef  row of a layer (backward): {g, k0, k1, -}:  dz = g*dy + k0 - k1*z
@@ -88,23 +89,25 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
 
 // ---- statistics finalisation --------------------------------------------------------------------------------
 // part [NPART][2][C] (sum, sum of squares) -> stats [C][4]; optional running-statistics update (torch semantics)
-__global__ __launch_bounds__(256) void sa_bn_finalize_kernel(const double *__restrict__ part, int nparts, int C,
+__global__ __launch_bounds__(1024) void sa_bn_finalize_kernel(const double *__restrict__ part, int nparts, int C,
                                                              double M, float eps, float momentum,
                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float *__restrict__ running_mean,
                                                              float *__restrict__ running_var, float *__restrict__ stats) {
-  // workgroup = 8 channels x {sum, sq} x 16 slabs of partial rows
-  __shared__ double s[16][16];
+  // workgroup = 8 channels x {sum, sq} x 64 slabs of partial rows
+  __shared__ double s[64][16];
   const int tid = threadIdx.x, col = tid & 15, slab = tid >> 4;
   const int k = col >> 3, c = blockIdx.x * 8 + (col & 7);
   double a = 0.0;
-  if (c < C)
-    for (int p = slab; p < nparts; p += 16) a += part[((size_t)p * 2 + k) * C + c];
+  if (c < C) {
+#pragma unroll 16
+    for (int p = slab; p < nparts; p += 64) a += part[((size_t)p * 2 + k) * C + c];
+  }
   s[slab][col] = a;
   __syncthreads();
   if (tid < 8 && c < C) {
     double sm = 0.0, q = 0.0;
-    for (int i = 0; i < 16; ++i) sm += s[i][tid], q += s[i][tid + 8];
+    for (int i = 0; i < 64; ++i) sm += s[i][tid], q += s[i][tid + 8];
     const double mean = sm / M;
     double var = q / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -122,21 +125,23 @@ __global__ __launch_bounds__(256) void sa_bn_finalize_kernel(const double *__res
 }
 
 // part [NPART][2][C] (sum dy, sum dy*xhat) -> coef [C][4], dgamma, dbeta
-__global__ __launch_bounds__(256) void sa_bwd_finalize_kernel(const double *__restrict__ part, int nparts, int C,
+__global__ __launch_bounds__(1024) void sa_bwd_finalize_kernel(const double *__restrict__ part, int nparts, int C,
                                                               double M, const float *__restrict__ stats,
                                                               float *__restrict__ coef, float *__restrict__ dgamma,
                                                               float *__restrict__ dbeta) {
-  __shared__ double s[16][16];
+  __shared__ double s[64][16];
   const int tid = threadIdx.x, col = tid & 15, slab = tid >> 4;
   const int k = col >> 3, c = blockIdx.x * 8 + (col & 7);
   double a = 0.0;
-  if (c < C)
-    for (int p = slab; p < nparts; p += 16) a += part[((size_t)p * 2 + k) * C + c];
+  if (c < C) {
+#pragma unroll 16
+    for (int p = slab; p < nparts; p += 64) a += part[((size_t)p * 2 + k) * C + c];
+  }
   s[slab][col] = a;
   __syncthreads();
   if (tid < 8 && c < C) {
     double s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < 16; ++i) s1 += s[i][tid], s2 += s[i][tid + 8];
+    for (int i = 0; i < 64; ++i) s1 += s[i][tid], s2 += s[i][tid + 8];
     const float mean = stats[c * 4], istd = stats[c * 4 + 1], g = stats[c * 4 + 2];
     const float a1 = (float)(s1 / M), b1 = (float)(s2 / M);
     const float k1 = g * b1 * istd;
@@ -150,20 +155,26 @@ __global__ __launch_bounds__(256) void sa_bwd_finalize_kernel(const double *__re
 }
 
 // ---- middle layers forward: zout = relu(bn(zin)) W^T, statistics of zout -------------------------------------
+// Per 64-row tile: [prefetched registers -> BN+ReLU -> LDS] | sync | issue the next tile's loads | MFMA |
+// accumulators -> LDS (transposed staging) | sync | full-row 16-byte stores.  The loads of tile t+1 and the stores
+// of tile t are in flight while the matrix cores work on tile t.
 template <int CIN, int NT>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
                                                          float *__restrict__ zout, double *__restrict__ part) {
   constexpr int LD = CIN + 4, KS = CIN / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
-  extern __shared__ __attribute__((aligned(16))) float s_a[];  // [TM][LD]
+  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_a = smem;             // [TM][LD]   activations (MFMA B operand)
+  float *s_o = smem + TM * LD;   // [TM][LDO]  output tile, row-major
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int cb = blockIdx.y * 64 * NT + w * 16 * NT;
+  const int cbb = blockIdx.y * COB, wc = w * 16 * NT, cb = cbb + wc;
   float wf[NT][KS];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wf[j][ks] = W[(size_t)(cb + 16 * j + l15) * CIN + ks * 4 + lg];
-  const int c4 = tid % C4, r0 = tid / C4;
+  const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
   f32x4 mean, sc, be;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -174,20 +185,42 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
   for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long ntiles = (R + TM - 1) / TM;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  f32x4 pre[NV];
+  // Prefetch with hand-issued loads: the compiler's wait-count insertion would drain the previous tile's stores
+  // too (vmcnt is one in-order counter for loads and stores on gfx9); here the wait before staging is
+  // vmcnt(#stores of one tile), which leaves those stores in flight.  Row index clamped: rows past the end are
+  // zeroed when staged.
+  auto fetch = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
+    }
+  };
+  auto wait_prefetch = [&](bool stores_pending) {
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));  // uses of pre[] stay below the wait
+  };
+  // one tile; FULL = all TM rows exist (no bounds checks: the stores are then straight-line code too)
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
     const long row0 = t * TM;
+    wait_prefetch(stores_pending);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int row = r0 + i * RSTEP;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < R) {
-        const f32x4 v = ld4(zin + (size_t)(row0 + row) * CIN + c4 * 4);
+      f32x4 a;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = fmaxf((v[u] - mean[u]) * sc[u] + be[u], 0.f);
-      }
+      for (int u = 0; u < 4; ++u) a[u] = fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+      if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
       st4(&s_a[row * LD + c4 * 4], a);
     }
     __syncthreads();
+    if (FULL) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
     f32x4 acc[TM / 16][NT];
 #pragma unroll
     for (int mt = 0; mt < TM / 16; ++mt)
@@ -202,19 +235,37 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
         for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
       }
     }
-    __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < TM / 16; ++mt) {
-      const long grow = row0 + mt * 16 + l15;
-      if (grow < R) {
+    for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          st4(zout + (size_t)grow * Cout + cb + 16 * j + 4 * lg, acc[mt][j]);
+      for (int j = 0; j < NT; ++j) {
+        st4(&s_o[(mt * 16 + l15) * LDO + wc + 16 * j + 4 * lg], acc[mt][j]);
+        if (FULL || row0 + mt * 16 + l15 < R) {
           ssum[j] += acc[mt][j];
           ssq[j] += acc[mt][j] * acc[mt][j];
         }
       }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int row = or0 + i * OSTEP;
+      if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
     }
+  };
+  const long nfull = R / TM;
+  bool pending = false;
+  if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  // the last prefetch is unused, but its destination registers must stay reserved until it has landed
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(pre[i]));
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    fetch(nfull);
+    tile(nfull, std::false_type{}, false);
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -227,6 +278,8 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
         const int c = cb + 16 * j + 4 * lg + u;
         part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)a;
         part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)q;
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
       }
     }
 }
@@ -405,6 +458,8 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
         const int c = cb + 16 * j + 4 * lg + u;
         part[((size_t)blockIdx.x * 2 + 0) * CP + c] = (double)a;
         part[((size_t)blockIdx.x * 2 + 1) * CP + c] = (double)q;
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * CP + c] = 0.0, part[((size_t)pr * 2 + 1) * CP + c] = 0.0;
       }
     }
 }
@@ -607,6 +662,24 @@ bool rows_layout(int B, int Np, long E, RowsLayout &L) {
   return true;
 }
 
+// Workgroups (256 threads) of `kernel` that are resident on the whole device at once.  The GEMM kernels are
+// persistent: a grid larger than this would run its surplus as a second, nearly empty round.
+template <typename K>
+int resident_blocks(K kernel, size_t lds) {
+  int per = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, lds) != hipSuccess || per < 1) per = 1;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+    cus = 256;
+  (void)hipGetLastError();
+  return per * cus;
+}
+inline int grid_rows(int resident, int gy, long tiles) {
+  long g = resident / gy;
+  if (g > NPART) g = NPART;
+  if (g > tiles) g = tiles;
+  return (int)(g < 1 ? 1 : g);
+}
+
 inline unsigned nblocks(long work, int per) {
   long g = (work + per - 1) / per;
   return (unsigned)(g < 1 ? 1 : g);
@@ -616,7 +689,30 @@ inline unsigned nblocks(long work, int per) {
 
 // ===========================================================================================================
 extern "C" int spacap_sa_nparts(void) { return NPART; }
-extern "C" int spacap_sa_nslabs(void) { return NSLAB; }
+// row slabs (= partial results = workgroups per output tile) of the weight-gradient GEMM: what is resident at
+// once, at most 64 MB of partials
+namespace {
+int wgrad_resident(int CK, int CP, bool pooled) {
+#define WR(CKB, CPV, PV)                                                        \
+  {                                                                             \
+    static const int res = resident_blocks(sa_wgrad_kernel<CKB, CPV, PV>, 0);   \
+    return res;                                                                 \
+  }
+  if (pooled && CK % 128 == 0 && CP == 64) WR(128, 64, true)
+  if (pooled && CK % 128 == 0 && CP == 128) WR(128, 128, true)
+  if (!pooled && CK == 64 && CP == 64) WR(64, 64, false)
+  if (!pooled && CK == 128 && CP == 128) WR(128, 128, false)
+#undef WR
+  return 512;
+}
+}  // namespace
+extern "C" int spacap_sa_wgrad_slabs(long R, int CK, int CP, int pooled) {
+  const int gy = CK >= 128 ? CK / 128 : 1;
+  long n = wgrad_resident(CK, CP, pooled != 0) / gy, cap = (16L << 20) / ((long)CK * CP), tiles = (R + TW - 1) / TW;
+  if (n > cap) n = cap;
+  if (n > tiles) n = tiles;
+  return (int)(n < 1 ? 1 : n);
+}
 
 extern "C" int spacap_sa_mlp_supported(int C1, int C2, int C3) {
   const bool sa1 = (C1 == 64 && C2 == 64 && C3 == 128);
@@ -646,7 +742,7 @@ extern "C" int spacap_sa_bn_finalize_f32(const double *part, int C, long count, 
                                          float *running_var, float *stats, spacap_stream_t stream) {
   const char *what = "spacap_sa_bn_finalize_f32";
   SPACAP_REQUIRE(part && gamma && beta && stats && C >= 1 && count >= 1, "%s: bad arguments", what);
-  hipLaunchKernelGGL(sa_bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, spacap::as_stream(stream), part, NPART, C,
+  hipLaunchKernelGGL(sa_bn_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, spacap::as_stream(stream), part, NPART, C,
                      (double)count, eps, momentum, gamma, beta, running_mean, running_var, stats);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -656,7 +752,7 @@ extern "C" int spacap_sa_bwd_finalize_f32(const double *part, int C, long count,
                                           float *dgamma, float *dbeta, spacap_stream_t stream) {
   const char *what = "spacap_sa_bwd_finalize_f32";
   SPACAP_REQUIRE(part && stats && coef && dgamma && dbeta && C >= 1 && count >= 1, "%s: bad arguments", what);
-  hipLaunchKernelGGL(sa_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, spacap::as_stream(stream), part, NPART, C,
+  hipLaunchKernelGGL(sa_bwd_finalize_kernel, dim3((C + 7) / 8), dim3(1024), 0, spacap::as_stream(stream), part, NPART, C,
                      (double)count, stats, coef, dgamma, dbeta);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -667,15 +763,21 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   const char *what = "spacap_sa_mid_fwd_f32";
   SPACAP_REQUIRE(zin && st_in && W && zout && part && R >= 1, "%s: bad arguments", what);
   hipStream_t s = spacap::as_stream(stream);
-  const size_t lds = (size_t)TM * (Cin + 4) * sizeof(float);
-  if (Cin == 64 && Cout == 64)
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<64, 1>), dim3(NPART, 1), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
-  else if (Cin == 64 && Cout % 128 == 0)
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<64, 2>), dim3(NPART, Cout / 128), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
-  else if (Cin == 128 && Cout % 128 == 0)
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2>), dim3(NPART, Cout / 128), dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part);
+  const int nt = (Cin == 64 && Cout == 64) ? 1 : 2;
+  const size_t lds = (size_t)TM * ((Cin + 4) + (64 * nt + 4)) * sizeof(float);
+  const long tiles = (R + TM - 1) / TM;
+#define MF(CI, NTV, GY)                                                                                              \
+  {                                                                                                                  \
+    static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV>, lds);                                         \
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256), lds, s, zin,    \
+                       st_in, W, Cout, R, zout, part);                                                               \
+  }
+  if (Cin == 64 && Cout == 64) MF(64, 1, 1)
+  else if (Cin == 64 && Cout % 128 == 0) MF(64, 2, Cout / 128)
+  else if (Cin == 128 && Cout % 128 == 0) MF(128, 2, Cout / 128)
   else
     SPACAP_REQUIRE(false, "%s: (Cin=%d, Cout=%d) unsupported", what, Cin, Cout);
+#undef MF
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -715,7 +817,8 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   if (lds > 65536)                                                                                                   \
     SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_dgrad_kernel<CKV, NTV, PV>),             \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what);              \
-  hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV>), dim3(NPART, GY), dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part)
+  static const int res = resident_blocks(sa_dgrad_kernel<CKV, NTV, PV>, lds);                                         \
+  hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV>), dim3(grid_rows(res, GY, (R + TM - 1) / TM), GY), dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part)
   if (arg && CK == 128 && CP == 64) { DG(128, 1, true, 1); }
   else if (arg && CK == 256 && CP == 128) { DG(256, 1, true, 2); }
   else if (arg && CK == 128 && CP == 128) { DG(128, 2, true, 1); }
@@ -727,7 +830,7 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   return SPACAP_OK;
 }
 
-// partW: [spacap_sa_nslabs()][CK][CP] partial weight gradients, summed by the caller in slab order
+// partW: [spacap_sa_wgrad_slabs(R,CK,CP,pooled)][CK][CP] partial weight gradients, summed by the caller in slab order
 extern "C" int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                                    const float *zp, const float *st_p, long R, int CK, int CP, float *partW,
                                    spacap_stream_t stream) {
@@ -735,8 +838,9 @@ extern "C" int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, c
   SPACAP_REQUIRE(dy && zk && coef && zp && st_p && partW && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
   hipStream_t s = spacap::as_stream(stream);
+  const int nslab = spacap_sa_wgrad_slabs(R, CK, CP, arg ? 1 : 0);
 #define WG(CKB, CPV, PV) \
-  hipLaunchKernelGGL((sa_wgrad_kernel<CKB, CPV, PV>), dim3(NSLAB, CK / CKB), dim3(256), 0, s, dy, arg, S, zk, coef, CK, zp, st_p, R, partW)
+  hipLaunchKernelGGL((sa_wgrad_kernel<CKB, CPV, PV>), dim3(nslab, CK / CKB), dim3(256), 0, s, dy, arg, S, zk, coef, CK, zp, st_p, R, partW)
   if (arg && CK % 128 == 0 && CP == 64) WG(128, 64, true);
   else if (arg && CK % 128 == 0 && CP == 128) WG(128, 128, true);
   else if (!arg && CK == 64 && CP == 64) WG(64, 64, false);

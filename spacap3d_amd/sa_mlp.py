@@ -85,7 +85,7 @@ class _SAMLP(Function):
         st = torch.cuda.current_stream(dev).cuda_stream
         f32 = dict(dtype=torch.float32, device=dev)
         dout = dout.contiguous()
-        nparts, nslabs = int(lib.spacap_sa_nparts()), int(lib.spacap_sa_nslabs())
+        nparts = int(lib.spacap_sa_nparts())
         with torch.cuda.device(dev):
             part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
             coef = [torch.empty(c, 4, **f32) for c in (C1, C2, C3)]
@@ -102,7 +102,7 @@ class _SAMLP(Function):
                                              G, S, C3, dym.data_ptr(), part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
             finalize(2, C3, st3)
             # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
-            pw = torch.empty(nslabs, C3, C2, **f32)
+            pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
             check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
                                           z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
             dW3 = pw.sum(0)
@@ -112,7 +112,7 @@ class _SAMLP(Function):
                                           part.data_ptr(), st), "spacap_sa_dgrad_f32")
             finalize(1, C2, st2)
             # layer 2
-            pw = torch.empty(nslabs, C2, C1, **f32)
+            pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)
             check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
                                           st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
             dW2 = pw.sum(0)
