@@ -148,7 +148,7 @@ def test_rejects_bad_arguments(att):
         att.attention(q[..., :8].contiguous().to(DEV), k[..., :8].contiguous().to(DEV), v[..., :8].contiguous().to(DEV))
 
 
-@pytest.mark.parametrize("shape", [(8, 256, 128), (8, 32, 128), (3, 7, 512), (1, 1, 128), (5, 130)])
+@pytest.mark.parametrize("shape", [(8, 256, 128), (8, 32, 128), (3, 7, 512), (1, 1, 128), (5, 130), (4, 101, 300), (3, 9, 1000), (2, 64)])
 def test_fused_layernorm_matches_reference_formula(att, shape):
     """models/transformer_captioner.py:102-113: unbiased std, eps added to std."""
     g = torch.Generator().manual_seed(len(shape))

@@ -82,6 +82,7 @@ def report():
     first = begins[-3]
     tot = collections.Counter()
     kern = collections.defaultdict(collections.Counter)
+    kcnt = collections.defaultdict(collections.Counter)
     cnt = collections.Counter()
     mi, phase = -1, None
     big = []
@@ -95,6 +96,7 @@ def report():
         tot[phase] += e - s
         cnt[phase] += 1
         kern[phase][n] += e - s
+        kcnt[phase][n] += 1
         if mi >= begins[-1] and e - s >= 30_000:
             big.append((phase, (e - s) / 1e3, n[:160]))
     K = 3
@@ -102,7 +104,7 @@ def report():
     for ph, v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print(f"{v / 1e6 / K:8.3f} ms  {cnt[ph] / K:6.0f} kernels  {ph}")
         for n, kv in kern[ph].most_common(top):
-            print(f"            {kv / 1e6 / K:7.3f}  {n[:110]}")
+            print(f"            {kv / 1e6 / K:7.3f} {kcnt[ph][n] / K:5.0f}x  {n[:110]}")
     print("\nkernels >= 30 us of the last step, in launch order")
     for ph, us, n in big:
         print(f"{us:8.1f} us  {ph:22s} {n}")
