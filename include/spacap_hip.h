@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPACAP_ABI_VERSION 1
+#define SPACAP_ABI_VERSION 2
 
 #define SPACAP_OK 0
 #define SPACAP_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -156,8 +156,10 @@ int spacap_mha_fwd_f32(const float *q, const float *k, const float *v, long q_sb
  * dense; d_p f32 [B,h,Lq,Lk] dense or NULL is the gradient w.r.t. the returned post-dropout p_attn
  * (non-NULL for the encoder layer that feeds the relation head,
  * models/transformer_captioner.py:392-394).  `workspace`: spacap_mha_bwd_workspace_bytes(B,h,Lq)
- * bytes of scratch.  Outputs dq f32 [B,Lq,h,d_k], dk,dv f32 [B,Lk,h,d_k] dense (the layout of the
- * projections before `.transpose(1,2)`); every element is written. */
+ * bytes of scratch.  Outputs dq f32 [B,Lq,h,d_k], dk,dv f32 [B,Lk,h,d_k] (the layout of the projections
+ * before `.transpose(1,2)`); every element is written.  grad_row_stride: floats between consecutive rows
+ * (b, position) of dq / dk / dv; 0 = dense (h*d_k).  A packed q|k|v projection (one GEMM) passes 3*h*d_k and
+ * three pointers into one [B,L,3*h*d_k] buffer. */
 size_t spacap_mha_bwd_workspace_bytes(int B, int h, int Lq);
 int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
@@ -165,7 +167,7 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
                        int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
                        const float *stats, const float *d_out, const float *d_p, void *workspace,
-                       float *dq, float *dk, float *dv, spacap_stream_t stream);
+                       float *dq, float *dk, float *dv, long grad_row_stride, spacap_stream_t stream);
 
 /* ---- train-mode BatchNorm + ReLU (+ max over the samples) of the shared MLPs ---------------------
  * (replaces BatchNorm2d -> ReLU [-> F.max_pool2d] of lib/pointnet2/pytorch_utils.py:11-36 and

@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspacap_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i = ctypes.c_int
 _l = ctypes.c_long
@@ -75,7 +75,7 @@ SIGNATURES = {
                            + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p]),
     "spacap_mha_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "spacap_mha_bwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
-                           + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+                           + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
 }
 
 

@@ -28,6 +28,20 @@ def _prep_mask(mask, B, Lq, Lk):
     """reference masks: (B,1,1,Lk) int64 key mask or (B,1,Lq,Lk) bool -> uint8 (B,Lq|1,Lk)."""
     if mask is None:
         return None, 0, 0
+    # the same mask object goes through every layer of a stack: convert it once (2 launches saved per layer)
+    for ent in _MASK_CACHE:
+        if ent[0] is mask and ent[1] == (mask._version, B, Lq, Lk):
+            return ent[2]
+    res = _prep_mask_uncached(mask, B, Lq, Lk)
+    _MASK_CACHE.insert(0, (mask, (mask._version, B, Lq, Lk), res))
+    del _MASK_CACHE[4:]
+    return res
+
+
+_MASK_CACHE = []
+
+
+def _prep_mask_uncached(mask, B, Lq, Lk):
     m = mask
     if m.dim() == 4:
         assert m.size(1) == 1, "per-head masks are not used by the reference"
@@ -125,10 +139,83 @@ class FusedAttention(Function):
                 B, h, Lq, Lk, dk, scale, float(dropout_p), int(seed),
                 rng_state(q.device).data_ptr() if dropout_p > 0.0 else None, lse.data_ptr(),
                 d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None, ws.data_ptr(),
-                dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(),
+                dq.data_ptr(), dk_.data_ptr(), dv.data_ptr(), 0,
                 torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_bwd_f32")
         return (dq.transpose(1, 2), dk_.transpose(1, 2), dv.transpose(1, 2), None, None, None, None, None, None,
                 None)
+
+
+class FusedSelfAttentionPacked(Function):
+    """Self-attention on a packed projection qkv (B, L, 3*h*d_k) = [q | k | v] (one GEMM instead of three): the
+    kernels read q, k, v through strides and the backward writes dq, dk, dv straight into one (B, L, 3*h*d_k)
+    buffer, so the projection's backward is one dX GEMM, one dW GEMM and one bias sum instead of three each plus
+    two accumulations.  Returns (out (B,L,h*d_k), p_attn (B,h,L,L) or the row statistics)."""
+
+    @staticmethod
+    def forward(ctx, qkv, h, mask_u8, mask_sb, mask_sq, dropout_p, seed, need_p):
+        if not qkv.is_cuda:
+            raise RuntimeError("CPU not supported")
+        qkv = qkv.contiguous()
+        B, L, three_hd = qkv.shape
+        hd = three_hd // 3
+        dk = hd // h
+        scale = 1.0 / math.sqrt(dk)
+        es = qkv.element_size()
+        strides = (L * three_hd, dk, three_hd)
+        with torch.cuda.device(qkv.device):
+            out = torch.empty(B, L, hd, dtype=torch.float32, device=qkv.device)
+            p = torch.empty(B, h, L, L, dtype=torch.float32, device=qkv.device) if need_p else None
+            lse = torch.empty(B, h, L, 2, dtype=torch.float32, device=qkv.device)
+            base = qkv.data_ptr()
+            check(lib.spacap_mha_fwd_f32(
+                base, base + hd * es, base + 2 * hd * es, *strides, *strides, *strides,
+                mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq, None, 0, 0, 0,
+                B, h, L, L, dk, scale, float(dropout_p), int(seed),
+                rng_state(qkv.device).data_ptr() if dropout_p > 0.0 else None,
+                out.data_ptr(), p.data_ptr() if need_p else None, lse.data_ptr(),
+                torch.cuda.current_stream(qkv.device).cuda_stream), "spacap_mha_fwd_f32")
+        ctx.save_for_backward(qkv, mask_u8, lse)
+        ctx.meta = (h, mask_sb, mask_sq, dropout_p, seed, scale, need_p)
+        if need_p:
+            return out, p
+        ctx.mark_non_differentiable(lse)
+        return out, lse
+
+    @staticmethod
+    def backward(ctx, d_out, d_p):
+        qkv, mask_u8, lse = ctx.saved_tensors
+        h, mask_sb, mask_sq, dropout_p, seed, scale, need_p = ctx.meta
+        B, L, three_hd = qkv.shape
+        hd = three_hd // 3
+        dk = hd // h
+        es = qkv.element_size()
+        strides = (L * three_hd, dk, three_hd)
+        with torch.cuda.device(qkv.device):
+            d_out_c = d_out.contiguous()
+            d_p_c = d_p.contiguous() if (need_p and d_p is not None) else None
+            dqkv = torch.empty_like(qkv)
+            ws = torch.empty(max(int(lib.spacap_mha_bwd_workspace_bytes(B, h, L)), 16), dtype=torch.uint8,
+                             device=qkv.device)
+            base, gb = qkv.data_ptr(), dqkv.data_ptr()
+            check(lib.spacap_mha_bwd_f32(
+                base, base + hd * es, base + 2 * hd * es, *strides, *strides, *strides,
+                mask_u8.data_ptr() if mask_u8 is not None else None, mask_sb, mask_sq, None, 0, 0, 0,
+                B, h, L, L, dk, scale, float(dropout_p), int(seed),
+                rng_state(qkv.device).data_ptr() if dropout_p > 0.0 else None, lse.data_ptr(),
+                d_out_c.data_ptr(), d_p_c.data_ptr() if d_p_c is not None else None, ws.data_ptr(),
+                gb, gb + hd * es, gb + 2 * hd * es, three_hd,
+                torch.cuda.current_stream(qkv.device).cuda_stream), "spacap_mha_bwd_f32")
+        return dqkv, None, None, None, None, None, None, None
+
+
+def self_attention_packed(qkv, h, mask=None, dropout_p=0.0, training=False, need_p=True):
+    """qkv (B,L,3*h*d_k) packed [q | k | v] -> (out (B,L,h*d_k), p_attn (B,h,L,L) or None)."""
+    B, L, _ = qkv.shape
+    m, msb, msq = _prep_mask(mask, B, L, L)
+    p = float(dropout_p) if training else 0.0
+    seed = _next_seed() if p > 0.0 else 0
+    out, second = FusedSelfAttentionPacked.apply(qkv, h, m, msb, msq, p, seed, need_p)
+    return out, (second if need_p else None)
 
 
 def attention(query, key, value, mask=None, dropout_p=0.0, training=False, need_p=True, bias=None):

@@ -24,6 +24,7 @@ class HipBackend:
                   "group_points_grad", "group_max", "group_max_grad"):
             setattr(self, n, getattr(ext, n))
         self.attention = _att.attention
+        self.self_attention_packed = _att.self_attention_packed
         self.layer_norm = _att.layer_norm
         self.relation_feature = _att.relation_feature
         self.relation_layer1 = _att.relation_layer1

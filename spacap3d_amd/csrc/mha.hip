@@ -47,6 +47,7 @@ struct MhaArgs {
   float *out, *p_out, *stats;       // forward outputs
   const float *d_out, *d_p;         // backward inputs
   float *dq, *dk, *dv, *delta;      // backward outputs / scratch
+  long g_sl;                        // row stride (floats) of dq / dk / dv: h * d_k when dense
 };
 
 __device__ __forceinline__ bool keep_elem(const MhaArgs &A, int b, int hh, int q, int key) {
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
   for (int rr = 0; rr < 4; ++rr) {
     const int qo = q0 + 4 * lg + rr;
     if (qo < A.Lq) {
-      float *op = A.dq + (((size_t)b * A.Lq + qo) * A.h + hh) * DK;
+      float *op = A.dq + ((size_t)b * A.Lq + qo) * A.g_sl + hh * DK;
 #pragma unroll
       for (int db = 0; db < DK / 16; ++db) op[16 * db + lq] = dq[db][rr];
     }
@@ -344,8 +345,8 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
   for (int rr = 0; rr < 4; ++rr) {
     const int ko = key0 + 4 * lg + rr;
     if (ko < A.Lk) {
-      float *okp = A.dk + (((size_t)b * A.Lk + ko) * A.h + hh) * DK;
-      float *ovp = A.dv + (((size_t)b * A.Lk + ko) * A.h + hh) * DK;
+      float *okp = A.dk + ((size_t)b * A.Lk + ko) * A.g_sl + hh * DK;
+      float *ovp = A.dv + ((size_t)b * A.Lk + ko) * A.g_sl + hh * DK;
 #pragma unroll
       for (int db = 0; db < DK / 16; ++db) {
         okp[16 * db + lq] = dk[db][rr];
@@ -438,15 +439,18 @@ extern "C" int spacap_mha_bwd_f32(const float *q, const float *k, const float *v
                                   long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
                                   int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
                                   const float *stats, const float *d_out, const float *d_p, void *workspace,
-                                  float *dq, float *dk, float *dv, spacap_stream_t stream) {
+                                  float *dq, float *dk, float *dv, long grad_row_stride, spacap_stream_t stream) {
   MhaArgs A;
   int rc = fill_args(A, "spacap_mha_bwd_f32", q, k, v, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, mask,
                      mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed, seed_dev);
   if (rc) return rc;
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(dq && dk && dv, "spacap_mha_bwd_f32: null output");
+  SPACAP_REQUIRE(grad_row_stride == 0 || grad_row_stride >= (long)h * d_k, "spacap_mha_bwd_f32: bad grad_row_stride");
   hipStream_t s = spacap::as_stream(stream);
+  A.g_sl = grad_row_stride ? grad_row_stride : (long)h * d_k;
   if (Lq == 0) {
+    SPACAP_REQUIRE(A.g_sl == (long)h * d_k, "spacap_mha_bwd_f32: Lq == 0 needs dense gradients");
     SPACAP_CHECK_HIP(hipMemsetAsync(dk, 0, sizeof(float) * (size_t)B * Lk * h * d_k, s), "spacap_mha_bwd_f32");
     SPACAP_CHECK_HIP(hipMemsetAsync(dv, 0, sizeof(float) * (size_t)B * Lk * h * d_k, s), "spacap_mha_bwd_f32");
     return SPACAP_OK;

@@ -87,9 +87,23 @@ class MultiHeadedAttention(nn.Module):
         self.store_attn = store_attn
 
     def forward(self, query, key, value, mask=None):
+        nb = query.size(0)
+        packed = getattr(ops(), "self_attention_packed", None) if (query is key and key is value) else None
+        if packed is not None and query.is_cuda:
+            # self-attention: q, k, v from ONE GEMM over the concatenated weights; the kernels read the packed result
+            # through strides and write one packed gradient (see attention.FusedSelfAttentionPacked)
+            hd = self.h * self.d_k
+            w = torch.cat([l.weight for l in self.linears[:3]], dim=0)
+            b = torch.cat([l.bias for l in self.linears[:3]], dim=0)
+            qkv = F.linear(query, w, b)
+            need_p = self.keep_value if self.store_attn is None else (self.store_attn or self.keep_value)
+            p = self.dropout.p
+            x, self.attn = packed(qkv, self.h, mask=mask, dropout_p=p, training=self.dropout.training, need_p=need_p)
+            if self.keep_value:
+                self.value = qkv[..., 2 * hd:].view(nb, -1, self.h, self.d_k).transpose(1, 2)
+            return self.linears[-1](x)
         if mask is not None:
             mask = mask.unsqueeze(1)
-        nb = query.size(0)
         query, key, value = [l(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                              for l, x in zip(self.linears, (query, key, value))]
         need_p = self.keep_value if self.store_attn is None else (self.store_attn or self.keep_value)

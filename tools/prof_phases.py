@@ -86,6 +86,7 @@ def report():
     cnt = collections.Counter()
     mi, phase = -1, None
     big = []
+    seqk = []
     for s, e, n in ev:
         if is_mark(n):
             mi += 1
@@ -99,12 +100,18 @@ def report():
         kcnt[phase][n] += 1
         if mi >= begins[-1] and e - s >= 30_000:
             big.append((phase, (e - s) / 1e3, n[:160]))
+        if mi >= begins[-1] and phase == os.environ.get("PH_SEQ"):
+            seqk.append(((e - s) / 1e3, n[:130]))
     K = 3
     print(f"kernel time per phase, mean of the last {K} steps (eager; sum {sum(tot.values()) / 1e6 / K:.2f} ms/step)")
     for ph, v in sorted(tot.items(), key=lambda kv: -kv[1]):
         print(f"{v / 1e6 / K:8.3f} ms  {cnt[ph] / K:6.0f} kernels  {ph}")
         for n, kv in kern[ph].most_common(top):
             print(f"            {kv / 1e6 / K:7.3f} {kcnt[ph][n] / K:5.0f}x  {n[:110]}")
+    if seqk:
+        print(f"\nall kernels of phase {os.environ.get('PH_SEQ')} (last step), in launch order")
+        for us, n in seqk:
+            print(f"{us:8.1f} us  {n}")
     print("\nkernels >= 30 us of the last step, in launch order")
     for ph, us, n in big:
         print(f"{us:8.1f} us  {ph:22s} {n}")
