@@ -283,6 +283,15 @@ size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E);
 int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
                                void *workspace, spacap_stream_t stream);
 
+/* ---- Linear layers of the Transformer: weight + bias gradient in one launch ------------------------------------
+ * dW[ck,cp] = sum_r g[r,ck] x[r,cp], db[ck] = sum_r g[r,ck]  (backward of torch.nn.Linear as used by
+ * models/transformer_captioner.py:63-99,117-126).  g f32 [R,CK], x f32 [R,CP] dense, CK and CP multiples of 128.
+ * part f32 [spacap_linear_wgrad_slabs(R,CK,CP)][CK*CP (+CK when with_bias)]: per-slab partial sums (weights, then
+ * bias) that the caller adds up in slab order.  spacap_linear_wgrad_slabs returns 0 for shapes without a kernel. */
+int spacap_linear_wgrad_slabs(long R, int CK, int CP);
+int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
+                            spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,8 @@ class HipBackend:
         self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
+        from . import linear as _lin
+        self.linear = _lin.linear
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
 

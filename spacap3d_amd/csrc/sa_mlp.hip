@@ -893,3 +893,103 @@ extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, i
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ===========================================================================================================
+// Weight + bias gradient of a Linear layer:  dW[ck, cp] = sum_r g[r, ck] x[r, cp],  db[ck] = sum_r g[r, ck]
+// (torch.nn.Linear backward: models/transformer_captioner.py's projections and feed-forward layers).  The BLAS
+// path runs these [<= 2048 rows] x [128..2048]^2 reductions as a memset + a split-K GEMM + a separate column-sum
+// kernel (30 us of mostly latency for 67 MFLOP); here one launch produces per-slab partials of both (the bias
+// gradient falls out of the same staged tile as one more MFMA column against a constant 1), summed in slab order
+// by the caller.
+namespace {
+template <bool WITH_BIAS>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CK,
+                                                           int CP, long R, float *__restrict__ part) {
+  constexpr int CB = 128, LDG = CB + 16;
+  __shared__ __attribute__((aligned(16))) float s_g[TW * LDG];
+  __shared__ __attribute__((aligned(16))) float s_x[TW * LDG];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int ck0 = blockIdx.y * CB, cp0 = blockIdx.z * CB;
+  const int c4 = tid & 31, r0 = tid >> 5;  // 32 float4 per 128-wide row, 8 rows per pass
+  f32x4 acc[2][8], accb[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    accb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long ntiles = (R + TW - 1) / TW;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * TW;
+#pragma unroll
+    for (int i = 0; i < TW / 8; ++i) {
+      const int row = r0 + 8 * i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) {
+        a = ld4(g + (size_t)(row0 + row) * CK + ck0 + c4 * 4);
+        b = ld4(x + (size_t)(row0 + row) * CP + cp0 + c4 * 4);
+      }
+      st4(&s_g[row * LDG + c4 * 4], a);
+      st4(&s_x[row * LDG + c4 * 4], b);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TW / 4; ++ks) {
+      float af[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) af[m] = s_g[(ks * 4 + lg) * LDG + (w * 2 + m) * 16 + l15];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const float b = s_x[(ks * 4 + lg) * LDG + n * 16 + l15];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m][n] = MFMA16(af[m], b, acc[m][n]);
+      }
+      if (WITH_BIAS) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) accb[m] = MFMA16(af[m], 1.0f, accb[m]);
+      }
+    }
+    __syncthreads();
+  }
+  // partial layout per slab: [CK][CP] weights, then [CK] bias
+  float *o = part + (size_t)blockIdx.x * ((size_t)CK * CP + (WITH_BIAS ? CK : 0));
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        o[(size_t)(ck0 + (w * 2 + m) * 16 + 4 * lg + u) * CP + cp0 + n * 16 + l15] = acc[m][n][u];
+  if (WITH_BIAS && blockIdx.z == 0 && l15 == 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[(size_t)CK * CP + ck0 + (w * 2 + m) * 16 + 4 * lg + u] = accb[m][u];
+  }
+}
+}  // namespace
+
+// number of row slabs (= partial results) for a (rows, CK, CP) problem; 0 when the shape has no kernel
+extern "C" int spacap_linear_wgrad_slabs(long R, int CK, int CP) {
+  if (R < 1 || CK < 128 || CP < 128 || CK % 128 || CP % 128) return 0;
+  const long tiles = (R + TW - 1) / TW, yz = (long)(CK / 128) * (CP / 128);
+  long n = 1024 / yz, cap = (4L << 20) / ((long)CK * CP);
+  if (n > cap) n = cap;
+  if (n > tiles) n = tiles;
+  return (int)(n < 1 ? 1 : n);
+}
+
+// part f32 [spacap_linear_wgrad_slabs(R,CK,CP)][CK*CP (+ CK when with_bias)]
+extern "C" int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_linear_wgrad_f32";
+  const int nslab = spacap_linear_wgrad_slabs(R, CK, CP);
+  SPACAP_REQUIRE(nslab > 0, "%s: (R=%ld, CK=%d, CP=%d) unsupported", what, R, CK, CP);
+  SPACAP_REQUIRE(g && x && part, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const dim3 grid(nslab, CK / 128, CP / 128);
+  if (with_bias) hipLaunchKernelGGL((linear_wgrad_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  else hipLaunchKernelGGL((linear_wgrad_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

@@ -38,6 +38,19 @@ def attention(query, key, value, mask=None, dropout=None, need_p=True):
     return ops().attention(query, key, value, mask=mask, dropout_p=p, training=training, need_p=need_p)
 
 
+def _linear(x, lin):
+    """``lin(x)`` through the backend's Linear op (one-launch weight + bias gradient) when it has one."""
+    f = getattr(ops(), "linear", None)
+    if f is None or lin.bias is None or not x.is_cuda:
+        return lin(x)
+    return f(x, lin.weight, lin.bias)
+
+
+def _linear_wb(x, w, b):
+    f = getattr(ops(), "linear", None)
+    return f(x, w, b) if (f is not None and x.is_cuda) else F.linear(x, w, b)
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x W^T + b for inputs with very many rows (the relation head runs its MLP on B*K*K = 524 288 pair
     features).  Forward and dX are ordinary GEMMs; the weight gradient dW = G^T X reduces over all rows into a
@@ -95,13 +108,13 @@ class MultiHeadedAttention(nn.Module):
             hd = self.h * self.d_k
             w = torch.cat([l.weight for l in self.linears[:3]], dim=0)
             b = torch.cat([l.bias for l in self.linears[:3]], dim=0)
-            qkv = F.linear(query, w, b)
+            qkv = _linear_wb(query, w, b)
             need_p = self.keep_value if self.store_attn is None else (self.store_attn or self.keep_value)
             p = self.dropout.p
             x, self.attn = packed(qkv, self.h, mask=mask, dropout_p=p, training=self.dropout.training, need_p=need_p)
             if self.keep_value:
                 self.value = qkv[..., 2 * hd:].view(nb, -1, self.h, self.d_k).transpose(1, 2)
-            return self.linears[-1](x)
+            return _linear(x, self.linears[-1])
         if mask is not None:
             mask = mask.unsqueeze(1)
         query, key, value = [l(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
@@ -111,7 +124,7 @@ class MultiHeadedAttention(nn.Module):
         if self.keep_value:
             self.value = value
         x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
-        return self.linears[-1](x)
+        return _linear(x, self.linears[-1])
 
 
     def forward_incremental(self, x_new, cache, mask=None):
@@ -138,7 +151,7 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return self.w_2(self.dropout(F.relu(self.w_1(x))))
+        return _linear(self.dropout(F.relu(_linear(x, self.w_1))), self.w_2)
 
 
 class Embeddings(nn.Module):

@@ -209,3 +209,25 @@ def test_fused_relation_layer1_matches_feature_linear_relu(att, B, H, K, D):
     for got, want, name in zip(gpu, refs, "PVWb"):
         err = float((got.grad.cpu().double() - want.grad).abs().max()) / (float(want.grad.abs().max()) + 1e-12)
         assert err < 1e-4, (name, err)
+
+
+@pytest.mark.parametrize("R,CK,CP", [(2048, 128, 128), (2048, 384, 128), (2048, 2048, 128), (2048, 128, 2048),
+                                     (256, 128, 128), (257, 128, 256), (33, 256, 128), (1, 128, 128),
+                                     (100, 3001, 128)])
+def test_fused_linear_weight_and_bias_gradients(R, CK, CP):
+    """spacap_linear_wgrad_f32 (dW = g^T x and db = sum g in one launch) against float64 autograd; the last
+    case has no kernel (CK not a multiple of 128) and must take the BLAS route."""
+    from spacap3d_amd.linear import linear
+    g = torch.Generator().manual_seed(R + CK)
+    x = torch.randn(3, R, CP, generator=g)[0:1].squeeze(0)
+    W = torch.randn(CK, CP, generator=g) * 0.1
+    b = torch.randn(CK, generator=g)
+    w = torch.randn(R, CK, generator=g)
+    xr, Wr, br = (t.double().requires_grad_(True) for t in (x, W, b))
+    (torch.nn.functional.linear(xr, Wr, br) * w.double()).sum().backward()
+    xg, Wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = linear(xg, Wg, bg)
+    (y * w.to(DEV)).sum().backward()
+    for got, want in ((xg.grad, xr.grad), (Wg.grad, Wr.grad), (bg.grad, br.grad)):
+        err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 2e-5, err
