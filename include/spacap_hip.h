@@ -292,6 +292,22 @@ int spacap_linear_wgrad_slabs(long R, int CK, int CP);
 int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
                             spacap_stream_t stream);
 
+/* ---- fused elementwise pieces of the Transformer sublayers (csrc/elementwise.hip) -----------------------------
+ * Dropout as torch.nn.Dropout (keep with probability 1-p, kept values scaled by 1/(1-p)); the keep mask is a
+ * counter hash of (seed + *seed_dev, element index), regenerated in the backward.  All tensors dense f32 [n],
+ * 16-byte aligned.
+ *   relu_dropout:  out = dropout(relu(x))      (models/transformer_captioner.py:126)
+ *                  dx  = (y > 0) ? g/(1-p) : 0 with y the saved forward output
+ *   dropout_add:   out = res + dropout(y)      (models/transformer_captioner.py:115-123)
+ *                  dy  = keep ? g/(1-p) : 0    (same seed words as the forward call) */
+int spacap_relu_dropout_fwd_f32(const float *x, long n, float p, uint64_t seed, const uint64_t *seed_dev,
+                                float *out, spacap_stream_t stream);
+int spacap_relu_dropout_bwd_f32(const float *g, const float *y, long n, float p, float *dx, spacap_stream_t stream);
+int spacap_dropout_add_fwd_f32(const float *res, const float *y, long n, float p, uint64_t seed,
+                               const uint64_t *seed_dev, float *out, spacap_stream_t stream);
+int spacap_dropout_add_bwd_f32(const float *g, long n, float p, uint64_t seed, const uint64_t *seed_dev,
+                               float *out, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

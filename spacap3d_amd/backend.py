@@ -30,6 +30,9 @@ class HipBackend:
         self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
+        from . import fused_dropout as _fd
+        self.relu_dropout = _fd.relu_dropout
+        self.dropout_add = _fd.dropout_add
         from . import linear as _lin
         self.linear = _lin.linear
         from . import sa_mlp as _sa

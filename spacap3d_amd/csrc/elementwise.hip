@@ -1,0 +1,137 @@
+// Fused elementwise pieces of the Transformer sublayers for gfx950 (MI355X).
+//
+//   relu_dropout :  y = dropout(relu(x))            models/transformer_captioner.py:126  (feed-forward hidden layer)
+//   dropout_add  :  out = res + dropout(y)          models/transformer_captioner.py:115-123 (SublayerConnection)
+//
+// PyTorch runs each as two launches forward (and keeps a byte mask for backward); here one launch each way.  The
+// keep mask is a counter hash of (seed, element index) -- regenerated in the backward instead of stored -- with the
+// same two-part seed as the attention dropout (host word per call + device-resident step counter, so a replayed
+// hipGraph draws new masks every step).  Dropout semantics as torch.nn.Dropout: keep with probability 1 - p,
+// scale kept values by 1 / (1 - p).
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+struct DropSeed {
+  unsigned lo, hi;
+};
+
+__device__ __forceinline__ DropSeed make_seed(unsigned long long seed, const unsigned long long *seed_dev) {
+  const unsigned long long s = seed + (seed_dev ? *seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+  return DropSeed{(unsigned)s, (unsigned)(s >> 32)};
+}
+
+// 32-bit finaliser (murmur3 fmix32) over the element index mixed with both seed words
+__device__ __forceinline__ unsigned hash32(unsigned long long idx, DropSeed s) {
+  unsigned h = (unsigned)idx ^ s.lo;
+  h += ((unsigned)(idx >> 32) ^ s.hi) * 0x9E3779B1u;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+template <int MODE>  // 0: y = drop(relu(x)); 1: out = res + drop(x); 2: dx = keep ? g * scale : 0
+__global__ __launch_bounds__(256) void drop_kernel(const float *__restrict__ x, const float *__restrict__ res, long n,
+                                                   unsigned thresh, float scale, unsigned long long seed,
+                                                   const unsigned long long *__restrict__ seed_dev, float *__restrict__ out) {
+  const DropSeed sd = make_seed(seed, seed_dev);
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(x + 4 * i);
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) r = *reinterpret_cast<const f32x4 *>(res + 4 * i);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool keep = thresh == 0u || hash32((unsigned long long)(4 * i + u), sd) >= thresh;
+      float a = MODE == 0 ? fmaxf(v[u], 0.f) : v[u];
+      a = keep ? a * scale : 0.f;
+      v[u] = MODE == 1 ? r[u] + a : a;
+    }
+    *reinterpret_cast<f32x4 *>(out + 4 * i) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {  // tail
+    const long i = (n4 << 2) + threadIdx.x;
+    const bool keep = thresh == 0u || hash32((unsigned long long)i, sd) >= thresh;
+    float a = MODE == 0 ? fmaxf(x[i], 0.f) : x[i];
+    a = keep ? a * scale : 0.f;
+    out[i] = MODE == 1 ? res[i] + a : a;
+  }
+}
+
+// dx = (y > 0) ? g * scale : 0      (y = the saved output of relu_dropout: positive exactly where kept and x > 0)
+__global__ __launch_bounds__(256) void relu_dropout_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                               long n, float scale, float *__restrict__ dx) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const f32x4 gv = *reinterpret_cast<const f32x4 *>(g + 4 * i), yv = *reinterpret_cast<const f32x4 *>(y + 4 * i);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = yv[u] > 0.f ? gv[u] * scale : 0.f;
+    *reinterpret_cast<f32x4 *>(dx + 4 * i) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    dx[i] = y[i] > 0.f ? g[i] * scale : 0.f;
+  }
+}
+
+inline unsigned grid_for(long n) {
+  long g = ((n >> 2) + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  return (unsigned)g;
+}
+
+inline bool drop_params(float p, unsigned &thresh, float &scale) {
+  if (!(p >= 0.f && p < 1.f)) return false;
+  thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  scale = 1.0f / (1.0f - p);
+  return true;
+}
+
+}  // namespace
+
+#define DROP_ENTRY(NAME, MODE, XARG, RESARG)                                                                         \
+  unsigned thresh;                                                                                                   \
+  float scale;                                                                                                       \
+  SPACAP_REQUIRE(n >= 0 && drop_params(p, thresh, scale), NAME ": bad arguments (n=%ld, p=%f)", n, (double)p);      \
+  if (n == 0) return SPACAP_OK;                                                                                      \
+  SPACAP_REQUIRE(XARG && out && ((reinterpret_cast<uintptr_t>(XARG) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, \
+                 NAME ": null or unaligned pointer");                                                               \
+  hipLaunchKernelGGL((drop_kernel<MODE>), dim3(grid_for(n)), dim3(256), 0, spacap::as_stream(stream), XARG, RESARG,  \
+                     n, thresh, scale, (unsigned long long)seed, (const unsigned long long *)seed_dev, out);         \
+  SPACAP_CHECK_LAUNCH(NAME);                                                                                         \
+  return SPACAP_OK;
+
+extern "C" int spacap_relu_dropout_fwd_f32(const float *x, long n, float p, uint64_t seed, const uint64_t *seed_dev,
+                                           float *out, spacap_stream_t stream) {
+  DROP_ENTRY("spacap_relu_dropout_fwd_f32", 0, x, (const float *)nullptr)
+}
+
+extern "C" int spacap_relu_dropout_bwd_f32(const float *g, const float *y, long n, float p, float *dx,
+                                           spacap_stream_t stream) {
+  unsigned thresh;
+  float scale;
+  SPACAP_REQUIRE(n >= 0 && drop_params(p, thresh, scale), "spacap_relu_dropout_bwd_f32: bad arguments");
+  if (n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(g && y && dx, "spacap_relu_dropout_bwd_f32: null pointer");
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, spacap::as_stream(stream), g, y, n, scale, dx);
+  SPACAP_CHECK_LAUNCH("spacap_relu_dropout_bwd_f32");
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_dropout_add_fwd_f32(const float *res, const float *y, long n, float p, uint64_t seed,
+                                          const uint64_t *seed_dev, float *out, spacap_stream_t stream) {
+  SPACAP_REQUIRE(res != nullptr || n == 0, "spacap_dropout_add_fwd_f32: null pointer");
+  DROP_ENTRY("spacap_dropout_add_fwd_f32", 1, y, res)
+}
+
+extern "C" int spacap_dropout_add_bwd_f32(const float *g, long n, float p, uint64_t seed, const uint64_t *seed_dev,
+                                          float *out, spacap_stream_t stream) {
+  DROP_ENTRY("spacap_dropout_add_bwd_f32", 2, g, (const float *)nullptr)
+}

@@ -151,7 +151,10 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x):
-        return _linear(self.dropout(F.relu(_linear(x, self.w_1))), self.w_2)
+        h = _linear(x, self.w_1)
+        f = getattr(ops(), "relu_dropout", None)
+        h = f(h, self.dropout.p, self.dropout.training) if (f is not None and h.is_cuda) else self.dropout(F.relu(h))
+        return _linear(h, self.w_2)
 
 
 class Embeddings(nn.Module):
@@ -193,7 +196,11 @@ class SublayerConnection(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, sublayer):
-        return x + self.dropout(sublayer(self.norm(x)))
+        y = sublayer(self.norm(x))
+        f = getattr(ops(), "dropout_add", None)
+        if f is not None and y.is_cuda:
+            return f(x, y, self.dropout.p, self.dropout.training)
+        return x + self.dropout(y)
 
 
 class PositionalEncoding(nn.Module):

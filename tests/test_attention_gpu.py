@@ -231,3 +231,44 @@ def test_fused_linear_weight_and_bias_gradients(R, CK, CP):
     for got, want in ((xg.grad, xr.grad), (Wg.grad, Wr.grad), (bg.grad, br.grad)):
         err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
         assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("n", [2048 * 2048, 2048 * 128, 1003, 5])
+def test_fused_relu_dropout_and_dropout_add(n):
+    """csrc/elementwise.hip: kept fraction ~ 1-p, kept values scaled by 1/(1-p), the backward uses the same mask as
+    the forward, p = 0 / eval are the plain ops."""
+    from spacap3d_amd import fused_dropout as fd
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+    p = 0.1
+    y = fd.relu_dropout(x, p, True)
+    kept = (y != 0)
+    pos = x.detach() > 0
+    assert not bool((kept & ~pos).any())                       # nothing appears where relu is zero
+    assert torch.allclose(y[kept], x.detach()[kept] / (1 - p), rtol=1e-6)
+    if n > 10000:
+        frac = float(kept.sum()) / float(pos.sum())
+        assert abs(frac - (1 - p)) < 0.01, frac
+    w = torch.randn(n, generator=g).to(DEV)
+    (y * w).sum().backward()
+    assert torch.allclose(x.grad, torch.where(kept, w / (1 - p), torch.zeros_like(w)), rtol=1e-6)
+    x.grad = None
+    out = fd.dropout_add(r, x, p, True)
+    d = out.detach() - r.detach()
+    keep2 = d != 0
+    if n > 10000:
+        assert abs(float(keep2.float().mean()) - (1 - p)) < 0.01
+    assert torch.allclose(d[keep2], x.detach()[keep2] / (1 - p), rtol=1e-4, atol=1e-5)
+    (out * w).sum().backward()
+    assert torch.equal(r.grad, w)
+    big = x.detach().abs() > 1e-3   # (out - r) can round to 0 for tiny x: compare the mask where it is observable
+    want = torch.where(keep2, w / (1 - p), torch.zeros_like(w))
+    assert torch.allclose(x.grad[big], want[big], rtol=1e-6)
+    assert bool(((x.grad == 0) | torch.isclose(x.grad, w / (1 - p), rtol=1e-6)).all())
+    # a second call draws another mask; eval mode / p = 0 are the plain ops
+    y2 = fd.relu_dropout(x, p, True)
+    if n > 10000:
+        assert not torch.equal(y2 != 0, kept)
+    assert torch.equal(fd.relu_dropout(x, p, False), torch.relu(x))
+    assert torch.equal(fd.dropout_add(r, x, 0.0, True), r + x)
