@@ -356,6 +356,307 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Key-split / query-split variants for long sequences (Lk > 64).  The kernels above give one wavefront
+// 16 queries x ALL keys (or 16 keys x all queries): at B*h = 64 and L = 256 that is 1 024 wavefronts, one
+// per SIMD, each a serial chain over 16 tiles (40-65 us for 0.27 GFLOP).  Here the four waves of a
+// workgroup share the 16 queries (keys) and split the other dimension; row maxima / sums / partial
+// products are combined through LDS in a fixed order (deterministic), identical arithmetic per element.
+// ------------------------------------------------------------------------------------------------
+template <int NTW, int DK>  // NTW key tiles per wave, 4 waves: Lk <= 64 * NTW
+__global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
+  __shared__ float s_m[4][16], s_l[4][16];
+  __shared__ float s_o[4][16][DK + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int q0 = blockIdx.x * 16;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int q = q0 + lq;
+  const int qc = q < A.Lq ? q : A.Lq - 1;
+  const int t0 = w * NTW;
+
+  const float *qp = A.q + b * A.q_sb + hh * A.q_sh + qc * A.q_sl;
+  float qreg[DK / 4];
+#pragma unroll
+  for (int s = 0; s < DK / 4; ++s) qreg[s] = qp[4 * s + lg];
+
+  f32x4 acc[NTW];
+  const float *kbase = A.k + b * A.k_sb + hh * A.k_sh;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int t = t0 + tt;
+    acc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (16 * t < A.Lk) {
+      const int key = 16 * t + lq;
+      const float *kp = kbase + (key < A.Lk ? key : A.Lk - 1) * A.k_sl;
+#pragma unroll
+      for (int s = 0; s < DK / 4; ++s) acc[tt] = MFMA16(kp[4 * s + lg], qreg[s], acc[tt]);
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bool masked;
+      acc[tt][r] = logit(A, acc[tt][r], b, hh, q, 16 * (t0 + tt) + 4 * lg + r, masked);
+      m = fmaxf(m, acc[tt][r]);
+    }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  if (lg == 0) s_m[w][lq] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_m[0][lq], s_m[1][lq]), fmaxf(s_m[2][lq], s_m[3][lq]));
+  float l = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc[tt][r] = expf(acc[tt][r] - m);
+      l += acc[tt][r];
+    }
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (lg == 0) s_l[w][lq] = l;
+  __syncthreads();
+  l = (s_l[0][lq] + s_l[1][lq]) + (s_l[2][lq] + s_l[3][lq]);
+  if (w == 0 && lg == 0 && q < A.Lq) {
+    float *st = A.stats + (((size_t)b * A.h + hh) * A.Lq + q) * 2;
+    st[0] = m;
+    st[1] = l;
+  }
+  const bool vec_ok = (A.Lk & 3) == 0;
+  float *prow = A.p_out ? A.p_out + (((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk : nullptr;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    f32x4 p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float pv = acc[tt][r] / l;
+      if (!keep_elem(A, b, hh, q, 16 * (t0 + tt) + 4 * lg + r)) pv = 0.f; else pv *= A.keep_scale;
+      p[r] = pv;
+    }
+    acc[tt] = p;
+    if (prow && q < A.Lq) {
+      const int key = 16 * (t0 + tt) + 4 * lg;
+      if (vec_ok) {
+        if (key < A.Lk) *reinterpret_cast<f32x4 *>(prow + key) = p;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key + r < A.Lk) prow[key + r] = p[r];
+      }
+    }
+  }
+  f32x4 o[DK / 16];
+#pragma unroll
+  for (int db = 0; db < DK / 16; ++db) o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float *vbase = A.v + b * A.v_sb + hh * A.v_sh;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    if (16 * (t0 + tt) < A.Lk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * (t0 + tt) + 4 * lg + r;
+        const float *vp = vbase + (key < A.Lk ? key : A.Lk - 1) * A.v_sl;
+#pragma unroll
+        for (int db = 0; db < DK / 16; ++db) o[db] = MFMA16(acc[tt][r], vp[16 * db + lq], o[db]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int db = 0; db < DK / 16; ++db) s_o[w][4 * lg + rr][16 * db + lq] = o[db][rr];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * DK; e += 256) {
+    const int qi = e / DK, d = e - qi * DK;
+    if (q0 + qi < A.Lq)
+      A.out[(((size_t)b * A.Lq + q0 + qi) * A.h + hh) * DK + d] =
+          (s_o[0][qi][d] + s_o[1][qi][d]) + (s_o[2][qi][d] + s_o[3][qi][d]);
+  }
+}
+
+template <int NTW, int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) {
+  __shared__ float s_d[4][16];
+  __shared__ float s_o[4][16][DK + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int q0 = blockIdx.x * 16;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int q = q0 + lq;
+  const int qc = q < A.Lq ? q : A.Lq - 1;
+  const int t0 = w * NTW;
+
+  const float *qp = A.q + b * A.q_sb + hh * A.q_sh + qc * A.q_sl;
+  const float *dop = A.d_out + (((size_t)b * A.Lq + qc) * A.h + hh) * DK;
+  float qreg[DK / 4], doreg[DK / 4];
+#pragma unroll
+  for (int s = 0; s < DK / 4; ++s) {
+    qreg[s] = qp[4 * s + lg];
+    doreg[s] = dop[4 * s + lg];
+  }
+  const float *st = A.stats + (((size_t)b * A.h + hh) * A.Lq + qc) * 2;
+  const float m = st[0], inv_l = 1.0f / st[1];
+
+  f32x4 p[NTW], dp[NTW];
+  const float *kbase = A.k + b * A.k_sb + hh * A.k_sh;
+  const float *vbase = A.v + b * A.v_sb + hh * A.v_sh;
+  const float *dprow = A.d_p ? A.d_p + (((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk : nullptr;
+  float delta = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int t = t0 + tt;
+    p[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dp[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (16 * t < A.Lk) {
+      const int keyl = 16 * t + lq;
+      const int kcl = keyl < A.Lk ? keyl : A.Lk - 1;
+      const float *kp = kbase + kcl * A.k_sl;
+      const float *vp = vbase + kcl * A.v_sl;
+#pragma unroll
+      for (int s = 0; s < DK / 4; ++s) {
+        p[tt] = MFMA16(kp[4 * s + lg], qreg[s], p[tt]);
+        dp[tt] = MFMA16(vp[4 * s + lg], doreg[s], dp[tt]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * lg + r;
+        bool masked;
+        const float s = logit(A, p[tt][r], b, hh, q, key, masked);
+        const float pr = (key < A.Lk) ? expf(s - m) * inv_l : 0.f;
+        float g = dp[tt][r];
+        if (dprow && key < A.Lk) g += dprow[key];
+        g = keep_elem(A, b, hh, q, key) ? g * A.keep_scale : 0.f;
+        delta += g * pr;
+        p[tt][r] = pr;
+        dp[tt][r] = (masked || key >= A.Lk) ? NAN : g;
+      }
+    }
+  }
+  delta += __shfl_xor(delta, 16);
+  delta += __shfl_xor(delta, 32);
+  if (lg == 0) s_d[w][lq] = delta;
+  __syncthreads();
+  delta = (s_d[0][lq] + s_d[1][lq]) + (s_d[2][lq] + s_d[3][lq]);
+  if (w == 0 && lg == 0 && q < A.Lq) A.delta[((size_t)b * A.h + hh) * A.Lq + q] = delta;
+
+  f32x4 dq[DK / 16];
+#pragma unroll
+  for (int db = 0; db < DK / 16; ++db) dq[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int t = t0 + tt;
+    if (16 * t < A.Lk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * lg + r;
+        const float g = dp[tt][r];
+        const float ds = (g != g) ? 0.f : p[tt][r] * (g - delta) * A.scale;
+        const float *kp = kbase + (key < A.Lk ? key : A.Lk - 1) * A.k_sl;
+#pragma unroll
+        for (int db = 0; db < DK / 16; ++db) dq[db] = MFMA16(ds, kp[16 * db + lq], dq[db]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int db = 0; db < DK / 16; ++db) s_o[w][4 * lg + rr][16 * db + lq] = dq[db][rr];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * DK; e += 256) {
+    const int qi = e / DK, d = e - qi * DK;
+    if (q0 + qi < A.Lq)
+      A.dq[((size_t)b * A.Lq + q0 + qi) * A.g_sl + hh * DK + d] =
+          (s_o[0][qi][d] + s_o[1][qi][d]) + (s_o[2][qi][d] + s_o[3][qi][d]);
+  }
+}
+
+// dK / dV: 16 keys per workgroup, the query tiles interleaved over the 4 waves
+template <int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A) {
+  __shared__ float s_k[4][16][DK + 1], s_v[4][16][DK + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int b = blockIdx.z, hh = blockIdx.y;
+  const int key0 = blockIdx.x * 16;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int key = key0 + lq;
+  const int kc = key < A.Lk ? key : A.Lk - 1;
+
+  const float *kp = A.k + b * A.k_sb + hh * A.k_sh + kc * A.k_sl;
+  const float *vp = A.v + b * A.v_sb + hh * A.v_sh + kc * A.v_sl;
+  float kreg[DK / 4], vreg[DK / 4];
+#pragma unroll
+  for (int s = 0; s < DK / 4; ++s) {
+    kreg[s] = kp[4 * s + lg];
+    vreg[s] = vp[4 * s + lg];
+  }
+  f32x4 dk[DK / 16], dv[DK / 16];
+#pragma unroll
+  for (int db = 0; db < DK / 16; ++db) {
+    dk[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float *qbase = A.q + b * A.q_sb + hh * A.q_sh;
+  const float *stb = A.stats + ((size_t)b * A.h + hh) * A.Lq * 2;
+  const float *delb = A.delta + ((size_t)b * A.h + hh) * A.Lq;
+
+  for (int qt = w; qt * 16 < A.Lq; qt += 4) {
+    const int qa = qt * 16 + lq;
+    const int qac = qa < A.Lq ? qa : A.Lq - 1;
+    const float *qp = qbase + qac * A.q_sl;
+    const float *dop = A.d_out + (((size_t)b * A.Lq + qac) * A.h + hh) * DK;
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, g4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < DK / 4; ++s) {
+      s4 = MFMA16(qp[4 * s + lg], kreg[s], s4);
+      g4 = MFMA16(dop[4 * s + lg], vreg[s], g4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = qt * 16 + 4 * lg + r;
+      const int qc = q < A.Lq ? q : A.Lq - 1;
+      const bool valid = (q < A.Lq) && (key < A.Lk);
+      bool masked;
+      const float s = logit(A, s4[r], b, hh, q, key, masked);
+      const float pr = valid ? expf(s - stb[qc * 2]) / stb[qc * 2 + 1] : 0.f;
+      float g = g4[r];
+      if (A.d_p && valid) g += A.d_p[(((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk + kc];
+      const bool keep = keep_elem(A, b, hh, q, key);
+      g = keep ? g * A.keep_scale : 0.f;
+      const float pd = keep ? pr * A.keep_scale : 0.f;
+      const float ds = (masked || !valid) ? 0.f : pr * (g - delb[qc]) * A.scale;
+      const float *qr = qbase + qc * A.q_sl;
+      const float *dor = A.d_out + (((size_t)b * A.Lq + qc) * A.h + hh) * DK;
+#pragma unroll
+      for (int db = 0; db < DK / 16; ++db) {
+        dk[db] = MFMA16(ds, qr[16 * db + lq], dk[db]);
+        dv[db] = MFMA16(valid ? pd : 0.f, dor[16 * db + lq], dv[db]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int db = 0; db < DK / 16; ++db) {
+      s_k[w][4 * lg + rr][16 * db + lq] = dk[db][rr];
+      s_v[w][4 * lg + rr][16 * db + lq] = dv[db][rr];
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 16 * DK; e += 256) {
+    const int ki = e / DK, d = e - ki * DK;
+    if (key0 + ki < A.Lk) {
+      const size_t o = ((size_t)b * A.Lk + key0 + ki) * A.g_sl + hh * DK + d;
+      A.dk[o] = (s_k[0][ki][d] + s_k[1][ki][d]) + (s_k[2][ki][d] + s_k[3][ki][d]);
+      A.dv[o] = (s_v[0][ki][d] + s_v[1][ki][d]) + (s_v[2][ki][d] + s_v[3][ki][d]);
+    }
+  }
+}
+
 int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, const float *v, long q_sb,
               long q_sh, long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
               const uint8_t *mask, long mask_sb, long mask_sq, const float *bias, long bias_sb, long bias_sh,
@@ -387,11 +688,12 @@ int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, cons
 
 template <int DK>
 void launch_fwd(const MhaArgs &A, hipStream_t s) {
-  dim3 grid((A.Lq + 63) / 64, A.h, A.B);
+  dim3 grid((A.Lq + 63) / 64, A.h, A.B), gs((A.Lq + 15) / 16, A.h, A.B);
   if (A.Lk <= 32) hipLaunchKernelGGL((mha_fwd_kernel<2, DK>), grid, dim3(256), 0, s, A);
   else if (A.Lk <= 64) hipLaunchKernelGGL((mha_fwd_kernel<4, DK>), grid, dim3(256), 0, s, A);
-  else if (A.Lk <= 256) hipLaunchKernelGGL((mha_fwd_kernel<16, DK>), grid, dim3(256), 0, s, A);
-  else hipLaunchKernelGGL((mha_fwd_kernel<32, DK>), grid, dim3(256), 0, s, A);
+  else if (A.Lk <= 128) hipLaunchKernelGGL((mha_fwd_split_kernel<2, DK>), gs, dim3(256), 0, s, A);
+  else if (A.Lk <= 256) hipLaunchKernelGGL((mha_fwd_split_kernel<4, DK>), gs, dim3(256), 0, s, A);
+  else hipLaunchKernelGGL((mha_fwd_split_kernel<8, DK>), gs, dim3(256), 0, s, A);
 }
 
 template <int DK>
@@ -399,10 +701,12 @@ void launch_bwd(const MhaArgs &A, hipStream_t s) {
   dim3 gq((A.Lq + 15) / 16, A.h, A.B);
   if (A.Lk <= 32) hipLaunchKernelGGL((mha_bwd_dq_kernel<2, DK>), gq, dim3(64), 0, s, A);
   else if (A.Lk <= 64) hipLaunchKernelGGL((mha_bwd_dq_kernel<4, DK>), gq, dim3(64), 0, s, A);
-  else if (A.Lk <= 256) hipLaunchKernelGGL((mha_bwd_dq_kernel<16, DK>), gq, dim3(64), 0, s, A);
-  else hipLaunchKernelGGL((mha_bwd_dq_kernel<32, DK>), gq, dim3(64), 0, s, A);
+  else if (A.Lk <= 128) hipLaunchKernelGGL((mha_bwd_dq_split_kernel<2, DK>), gq, dim3(256), 0, s, A);
+  else if (A.Lk <= 256) hipLaunchKernelGGL((mha_bwd_dq_split_kernel<4, DK>), gq, dim3(256), 0, s, A);
+  else hipLaunchKernelGGL((mha_bwd_dq_split_kernel<8, DK>), gq, dim3(256), 0, s, A);
   dim3 gk((A.Lk + 15) / 16, A.h, A.B);
-  hipLaunchKernelGGL((mha_bwd_dkv_kernel<DK>), gk, dim3(64), 0, s, A);
+  if (A.Lq <= 64) hipLaunchKernelGGL((mha_bwd_dkv_kernel<DK>), gk, dim3(64), 0, s, A);
+  else hipLaunchKernelGGL((mha_bwd_dkv_split_kernel<DK>), gk, dim3(256), 0, s, A);
 }
 
 }  // namespace
