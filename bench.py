@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="sample inside the step instead of one step ahead")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-streams", action="store_true", help="keep the relation head and the detection losses on the main stream")
     ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
                                                  "relation head, 'caption' the whole captioner")
     ap.add_argument("--cpu-sample", type=int, default=2, help="scenes in the CPU-baseline sample")
@@ -134,7 +135,8 @@ def main():
     if args.ablate == "relation":
         model.caption.check_relation = False
         model.caption.model.encoder.layers[-1].self_attn.keep_value = False
-    trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"))
+    trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"),
+                      multi_stream=not args.no_streams)
     # each rank owns its own shard of scenes (seed + rank), resident in HBM before the timed region
     data = synthetic_batch(per_gpu, cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
 
@@ -208,6 +210,7 @@ def main():
                                    f"grad all-reduce + Adam)",
                        "global_batch": per_gpu * world, "parallelism": f"dp{world}",
                        "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None,
+                       "side_stream_branches": bool(trainer.multi_stream),
                        "params": sum(p.numel() for p in model.parameters()),
                        "allreduce_bytes": trainer.bucket.nbytes},
             "roofline": roof, "ops": ops, "final_loss": loss_val,

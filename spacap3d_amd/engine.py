@@ -5,15 +5,16 @@ CUDA_LAUNCH_BLOCKING=1) and without logging / checkpointing (out of scope, SURVE
 """
 import torch
 
+from . import streams
 from . import synthetic as S
 from .detector import sampling_pyramid
 from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
-from .loss_helper import get_scene_cap_loss
+from .loss_helper import get_scene_cap_loss, start_detection_losses
 
 
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 use_relation: bool = True, split_optimizer: bool = False):
+                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = True):
         self.model = model
         self.mean_size_arr = mean_size_arr
         self.use_relation = use_relation
@@ -29,6 +30,8 @@ class Trainer:
         self._graph_grads = None
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
+        # independent branches of the step (relation head, detection losses) on side streams: spacap3d_amd/streams.py
+        self.multi_stream = multi_stream
         broadcast_parameters(model)
 
     # -- sampling-pyramid prefetch ---------------------------------------------------------------------------
@@ -66,8 +69,13 @@ class Trainer:
         return d
 
     def loss(self, data_dict):
-        d = self.model(dict(data_dict))
-        d = get_scene_cap_loss(d, use_relation=self.use_relation, mean_size_arr=self.mean_size_arr)
+        # the detection losses only need the proposal module's outputs: started right after it (a side-stream branch
+        # when streams are enabled) so their ~300 tiny launches overlap with the Transformer
+        kw = dict(num_heading_bin=S.NUM_HEADING_BIN, num_size_cluster=S.NUM_SIZE_CLUSTER, mean_size_arr=self.mean_size_arr)
+        need = ("vote_label", "center_label")
+        early = (lambda d: start_detection_losses(d, **kw)) if all(k in data_dict for k in need) else None
+        d = self.model(dict(data_dict), after_proposal=early)
+        d = get_scene_cap_loss(d, use_relation=self.use_relation, **kw)
         return d
 
     def _setup(self, data_dict):
@@ -87,12 +95,15 @@ class Trainer:
     def _core(self, data_dict, with_optimizer=True):
         """zero grads -> forward -> loss -> backward [-> all-reduce -> Adam]; no host sync, capturable."""
         pc = data_dict["point_clouds"]
+        streams.enable(self.multi_stream and pc.is_cuda)
         if pc.is_cuda:
             from .attention import advance_rng
             advance_rng(pc.device)  # new attention-dropout masks every step, also under graph replay
         self.bucket.zero()
         d = self.loss(data_dict)
         d["loss"].backward()
+        if pc.is_cuda:
+            streams.join_all(pc.device)  # side-stream branches (relation head, detection losses) re-join here
         if with_optimizer:
             self.bucket.all_reduce_mean(force_pack=self.split_optimizer)
             self.optimizer.step()

@@ -160,6 +160,31 @@ def compute_relation_loss(d):
     return out
 
 
+def _with(d, object_assignment, objectness_label):
+    """``d`` plus the two labels the box loss reads (they are written into ``d`` right after)."""
+    d["object_assignment"] = object_assignment
+    d["objectness_label"] = objectness_label
+    return d
+
+
+def start_detection_losses(d, num_heading_bin=1, num_size_cluster=18, mean_size_arr=None):
+    """Vote / objectness / box / class losses (lib/loss_helper.py:291-345): everything that only needs the proposal
+    module's outputs.  Issued as a side-stream branch (spacap3d_amd/streams.py) when that is enabled -- the engine
+    calls this right after the proposal module so that the ~300 tiny launches run beside the Transformer -- and
+    joined in ``get_scene_cap_loss``."""
+    from . import streams
+    with streams.branch("detection_loss", d["seed_xyz"]):
+        vote_loss = compute_vote_loss(d)
+        objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)
+        center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
+            compute_box_and_sem_cls_loss(_with(d, object_assignment, objectness_label), num_heading_bin,
+                                         num_size_cluster, mean_size_arr)
+        box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
+    d["_detection_losses"] = (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment,
+                              center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss,
+                              sem_cls_loss, box_loss)
+
+
 def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, caption=True, use_relation=False,
                        num_heading_bin=1, num_size_cluster=18, mean_size_arr=None):
     """Mutates and returns ``data_dict`` with every key the reference writes (lib/loss_helper.py:291-385).
@@ -171,18 +196,23 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     dev = d["seed_xyz"].device
     zero = _const("zero", dev, lambda: torch.zeros(()))
 
-    vote_loss = compute_vote_loss(d)
-    objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)
+    from . import streams
+    if "_detection_losses" not in d:
+        start_detection_losses(d, num_heading_bin, num_size_cluster, mean_size_arr)
+    (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment, center_loss, heading_cls_loss,
+     heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss, box_loss) = d.pop("_detection_losses")
+    if caption:
+        d["cap_loss"], d["cap_acc"] = compute_cap_loss(d)
+    else:
+        d["cap_loss"], d["cap_acc"], d["pred_ious"] = zero, zero, zero
+    streams.join("detection_loss", d["seed_xyz"])
+    streams.join("relation", d["seed_xyz"])
     total = objectness_label.shape[0] * objectness_label.shape[1]
     d["objectness_label"] = objectness_label
     d["objectness_mask"] = objectness_mask
     d["object_assignment"] = object_assignment
     d["pos_ratio"] = torch.sum(objectness_label.float()) / float(total)
     d["neg_ratio"] = torch.sum(objectness_mask) / float(total) - d["pos_ratio"]
-
-    center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
-        compute_box_and_sem_cls_loss(d, num_heading_bin, num_size_cluster, mean_size_arr)
-    box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
 
     d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
         torch.sum(objectness_mask) + 1e-6)
@@ -203,11 +233,6 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         d[k] = v if detection else zero
     if not detection:
         d["det_loss"] = zero
-
-    if caption:
-        d["cap_loss"], d["cap_acc"] = compute_cap_loss(d)
-    else:
-        d["cap_loss"], d["cap_acc"], d["pred_ious"] = zero, zero, zero
 
     loss = 0
     if detection:

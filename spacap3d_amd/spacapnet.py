@@ -34,7 +34,9 @@ class SpaCapNet(nn.Module):
                                                    early_guide=early_guide, check_relation=check_relation,
                                                    store_attn_all=store_attn_all)
 
-    def forward(self, data_dict, is_eval=False):
+    def forward(self, data_dict, is_eval=False, after_proposal=None):
+        """``after_proposal``: optional callable(data_dict) invoked between the proposal module and the captioner
+        (the training engine starts the detection losses there, on a side stream)."""
         data_dict = self.backbone_net(data_dict)
         xyz, features = data_dict["fp2_xyz"], data_dict["fp2_features"]
         data_dict["seed_inds"] = data_dict["fp2_inds"]
@@ -45,6 +47,8 @@ class SpaCapNet(nn.Module):
         data_dict["vote_xyz"] = xyz
         data_dict["vote_features"] = features
         data_dict = self.proposal(xyz, features, data_dict)
+        if after_proposal is not None:
+            after_proposal(data_dict)
         if not self.no_caption:
             data_dict = self.caption(data_dict, is_eval)
         return data_dict

@@ -425,9 +425,15 @@ class TransformerDecoderModel(nn.Module):
         ep["match_idx"] = idx.squeeze(1)
         ref_obj_feature = torch.gather(src, 1, idx.repeat(1, src.size(-1)).unsqueeze(1))
         seq, seq_mask = self._prepare_feature(ep["lang_label"])
-        out = self.model(src=src, tgt=seq, src_mask=ep["bbox_mask"].unsqueeze(1), tgt_mask=seq_mask,
+        src_mask = ep["bbox_mask"].unsqueeze(1)
+        memory = None
+        if self.model.encoder is not None:
+            memory = self.model.encode(src, src_pos, src_mask)
+            if self.check_relation:
+                self._relation_head(ep)  # reads the last encoder layer only: a side-stream branch beside the decoder
+        out = self.model(src=src, tgt=seq, src_mask=src_mask, tgt_mask=seq_mask,
                          obj_indicator=ref_obj_feature, src_pos=src_pos,
-                         obj_idx=idx if self.use_transformer_encoder else None)
+                         obj_idx=idx if self.use_transformer_encoder else None, memory=memory)
         out = out[:, 1:, :] if self.early_guide else out
         ep["lang_cap"] = self.model.generator(out)
         good = (target_ious > -1).squeeze(1)
@@ -435,14 +441,20 @@ class TransformerDecoderModel(nn.Module):
         n_good = good.sum()
         ep["pred_ious"] = (target_ious.squeeze(1) * good).sum() / n_good.clamp(min=1)
         ep["good_bbox_masks"] = good
-        if self.check_relation:
-            rp = self.relation_proposal  # Linear-ReLU-Linear-ReLU-Linear (:319-326)
-            sa = self.model.encoder.layers[-1].self_attn
+        if self.check_relation and "relation_pred" not in ep:
+            self._relation_head(ep)
+        return ep
+
+    def _relation_head(self, ep):
+        """relation_pred (B,K,K,9) from the last encoder layer's attention map and values (:392-397)."""
+        from . import streams
+        rp = self.relation_proposal  # Linear-ReLU-Linear-ReLU-Linear (:319-326)
+        sa = self.model.encoder.layers[-1].self_attn
+        with streams.branch("relation", sa.attn):
             # feature (P (x) V) + first Linear + ReLU in one kernel: the (B,K,K,128) feature is never formed
             hid = ops().relation_layer1(sa.attn, sa.value, rp[0].weight, rp[0].bias)
             hid = F.relu(tall_linear(hid, rp[2]))
             ep["relation_pred"] = tall_linear(hid, rp[4])
-        return ep
 
     def forward_eval(self, ep, use_cache=True):
         """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder AND the whole

@@ -27,11 +27,12 @@ def _run(mode, steps=6):
     model = _make()
     # tiny learning rate: the first Adam steps at the reference's 1e-3 are chaotic on a repeated synthetic batch
     # (two identical eager runs drift apart by 3 % after three steps), which would hide real discrepancies
-    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=(mode == "graph-split"))
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=(mode == "graph-split"),
+                 multi_stream=not mode.endswith("single-stream"))
     data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
-    nxt = data if mode in ("prefetch", "graph", "graph-split") else None
+    nxt = data if mode in ("prefetch", "graph", "graph-split", "graph-single-stream") else None
     losses = [float(tr.step(data, next_data=nxt))]
-    if mode in ("graph", "graph-split"):
+    if mode in ("graph", "graph-split", "graph-single-stream"):
         # enable_graph runs `warmup` real optimizer steps itself; account for them
         assert tr.enable_graph(data, warmup=2), tr.graph_error
         losses += [None, None]
@@ -48,8 +49,13 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
     c = _run("prefetch")
     g = _run("graph")
     gs = _run("graph-split")  # what a multi-rank run does: fwd+bwd in the graph, gradient packing + Adam outside
+    # every mode above runs the relation head and the detection losses as side-stream branches
+    # (spacap3d_amd/streams.py); these two keep the whole step on one stream
+    e1 = _run("eager-single-stream")
+    g1 = _run("graph-single-stream")
     assert all(x == x and abs(x) < 1e5 for x in a)
-    for name, other in (("eager-again", b), ("prefetch", c), ("graph", g), ("graph-split", gs)):
+    for name, other in (("eager-again", b), ("prefetch", c), ("graph", g), ("graph-split", gs),
+                        ("eager-single-stream", e1), ("graph-single-stream", g1)):
         for i, (x, y) in enumerate(zip(a, other)):
             if y is None:
                 continue
