@@ -308,6 +308,25 @@ int spacap_dropout_add_fwd_f32(const float *res, const float *y, long n, float p
 int spacap_dropout_add_bwd_f32(const float *g, long n, float p, uint64_t seed, const uint64_t *seed_dev,
                                float *out, spacap_stream_t stream);
 
+/* ---- input pipeline: subsample + augmentation + vote labels of HBM-resident scenes (csrc/scene_pipeline.hip) -----
+ * Replaces the per-point numpy work of ScannetReferenceDataset.__getitem__ (lib/dataset.py:335-338, 364-404, 415-428).
+ * scene_feat / scene_ins / scene_isobj: DEVICE arrays of B device pointers (one per batch item) to that item's scene:
+ * f32 [N_b, C] rows (xyz first), i32 [N_b] instance labels, u8 [N_b] "semantic label is one of the 37 object classes".
+ * choices i32 [B,P]: sampled row per output point.  aug f64 [B, spacap_scene_aug_doubles()]: flip_x, flip_y (non-zero
+ * = flip), Rx[9], Ry[9], Rz[9] (row-major rotation matrices applied as x' = x R^T in that order), t[3]; float64
+ * arithmetic rounded to float32 after every step, as numpy does.  Outputs pc f32 [B,P,C], ins_out i32 [B,P],
+ * isobj_out u8 [B,P]. */
+int spacap_scene_aug_doubles(void);
+int spacap_scene_sample_augment_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
+                                    const uint8_t *const *scene_isobj, const int32_t *choices, const double *aug,
+                                    int B, int P, int C, int augment, float *pc, int32_t *ins_out,
+                                    uint8_t *isobj_out, spacap_stream_t stream);
+/* votes f32 [B,P,9] (three identical votes: centre of the instance's sampled points - point), vmask i64 [B,P]; an
+ * instance votes iff isobj of its FIRST sampled point is set; instance labels outside [0, max_inst) never vote. */
+size_t spacap_scene_votes_workspace_bytes(int B, int max_inst);
+int spacap_scene_votes_f32(const float *pc, const int32_t *ins, const uint8_t *isobj, int B, int P, int C,
+                           int max_inst, void *workspace, float *votes, int64_t *vmask, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
