@@ -315,12 +315,13 @@ int spacap_dropout_add_bwd_f32(const float *g, long n, float p, uint64_t seed, c
  * choices i32 [B,P]: sampled row per output point.  aug f64 [B, spacap_scene_aug_doubles()]: flip_x, flip_y (non-zero
  * = flip), Rx[9], Ry[9], Rz[9] (row-major rotation matrices applied as x' = x R^T in that order), t[3]; float64
  * arithmetic rounded to float32 after every step, as numpy does.  Outputs pc f32 [B,P,C], ins_out i32 [B,P],
- * isobj_out u8 [B,P]. */
+ * isobj_out u8 [B,P]; optionally (scene_color: B pointers to f32 [N_b,3], color_out f32 [B,P,3]) the sampled colours. */
 int spacap_scene_aug_doubles(void);
 int spacap_scene_sample_augment_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
-                                    const uint8_t *const *scene_isobj, const int32_t *choices, const double *aug,
-                                    int B, int P, int C, int augment, float *pc, int32_t *ins_out,
-                                    uint8_t *isobj_out, spacap_stream_t stream);
+                                    const uint8_t *const *scene_isobj, const float *const *scene_color,
+                                    const int32_t *choices, const double *aug, int B, int P, int C, int augment,
+                                    float *pc, int32_t *ins_out, uint8_t *isobj_out, float *color_out,
+                                    spacap_stream_t stream);
 /* votes f32 [B,P,9] (three identical votes: centre of the instance's sampled points - point), vmask i64 [B,P]; an
  * instance votes iff isobj of its FIRST sampled point is set; instance labels outside [0, max_inst) never vote. */
 size_t spacap_scene_votes_workspace_bytes(int B, int max_inst);

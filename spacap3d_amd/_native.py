@@ -73,7 +73,7 @@ SIGNATURES = {
     "spacap_dropout_add_fwd_f32": (_i, [_p, _p, _l, _f, _u64, _p, _p, _p]),
     "spacap_dropout_add_bwd_f32": (_i, [_p, _l, _f, _u64, _p, _p, _p]),
     "spacap_scene_aug_doubles": (_i, []),
-    "spacap_scene_sample_augment_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "spacap_scene_sample_augment_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_scene_votes_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "spacap_scene_votes_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),

@@ -21,10 +21,11 @@ constexpr int AUG_DOUBLES = 32;  // per item: flip_x, flip_y, Rx[9], Ry[9], Rz[9
 __global__ __launch_bounds__(256) void scene_sample_augment_kernel(const float *const *__restrict__ scene_feat,
                                                                    const int32_t *const *__restrict__ scene_ins,
                                                                    const uint8_t *const *__restrict__ scene_isobj,
+                                                                   const float *const *__restrict__ scene_color,
                                                                    const int32_t *__restrict__ choices,
                                                                    const double *__restrict__ aug, int P, int C, int augment,
                                                                    float *__restrict__ pc, int32_t *__restrict__ ins_out,
-                                                                   uint8_t *__restrict__ isobj_out) {
+                                                                   uint8_t *__restrict__ isobj_out, float *__restrict__ color_out) {
   const int b = blockIdx.y;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
@@ -53,6 +54,11 @@ __global__ __launch_bounds__(256) void scene_sample_augment_kernel(const float *
   for (int c = 3; c < C; ++c) o[c] = row[c];
   ins_out[(size_t)b * P + p] = scene_ins[b][src];
   isobj_out[(size_t)b * P + p] = scene_isobj[b][src];
+  if (color_out) {
+    const float *c = scene_color[b] + (size_t)src * 3;
+    float *co = color_out + ((size_t)b * P + p) * 3;
+    co[0] = c[0], co[1] = c[1], co[2] = c[2];
+  }
 }
 
 __device__ __forceinline__ int f2key(float f) {  // order-preserving float -> signed int
@@ -120,16 +126,17 @@ __global__ __launch_bounds__(256) void votes_write_kernel(const float *__restric
 extern "C" int spacap_scene_aug_doubles(void) { return AUG_DOUBLES; }
 
 extern "C" int spacap_scene_sample_augment_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
-                                               const uint8_t *const *scene_isobj, const int32_t *choices,
-                                               const double *aug, int B, int P, int C, int augment, float *pc,
-                                               int32_t *ins_out, uint8_t *isobj_out, spacap_stream_t stream) {
+                                               const uint8_t *const *scene_isobj, const float *const *scene_color,
+                                               const int32_t *choices, const double *aug, int B, int P, int C,
+                                               int augment, float *pc, int32_t *ins_out, uint8_t *isobj_out,
+                                               float *color_out, spacap_stream_t stream) {
   const char *what = "spacap_scene_sample_augment_f32";
   SPACAP_REQUIRE(B >= 0 && P >= 0 && C >= 3 && B <= 65535, "%s: bad sizes", what);
   if (B == 0 || P == 0) return SPACAP_OK;
-  SPACAP_REQUIRE(scene_feat && scene_ins && scene_isobj && choices && pc && ins_out && isobj_out && (aug || !augment),
-                 "%s: null pointer", what);
+  SPACAP_REQUIRE(scene_feat && scene_ins && scene_isobj && choices && pc && ins_out && isobj_out && (aug || !augment) &&
+                     (scene_color || !color_out), "%s: null pointer", what);
   hipLaunchKernelGGL(scene_sample_augment_kernel, dim3((P + 255) / 256, B), dim3(256), 0, spacap::as_stream(stream), scene_feat,
-                     scene_ins, scene_isobj, choices, aug, P, C, augment, pc, ins_out, isobj_out);
+                     scene_ins, scene_isobj, scene_color, choices, aug, P, C, augment, pc, ins_out, isobj_out, color_out);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -53,9 +53,11 @@ class DeviceSceneDataset:
             lut[int(k)] = int(v)
         self.nyu2class = lut.to(self.device)
         self.raw2label = dict(raw2label or {})
-        self.scenes = {}
-        self.items = []
         self.C = 3 + (3 if use_normal else 0) + (1 if use_height else 0)
+        self._scene_index = {}
+        self._scenes = []       # per scene: the big per-vertex tensors (kept alive here; the kernels get pointers)
+        self._items = []
+        self._tables = None     # stacked per-scene / per-item label tables, built lazily by _finalize()
 
     # ---- loading -----------------------------------------------------------------------------------------------
     def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None):
@@ -68,21 +70,26 @@ class DeviceSceneDataset:
         if self.use_height:   # one-off per scene: the 0.99th percentile of z is the floor (:330-333)
             floor = np.percentile(pc[:, 2], 0.99)
             pc = np.concatenate([pc, np.expand_dims(pc[:, 2] - floor, 1)], 1)
-        d = self.device
-        bbox = np.asarray(bbox, dtype=np.float64)
-        sc = {
-            "feat": torch.as_tensor(np.ascontiguousarray(pc, dtype=np.float32)).to(d),
-            "color": torch.as_tensor(np.ascontiguousarray(vert[:, 3:6])).to(d),
-            "ins": torch.as_tensor(np.asarray(ins).astype(np.int32)).to(d),
-            "isobj": torch.as_tensor(np.isin(np.asarray(sem), NYU40IDS).astype(np.uint8)).to(d),
-            "bbox": torch.as_tensor(bbox).to(d),
-            "n": vert.shape[0], "flip_parity": {"x": 0, "y": 0},
-        }
         if int(np.asarray(ins).max(initial=0)) >= self.max_instances:
             raise ValueError("instance label >= max_instances")
-        for a, r in (("x", x), ("y", y), ("z", z)):
-            sc[a] = None if r is None else torch.as_tensor(np.asarray(r).astype(np.int64)).to(d)
-        self.scenes[scene_id] = sc
+        d = self.device
+        bbox = np.asarray(bbox, dtype=np.float64)
+        nb = min(bbox.shape[0], MAX_NUM_OBJ)
+        box8 = np.zeros((MAX_NUM_OBJ, 8))
+        box8[:nb] = bbox[:nb]
+        rel = np.zeros((3, MAX_NUM_OBJ, MAX_NUM_OBJ), dtype=np.int64)
+        for k, r in enumerate((x, y, z)):
+            if r is not None:
+                rel[k, :nb, :nb] = np.asarray(r)[:nb, :nb]
+        self._scene_index[scene_id] = len(self._scenes)
+        self._scenes.append({
+            "feat": torch.as_tensor(np.ascontiguousarray(pc, dtype=np.float32)).to(d),
+            "color": torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(d),
+            "ins": torch.as_tensor(np.asarray(ins).astype(np.int32)).to(d),
+            "isobj": torch.as_tensor(np.isin(np.asarray(sem), NYU40IDS).astype(np.uint8)).to(d),
+            "n": int(vert.shape[0]), "nb": nb, "box8": box8, "rel": rel,
+        })
+        self._tables = None
 
     def load_scene(self, root, scene_id):
         """``<root>/<scene_id>_aligned_vert.npy`` etc., the layout of CONF.PATH.SCANNET_DATA."""
@@ -94,115 +101,167 @@ class DeviceSceneDataset:
     def add_item(self, scene_id, object_id, object_name="", lang_feat=None, lang_ids=None, lang_len=None, ann_id=0):
         """One ScanRefer description (an entry of ``self.scanrefer``).  ``lang_feat`` (32,300) / ``lang_ids`` (32,)
         are the arrays ``_tranform_des`` builds (lib/dataset.py:76-118)."""
-        d = self.device
-        it = {"scene_id": scene_id, "object_id": int(object_id), "object_cat": int(self.raw2label.get(object_name, 17)),
-              "ann_id": int(ann_id)}
+        it = {"scene": self._scene_index[scene_id], "object_id": int(object_id),
+              "object_cat": int(self.raw2label.get(object_name, 17)), "ann_id": int(ann_id)}
         if lang_ids is not None:
-            ids = torch.as_tensor(np.asarray(lang_ids).astype(np.int64))
-            it["lang_ids"] = ids.to(d)
-            it["lang_label"] = torch.cat([torch.ones(1, dtype=torch.int64), ids]).to(d)   # :479-481
-            it["lang_feat"] = torch.as_tensor(np.asarray(lang_feat, dtype=np.float32)).to(d)
+            it["lang_ids"] = np.asarray(lang_ids).astype(np.int64)
+            it["lang_feat"] = np.asarray(lang_feat, dtype=np.float32)
             it["lang_len"] = int(lang_len)
-        self.items.append(it)
-        return len(self.items) - 1
+        self._items.append(it)
+        self._tables = None
+        return len(self._items) - 1
 
     def __len__(self):
-        return len(self.items)
+        return len(self._items)
+
+    def _finalize(self):
+        if self._tables is not None:
+            return self._tables
+        d = self.device
+        sc, it = self._scenes, self._items
+        t = {
+            "box8": torch.as_tensor(np.stack([s["box8"] for s in sc])).to(d),                       # (S,128,8) f64
+            "nb": torch.tensor([s["nb"] for s in sc], dtype=torch.int64, device=d),
+            "rel": torch.as_tensor(np.stack([s["rel"] for s in sc])).to(d),                         # (S,3,128,128) i64
+            "nvert": torch.tensor([s["n"] for s in sc], dtype=torch.int64, device=d),
+            "ptrs": torch.tensor([[s[k].data_ptr() for k in ("feat", "ins", "isobj", "color")] for s in sc],
+                                 dtype=torch.int64, device=d),                                     # (S,4)
+            "parity": torch.zeros(len(sc), 2, dtype=torch.int64, device=d),                         # flip state (x, y)
+            "item_scene": torch.tensor([i["scene"] for i in it], dtype=torch.int64, device=d),
+            "item_object": torch.tensor([i["object_id"] for i in it], dtype=torch.float64, device=d),
+            "item_cat": torch.tensor([i["object_cat"] for i in it], dtype=torch.int64, device=d),
+            "item_ann": torch.tensor([i["ann_id"] for i in it], dtype=torch.int64, device=d),
+            "nmax": max(s["n"] for s in sc),
+        }
+        if it and all("lang_ids" in i for i in it):
+            ids = torch.as_tensor(np.stack([i["lang_ids"] for i in it]))
+            t["lang_ids"] = ids.to(d)
+            t["lang_label"] = torch.cat([torch.ones(len(it), 1, dtype=torch.int64), ids], 1).to(d)   # :479-481
+            t["lang_feat"] = torch.as_tensor(np.stack([i["lang_feat"] for i in it])).to(d)
+            t["lang_len"] = torch.tensor([i["lang_len"] for i in it], dtype=torch.int64, device=d)
+        old = getattr(self, "_parity_keep", None)
+        if old is not None and old.shape == t["parity"].shape:
+            t["parity"] = old
+        self._tables = t
+        return t
 
     # ---- randomness --------------------------------------------------------------------------------------------
     def draw(self, indices, generator=None):
-        """Per-item random numbers in the reference's roles (lib/dataset.py:335, 366-401, 233-235)."""
-        g = generator
-        out = []
-        for i in indices:
-            n = self.scenes[self.items[i]["scene_id"]]["n"]
-            if n < self.num_points:
-                ch = torch.randint(0, n, (self.num_points,), generator=g)
-            else:
-                ch = torch.randperm(n, generator=g)[:self.num_points]
-            d = {"choices": ch}
-            if self.augment:
-                r = torch.rand(5, generator=g, dtype=torch.float64)
-                d["flip_x"], d["flip_y"] = bool(r[0] > 0.5), bool(r[1] > 0.5)
-                d["angles"] = [float(v) * math.pi / 18 - math.pi / 36 for v in r[2:5]]
-                d["translation"] = [(-0.5 + 0.001 * int(v)) for v in torch.randint(0, 1001, (3,), generator=g)]
-            out.append(d)
-        return out
+        """Per-item random numbers in the reference's roles (lib/dataset.py:335, 366-401, 233-235), drawn ON THE
+        DEVICE without a host sync: (choices (B,P) int32, aug (B,32) float64) for ``batch(..., draws=...)``.
+        ``generator``: a torch.Generator of this device (None = the default one)."""
+        t = self._finalize()
+        dev, P = self.device, self.num_points
+        idx = torch.as_tensor(list(indices), dtype=torch.int64, device=dev)
+        B = idx.numel()
+        n = t["nvert"][t["item_scene"][idx]]                                              # (B,)
+        u = torch.rand(B, t["nmax"], device=dev, generator=generator)
+        u = torch.where(torch.arange(t["nmax"], device=dev)[None, :] < n[:, None], u, torch.full_like(u, 2.0))
+        order = u.argsort(1)
+        if t["nmax"] >= P:
+            without = order[:, :P]
+        else:
+            without = torch.zeros(B, P, dtype=torch.int64, device=dev)
+        with_rep = (torch.rand(B, P, device=dev, generator=generator, dtype=torch.float64) * n[:, None]).long()
+        with_rep = torch.minimum(with_rep, n[:, None] - 1)
+        choices = torch.where((n < P)[:, None], with_rep, without).to(torch.int32)       # replace iff N < P (:35)
+        aug = torch.zeros(B, int(lib.spacap_scene_aug_doubles()), dtype=torch.float64, device=dev)
+        if self.augment:
+            r = torch.rand(B, 5, device=dev, generator=generator, dtype=torch.float64)
+            aug[:, 0:2] = (r[:, 0:2] > 0.5).double()
+            ang = r[:, 2:5] * math.pi / 18 - math.pi / 36
+            c, s = torch.cos(ang), torch.sin(ang)
+            one, zero = torch.ones(B, dtype=torch.float64, device=dev), torch.zeros(B, dtype=torch.float64, device=dev)
+            Rx = torch.stack([one, zero, zero, zero, c[:, 0], -s[:, 0], zero, s[:, 0], c[:, 0]], 1)
+            Ry = torch.stack([c[:, 1], zero, s[:, 1], zero, one, zero, -s[:, 1], zero, c[:, 1]], 1)
+            Rz = torch.stack([c[:, 2], -s[:, 2], zero, s[:, 2], c[:, 2], zero, zero, zero, one], 1)
+            aug[:, 2:11], aug[:, 11:20], aug[:, 20:29] = Rx, Ry, Rz
+            k = torch.randint(0, 1001, (B, 3), device=dev, generator=generator)
+            aug[:, 29:32] = -0.5 + k.double() * 0.001                                       # np.arange(-0.5, 0.501, 0.001)[k]
+        return choices, aug
+
+    def _host_draws(self, draws):
+        """Draws given as the reference's numbers (dicts: choices, flip_x, flip_y, angles, translation) -> tensors."""
+        dev = self.device
+        nd = int(lib.spacap_scene_aug_doubles())
+        aug_h = np.zeros((len(draws), nd))
+        if self.augment:
+            for b, d in enumerate(draws):
+                aug_h[b, 0], aug_h[b, 1] = float(d["flip_x"]), float(d["flip_y"])
+                for r, (ax, t) in enumerate(zip("xyz", d["angles"])):
+                    aug_h[b, 2 + 9 * r: 11 + 9 * r] = np.array(_rot(ax, t), dtype=np.float64).reshape(-1)
+                aug_h[b, 29:32] = d["translation"]
+        choices = torch.as_tensor(np.stack([np.asarray(d["choices"]) for d in draws]).astype(np.int32)).to(dev)
+        return choices, torch.as_tensor(aug_h).to(dev)
 
     # ---- batch -------------------------------------------------------------------------------------------------
-    def batch(self, indices, draws=None):
-        """data_dict of device tensors for the descriptions ``indices`` (processed in order, as the reference's
-        single-process loader would: the relation-label flip state advances item by item)."""
+    def batch(self, indices, draws=None, generator=None):
+        """data_dict of device tensors for the descriptions ``indices`` (in order, as the reference's single-process
+        loader would process them: the relation-label flip state advances item by item).  ``draws``: None (drawn on
+        the device), the (choices, aug) pair of ``draw()``, or a list of per-item dicts with the reference's numbers.
+        No host synchronisation when the draws come from the device."""
+        t = self._finalize()
+        dev, P, C = self.device, self.num_points, self.C
         if draws is None:
-            draws = self.draw(indices)
-        dev, P, B, C = self.device, self.num_points, len(indices), self.C
-        items = [self.items[i] for i in indices]
-        scs = [self.scenes[it["scene_id"]] for it in items]
+            choices, aug = self.draw(indices, generator)
+        elif isinstance(draws, (tuple,)):
+            choices, aug = draws
+        else:
+            choices, aug = self._host_draws(draws)
+        idx = torch.as_tensor(list(indices), dtype=torch.int64, device=dev)
+        B = idx.numel()
+        sidx = t["item_scene"][idx]
         st = torch.cuda.current_stream(dev).cuda_stream
         f64 = dict(dtype=torch.float64, device=dev)
-        nd = int(lib.spacap_scene_aug_doubles())
-        aug_h = np.zeros((B, nd))
-        rots = []
-        for b, d in enumerate(draws):
-            if self.augment:
-                Rs = [np.array(_rot(ax, t), dtype=np.float64) for ax, t in zip("xyz", d["angles"])]
-                aug_h[b, 0], aug_h[b, 1] = float(d["flip_x"]), float(d["flip_y"])
-                for r, R in enumerate(Rs):
-                    aug_h[b, 2 + 9 * r: 11 + 9 * r] = R.reshape(-1)
-                aug_h[b, 29:32] = d["translation"]
-                rots.append(Rs)
         with torch.cuda.device(dev):
-            choices = torch.stack([torch.as_tensor(np.asarray(d["choices"])).to(torch.int32) for d in draws]).to(dev)
-            aug = torch.as_tensor(aug_h).to(dev)
-            ptrs = torch.tensor([[sc[k].data_ptr() for sc in scs] for k in ("feat", "ins", "isobj")], dtype=torch.int64).to(dev)
+            ptrs = t["ptrs"][sidx].t().contiguous()                                        # (4,B) device pointers
             pc = torch.empty(B, P, C, dtype=torch.float32, device=dev)
             ins = torch.empty(B, P, dtype=torch.int32, device=dev)
             isobj = torch.empty(B, P, dtype=torch.uint8, device=dev)
+            color = torch.empty(B, P, 3, dtype=torch.float32, device=dev)
             check(lib.spacap_scene_sample_augment_f32(ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(),
-                                                      choices.data_ptr(), aug.data_ptr(), B, P, C, int(self.augment),
-                                                      pc.data_ptr(), ins.data_ptr(), isobj.data_ptr(), st),
-                  "spacap_scene_sample_augment_f32")
+                                                      ptrs[3].data_ptr(), choices.data_ptr(), aug.data_ptr(), B, P, C,
+                                                      int(self.augment), pc.data_ptr(), ins.data_ptr(), isobj.data_ptr(),
+                                                      color.data_ptr(), st), "spacap_scene_sample_augment_f32")
             votes = torch.empty(B, P, 9, dtype=torch.float32, device=dev)
             vmask = torch.empty(B, P, dtype=torch.int64, device=dev)
             ws = torch.empty(int(lib.spacap_scene_votes_workspace_bytes(B, self.max_instances)), dtype=torch.uint8, device=dev)
             check(lib.spacap_scene_votes_f32(pc.data_ptr(), ins.data_ptr(), isobj.data_ptr(), B, P, C, self.max_instances,
                                              ws.data_ptr(), votes.data_ptr(), vmask.data_ptr(), st), "spacap_scene_votes_f32")
-            # ---- boxes and labels: <= 128 rows per item, float64 like the reference ----
-            tb = torch.zeros(B, MAX_NUM_OBJ, 6, **f64)
-            box8 = torch.zeros(B, MAX_NUM_OBJ, 8, **f64)
-            mask = torch.zeros(B, MAX_NUM_OBJ, **f64)
-            nbs = []
-            for b, sc in enumerate(scs):
-                nb = min(sc["bbox"].shape[0], MAX_NUM_OBJ)
-                nbs.append(nb)
-                tb[b, :nb] = sc["bbox"][:nb, 0:6]
-                box8[b, :nb] = sc["bbox"][:nb]
-                mask[b, :nb] = 1
-            rel = {}
+            # ---- boxes and labels: <= 128 rows per item, float64 like the reference, batched over the items ----
+            box8 = t["box8"][sidx]                                                         # (B,128,8)
+            nb = t["nb"][sidx]
+            valid = torch.arange(MAX_NUM_OBJ, device=dev)[None, :] < nb[:, None]
+            mask = valid.double()
+            tb = box8[:, :, 0:6].clone()
             if self.augment:
-                flip = torch.as_tensor(aug_h[:, 0:2]).to(dev)
-                tb[:, :, 0] = torch.where(flip[:, 0:1] != 0, -1 * tb[:, :, 0], tb[:, :, 0])
-                tb[:, :, 1] = torch.where(flip[:, 1:2] != 0, -1 * tb[:, :, 1], tb[:, :, 1])
-                R = torch.as_tensor(np.stack([np.stack(r) for r in rots])).to(dev)       # (B,3,3,3)
+                fx, fy = aug[:, 0:1] != 0, aug[:, 1:2] != 0
+                tb[:, :, 0] = torch.where(fx, -1 * tb[:, :, 0], tb[:, :, 0])
+                tb[:, :, 1] = torch.where(fy, -1 * tb[:, :, 1], tb[:, :, 1])
                 for r, ax in enumerate("xyz"):
-                    tb = _rotate_aligned_boxes(tb, R[:, r], ax)
+                    tb = _rotate_aligned_boxes(tb, aug[:, 2 + 9 * r: 11 + 9 * r].view(B, 3, 3), ax)
                 tb[:, :, 0:3] += aug[:, None, 29:32]
+            rel = {}
             if self.use_relation:
-                for a in "xyz":
-                    out = torch.zeros(B, MAX_NUM_OBJ, MAX_NUM_OBJ, dtype=torch.int64, device=dev)
-                    for b, (sc, d) in enumerate(zip(scs, draws)):
-                        if a in "xy" and self.augment and d[f"flip_{a}"]:
-                            sc["flip_parity"][a] ^= 1       # the reference mutates its cached matrix (:369-384)
-                        m = sc[a]
-                        if a in "xy" and sc["flip_parity"][a]:
-                            m = torch.where(m == 0, 2, torch.where(m == 2, 0, m))
-                        out[b, :nbs[b], :nbs[b]] = m[:nbs[b], :nbs[b]]
-                    rel[f"{a}_label"] = out
-            valid = mask > 0
-            cls = torch.where(valid, self.nyu2class[box8[:, :, 6].long().clamp(0, 63)], torch.zeros_like(mask, dtype=torch.int64))
+                # The reference swaps classes 0 <-> 2 of the scene's CACHED matrix on every x / y flip (:369-384):
+                # item b sees the scene's parity after its own flip and after the flips of earlier items of the batch.
+                flips = (aug[:, 0:2] != 0).double() if self.augment else torch.zeros(B, 2, **f64)
+                same = (sidx[:, None] == sidx[None, :]) & (torch.arange(B, device=dev)[:, None] >= torch.arange(B, device=dev)[None, :])
+                par = (t["parity"][sidx].double() + same.double() @ flips).long() % 2              # (B,2)
+                t["parity"] = (t["parity"] + torch.zeros_like(t["parity"]).index_add_(0, sidx, flips.long())) % 2
+                self._parity_keep = t["parity"]
+                region = valid[:, :, None] & valid[:, None, :]
+                R3 = t["rel"][sidx]                                                        # (B,3,128,128)
+                for k, a in enumerate("xyz"):
+                    m = R3[:, k]
+                    if k < 2:
+                        sw = torch.where(m == 0, 2, torch.where(m == 2, 0, m))
+                        m = torch.where((par[:, k] == 1)[:, None, None] & region, sw, m)
+                    rel[f"{a}_label"] = m
+            cls = torch.where(valid, self.nyu2class[box8[:, :, 6].long().clamp(0, 63)], torch.zeros_like(nb)[:, None])
             size_res = torch.where(valid.unsqueeze(-1), tb[:, :, 3:6] - self.mean_size[cls], torch.zeros_like(tb[:, :, 3:6]))
             ids = torch.where(valid, box8[:, :, 7], torch.zeros_like(mask))
-            obj = torch.tensor([it["object_id"] for it in items], **f64)
+            obj = t["item_object"][idx]
             ref_box = (valid & (ids == obj[:, None])).long()
             # the reference's loop keeps the LAST matching box (:437-449)
             last = (ref_box * torch.arange(1, MAX_NUM_OBJ + 1, device=dev)).argmax(1)
@@ -214,30 +273,25 @@ class DeviceSceneDataset:
             size = self.mean_size[cls] + size_res
             corners = torch.where(valid[:, :, None, None], _corners(tb[:, :, 0:3], size), torch.zeros(B, MAX_NUM_OBJ, 8, 3, **f64))
             ref_corners = torch.where(has[:, None, None], corners[bi, last], torch.zeros(B, 8, 3, **f64))
-            color = torch.stack([sc["color"][c.long()] for sc, c in zip(scs, choices)])
         d = {
             "point_clouds": pc, "pcl_color": color, "center_label": tb[:, :, 0:3].float(),
             "heading_class_label": torch.zeros(B, MAX_NUM_OBJ, dtype=torch.int64, device=dev),
             "heading_residual_label": torch.zeros(B, MAX_NUM_OBJ, dtype=torch.float32, device=dev),
             "size_class_label": cls, "size_residual_label": size_res.float(),
-            "num_bbox": torch.tensor(nbs, dtype=torch.int64, device=dev), "sem_cls_label": cls.clone(),
+            "num_bbox": nb, "sem_cls_label": cls.clone(),
             "scene_object_ids": ids.long(), "box_label_mask": mask.float(), "box_label_mask_int": mask.long(),
             "vote_label": votes, "vote_label_mask": vmask, "ref_box_label": ref_box, "ref_center_label": ref_center.float(),
             "ref_heading_class_label": torch.zeros(B, dtype=torch.int64, device=dev),
             "ref_heading_residual_label": torch.zeros(B, dtype=torch.int64, device=dev),
             "ref_size_class_label": ref_cls, "ref_size_residual_label": ref_res.float(),
             "ref_box_corner_label": ref_corners, "gt_box_corner_label": corners, "gt_box_masks": mask.long(),
-            "gt_box_object_ids": ids.long(), "object_id": obj.long(),
-            "object_cat": torch.tensor([it["object_cat"] for it in items], dtype=torch.int64, device=dev),
-            "ann_id": torch.tensor([it["ann_id"] for it in items], dtype=torch.int64, device=dev),
-            "dataset_idx": torch.tensor(list(indices), dtype=torch.int64, device=dev),
+            "gt_box_object_ids": ids.long(), "object_id": obj.long(), "object_cat": t["item_cat"][idx],
+            "ann_id": t["item_ann"][idx], "dataset_idx": idx,
         }
         d.update(rel)
-        if all("lang_ids" in it for it in items):
-            d["lang_feat"] = torch.stack([it["lang_feat"] for it in items])
-            d["lang_ids"] = torch.stack([it["lang_ids"] for it in items])
-            d["lang_label"] = torch.stack([it["lang_label"] for it in items])
-            d["lang_len"] = torch.tensor([it["lang_len"] for it in items], dtype=torch.int64, device=dev)
+        if "lang_ids" in t:
+            for k in ("lang_feat", "lang_ids", "lang_label", "lang_len"):
+                d[k] = t[k][idx]
         return d
 
 

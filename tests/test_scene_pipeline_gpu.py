@@ -88,8 +88,13 @@ def test_own_draws_feed_a_training_step():
     from spacap3d_amd.spacapnet import build_default
     fx, _ = load_fixture()
     ds = _device_dataset(fx, 2048)
-    g = torch.Generator().manual_seed(0)
+    g = torch.Generator(device=DEV).manual_seed(0)
     d = ds.batch([0, 3], ds.draw([0, 3], generator=g))
+    ch, aug = ds.draw([0, 3, 1], generator=g)
+    n = torch.tensor([fx[f"{str(fx['item_scene'][i])}/vert"].shape[0] for i in (0, 3, 1)], device=DEV)
+    assert ch.shape == (3, 2048) and bool((ch >= 0).all()) and bool((ch < n[:, None]).all())
+    assert len(torch.unique(ch[0])) == 2048                       # 5000 vertices >= 2048 points: no repeats
+    assert bool((aug[:, 2] == 1).all()) and bool((aug[:, 29:32].abs() <= 0.5).all())
     assert d["point_clouds"].dtype == torch.float32 and d["vote_label_mask"].dtype == torch.int64
     assert 0 < int(d["vote_label_mask"].sum()) < 2 * 2048
     torch.manual_seed(0)
