@@ -328,6 +328,12 @@ size_t spacap_scene_votes_workspace_bytes(int B, int max_inst);
 int spacap_scene_votes_f32(const float *pc, const int32_t *ins, const uint8_t *isobj, int B, int P, int C,
                            int max_inst, void *workspace, float *votes, int64_t *vmask, spacap_stream_t stream);
 
+/* ---- optimizer: torch.optim.Adam (scripts/train.py:262) over one flat parameter buffer, one launch ---------------
+ * g' = grad_scale*g + weight_decay*p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step (device f32, 1-based).  All f32 [n], 16-byte aligned. */
+int spacap_adam_flat_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, const float *step, float grad_scale, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

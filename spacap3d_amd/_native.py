@@ -76,6 +76,7 @@ SIGNATURES = {
     "spacap_scene_sample_augment_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_scene_votes_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "spacap_scene_votes_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),

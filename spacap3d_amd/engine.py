@@ -87,9 +87,10 @@ class Trainer:
         # bucket only when there is something to all-reduce
         self.bucket = FlatGradBucket(used, views=False)
         kw = dict(lr=self.lr, weight_decay=self.weight_decay)
-        try:
-            self.optimizer = torch.optim.Adam(used, fused=used[0].is_cuda, capturable=used[0].is_cuda, **kw)
-        except (RuntimeError, TypeError):
+        if used[0].is_cuda:
+            from .optim import FlatAdam   # one launch over a flat parameter buffer (spacap3d_amd/optim.py)
+            self.optimizer = FlatAdam(self.bucket, **kw)
+        else:
             self.optimizer = torch.optim.Adam(used, **kw)
 
     def _core(self, data_dict, with_optimizer=True):
@@ -105,9 +106,14 @@ class Trainer:
         if pc.is_cuda:
             streams.join_all(pc.device)  # side-stream branches (relation head, detection losses) re-join here
         if with_optimizer:
-            self.bucket.all_reduce_mean(force_pack=self.split_optimizer)
-            self.optimizer.step()
+            self._optimizer_step(None)
         return d["loss"].detach()
+
+    def _optimizer_step(self, sources):
+        """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket."""
+        flat = not isinstance(self.optimizer, torch.optim.Optimizer)
+        self.bucket.all_reduce_mean(sources=sources, force_pack=self.split_optimizer or flat)
+        self.optimizer.step()
 
     # -- hipGraph mode ------------------------------------------------------------------------------------------
     # One training step is ~1 900 kernel launches, most of them microseconds long (Transformer, loss); eager
@@ -148,8 +154,7 @@ class Trainer:
                 for _ in range(warmup):
                     self._core(static, self._graph_with_opt)
                     if not self._graph_with_opt:
-                        self.bucket.all_reduce_mean(force_pack=self.split_optimizer)
-                        self.optimizer.step()
+                        self._optimizer_step(None)
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             g = torch.cuda.CUDAGraph()
@@ -181,8 +186,7 @@ class Trainer:
             self.prefetch(next_data)
         self.graph.replay()
         if not self._graph_with_opt:
-            self.bucket.all_reduce_mean(sources=self._graph_grads, force_pack=self.split_optimizer)
-            self.optimizer.step()
+            self._optimizer_step(self._graph_grads)
         return self._static_loss
 
     def step(self, data_dict, next_data=None):
