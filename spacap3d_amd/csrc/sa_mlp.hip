@@ -370,49 +370,94 @@ __device__ __forceinline__ f32x4 load_dz(const float *__restrict__ dy, const uin
 }
 
 // ---- data gradient: dy_prev = (dz_k W_k) * [a_prev > 0], and the BN sums of dy_prev -----------------------------
-template <int CK, int NT, bool POOLED>
+// Same pipeline as sa_mid_fwd_kernel: the next tile's z_k (and dense dy) rows are prefetched with hand-issued loads
+// while the matrix cores work, dz is formed while staging, and the accumulators go through LDS so that the epilogue
+// (mask by relu'(bn(z_prev)), BN sums, store) reads z_prev and writes dy_prev as full rows.
+// PREFETCH: register prefetch (off for CK = 256, where it would cost the second resident workgroup).
+// ALIAS: the output tile reuses the staging buffer (one more barrier, 18 KB less LDS; CK = 256).
+template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS>
 __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
                                                        const float *__restrict__ zk, const float *__restrict__ coef,
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
                                                        const float *__restrict__ st_p, long R, float *__restrict__ dyp,
                                                        double *__restrict__ part) {
   constexpr int LD = CK + 4, KS = CK / 4, C4 = CK / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
-  extern __shared__ __attribute__((aligned(16))) float s_a[];  // [TM][LD]
+  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
+  constexpr bool DENSE_PF = PREFETCH && !POOLED;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_a = smem;                               // [TM][LD]  dz (MFMA B operand)
+  float *s_o = ALIAS ? smem : smem + TM * LD;      // [TM][LDO] output tile, row-major
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int cb = blockIdx.y * 64 * NT + w * 16 * NT;
+  const int cbb = blockIdx.y * COB, wc = w * 16 * NT, cb = cbb + wc;
   float wf[NT][KS];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wf[j][ks] = Wk[(size_t)(ks * 4 + lg) * CP + cb + 16 * j + l15];
-  const int c4 = tid % C4, r0 = tid / C4;
-  f32x4 g, k0, k1;
+  const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
+  f32x4 g, k0, k1, pm, pi, ps, pb;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const float *s = coef + (size_t)(c4 * 4 + u) * 4;
     g[u] = s[0], k0[u] = s[1], k1[u] = s[2];
+    const float *q = st_p + (size_t)(cbb + o4 * 4 + u) * 4;
+    pm[u] = q[0], pi[u] = q[1], ps[u] = q[2], pb[u] = q[3];
   }
-  f32x4 pm[NT], pi[NT], ps[NT], pb[NT], s1[NT], s2[NT];
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  const int lgS = (S > 0 && (S & (S - 1)) == 0) ? __builtin_ctz((unsigned)S) : -1;
+  const long ntiles = (R + TM - 1) / TM, nfull = R / TM;
+  f32x4 pz[PREFETCH ? NV : 1], pd[DENSE_PF ? NV : 1];
+  auto fetch = [&](long t) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float *s = st_p + (size_t)(cb + 16 * j + 4 * lg + u) * 4;
-      pm[j][u] = s[0], pi[j][u] = s[1], ps[j][u] = s[2], pb[j][u] = s[3];
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zk + (size_t)grow * CK + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pz[i]) : "v"(src) : "memory");
+      if (DENSE_PF) {
+        const float *sd = dy + (size_t)grow * CK + c4 * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pd[i]) : "v"(sd) : "memory");
+      }
     }
-    s1[j] = s2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const long ntiles = (R + TM - 1) / TM;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  };
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
     const long row0 = t * TM;
+    if (PREFETCH) {
+      if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        asm volatile("" : "+v"(pz[i]));
+        if (DENSE_PF) asm volatile("" : "+v"(pd[i]));
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int row = r0 + i * RSTEP;
+      const long grow = row0 + row;
       f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < R) a = load_dz<POOLED>(dy, arg, S, zk, row0 + row, CK, c4 * 4, g, k0, k1);
+      if (FULL || grow < R) {
+        const f32x4 z = PREFETCH ? pz[i] : ld4(zk + (size_t)grow * CK + c4 * 4);
+        f32x4 d;
+        if (POOLED) {
+          const long grp = lgS >= 0 ? (grow >> lgS) : grow / S;
+          const int sidx = (int)(grow - grp * S);
+          const f32x4 dm = ld4(dy + (size_t)grp * CK + c4 * 4);
+          const uchar4 am = *reinterpret_cast<const uchar4 *>(arg + (size_t)grp * CK + c4 * 4);
+          d[0] = am.x == sidx ? dm[0] : 0.f;
+          d[1] = am.y == sidx ? dm[1] : 0.f;
+          d[2] = am.z == sidx ? dm[2] : 0.f;
+          d[3] = am.w == sidx ? dm[3] : 0.f;
+        } else {
+          d = DENSE_PF ? pd[i] : ld4(dy + (size_t)grow * CK + c4 * 4);
+        }
+        a = g * d + k0 - k1 * z;
+      }
       st4(&s_a[row * LD + c4 * 4], a);
     }
     __syncthreads();
+    if (PREFETCH && FULL) fetch(t + gridDim.x);
     f32x4 acc[TM / 16][NT];
 #pragma unroll
     for (int mt = 0; mt < TM / 16; ++mt)
@@ -427,43 +472,65 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
         for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
       }
     }
+    if (ALIAS) __syncthreads();  // every wave is done reading dz before the output tile overwrites it
+#pragma unroll
+    for (int mt = 0; mt < TM / 16; ++mt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) st4(&s_o[(mt * 16 + l15) * LDO + wc + 16 * j + 4 * lg], acc[mt][j]);
     __syncthreads();
 #pragma unroll
-    for (int mt = 0; mt < TM / 16; ++mt) {
-      const long grow = row0 + mt * 16 + l15;
-      if (grow < R) {
+    for (int i = 0; i < NO; ++i) {
+      const int row = or0 + i * OSTEP;
+      if (FULL || row0 + row < R) {
+        const size_t o = (size_t)(row0 + row) * CP + cbb + o4 * 4;
+        const f32x4 da = ld4(&s_o[row * LDO + o4 * 4]);
+        const f32x4 z = ld4(zp + o);
+        f32x4 d;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const size_t o = (size_t)grow * CP + cb + 16 * j + 4 * lg;
-          const f32x4 z = ld4(zp + o);
-          f32x4 d;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float pre = (z[u] - pm[j][u]) * ps[j][u] + pb[j][u];
-            d[u] = pre > 0.f ? acc[mt][j][u] : 0.f;
-            s1[j][u] += d[u];
-            s2[j][u] += d[u] * ((z[u] - pm[j][u]) * pi[j][u]);
-          }
-          st4(dyp + o, d);
+        for (int u = 0; u < 4; ++u) {
+          const float pre = (z[u] - pm[u]) * ps[u] + pb[u];
+          d[u] = pre > 0.f ? da[u] : 0.f;
+          s1[u] += d[u];
+          s2[u] += d[u] * ((z[u] - pm[u]) * pi[u]);
         }
+        st4(dyp + o, d);
       }
+    }
+    if (ALIAS) __syncthreads();  // the output tile is consumed before the next tile is staged over it
+  };
+  bool pending = false;
+  if (PREFETCH && (long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  if (PREFETCH) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      asm volatile("" ::"v"(pz[i]));
+      if (DENSE_PF) asm volatile("" ::"v"(pd[i]));
     }
   }
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float a = s1[j][u], q = s2[j][u];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
-      if (l15 == 0) {
-        const int c = cb + 16 * j + 4 * lg + u;
-        part[((size_t)blockIdx.x * 2 + 0) * CP + c] = (double)a;
-        part[((size_t)blockIdx.x * 2 + 1) * CP + c] = (double)q;
-        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
-          part[((size_t)pr * 2 + 0) * CP + c] = 0.0, part[((size_t)pr * 2 + 1) * CP + c] = 0.0;
-      }
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    if (PREFETCH) {
+      fetch(nfull);
     }
+    tile(nfull, std::false_type{}, false);
+  }
+  // BN sums: this thread owns columns cbb + 4*o4 .. +3 for the rows or0 + k*OSTEP; combine the OSTEP row groups
+  __syncthreads();
+  float *s_red = smem;  // [2][OSTEP][COB]
+  st4(&s_red[(0 * OSTEP + or0) * COB + o4 * 4], s1);
+  st4(&s_red[(1 * OSTEP + or0) * COB + o4 * 4], s2);
+  __syncthreads();
+  if (tid < 2 * COB) {
+    const int k = tid / COB, c = tid % COB;
+    float a = 0.f;
+    for (int i = 0; i < OSTEP; ++i) a += s_red[(k * OSTEP + i) * COB + c];
+    part[((size_t)blockIdx.x * 2 + k) * CP + cbb + c] = (double)a;
+    for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x) part[((size_t)pr * 2 + k) * CP + cbb + c] = 0.0;
+  }
 }
 
 // ---- weight gradient: dW_k[ck, cp] = sum_r dz_k[r, ck] a_prev[r, cp]; one partial per row slab -----------------
@@ -814,18 +881,21 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   SPACAP_REQUIRE(dy && zk && coef && Wk && zp && st_p && dyp && part && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
   hipStream_t s = spacap::as_stream(stream);
-  const size_t lds = (size_t)TM * (CK + 4) * sizeof(float);
-#define DG(CKV, NTV, PV, GY)                                                                                         \
-  if (lds > 65536)                                                                                                   \
-    SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_dgrad_kernel<CKV, NTV, PV>),             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what);              \
-  static const int res = resident_blocks(sa_dgrad_kernel<CKV, NTV, PV>, lds);                                         \
-  hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV>), dim3(grid_rows(res, GY, (R + TM - 1) / TM), GY), dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part)
-  if (arg && CK == 128 && CP == 64) { DG(128, 1, true, 1); }
-  else if (arg && CK == 256 && CP == 128) { DG(256, 1, true, 2); }
-  else if (arg && CK == 128 && CP == 128) { DG(128, 2, true, 1); }
-  else if (!arg && CK == 64 && CP == 64) { DG(64, 1, false, 1); }
-  else if (!arg && CK == 128 && CP == 128) { DG(128, 2, false, 1); }
+#define DG(CKV, NTV, PV, PF, AL, GY)                                                                                 \
+  {                                                                                                                  \
+    const size_t lds = (size_t)TM * ((CKV + 4) + ((AL) ? 0 : (64 * NTV + 4))) * sizeof(float);                       \
+    if (lds > 65536)                                                                                                 \
+      SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_dgrad_kernel<CKV, NTV, PV, PF, AL>),   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what);            \
+    static const int res = resident_blocks(sa_dgrad_kernel<CKV, NTV, PV, PF, AL>, lds);                              \
+    hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV, PF, AL>), dim3(grid_rows(res, GY, (R + TM - 1) / TM), GY),     \
+                       dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part);                      \
+  }
+  if (arg && CK == 128 && CP == 64) DG(128, 1, true, true, false, 1)
+  else if (arg && CK == 256 && CP == 128) DG(256, 1, true, false, true, 2)
+  else if (arg && CK == 128 && CP == 128) DG(128, 2, true, true, false, 1)
+  else if (!arg && CK == 64 && CP == 64) DG(64, 1, false, true, false, 1)
+  else if (!arg && CK == 128 && CP == 128) DG(128, 2, false, true, false, 1)
   else SPACAP_REQUIRE(false, "%s: (CK=%d, CP=%d, pooled=%d) unsupported", what, CK, CP, arg ? 1 : 0);
 #undef DG
   SPACAP_CHECK_LAUNCH(what);
