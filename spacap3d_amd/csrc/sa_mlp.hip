@@ -562,27 +562,62 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(const float *__restrict__
 #pragma unroll
     for (int n = 0; n < NTT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long ntiles = (R + TW - 1) / TW;
+  const int lgS = (S > 0 && (S & (S - 1)) == 0) ? __builtin_ctz((unsigned)S) : -1;
+  // software pipeline: the raw operands of tile t + gridDim.x are loaded into registers while tile t is multiplied
+  f32x4 rz[NVZ], rd[NVZ], ra[NVA];
+  uchar4 rg[POOLED ? NVZ : 1];
+  int rs[POOLED ? NVZ : 1];
+  auto fetch = [&](long t) {
+    const long row0 = t * TW;
+#pragma unroll
+    for (int i = 0; i < NVZ; ++i) {
+      long grow = row0 + zr0 + i * RZ;
+      grow = grow < R ? grow : R - 1;
+      rz[i] = ld4(zk + (size_t)grow * CK + ckb0 + z4 * 4);
+      if (POOLED) {
+        const long grp = lgS >= 0 ? (grow >> lgS) : grow / S;
+        rs[i] = (int)(grow - grp * S);
+        rd[i] = ld4(dy + (size_t)grp * CK + ckb0 + z4 * 4);
+        rg[i] = *reinterpret_cast<const uchar4 *>(arg + (size_t)grp * CK + ckb0 + z4 * 4);
+      } else {
+        rd[i] = ld4(dy + (size_t)grow * CK + ckb0 + z4 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) {
+      long grow = row0 + ar0 + i * RA;
+      grow = grow < R ? grow : R - 1;
+      ra[i] = ld4(zp + (size_t)grow * CP + a4 * 4);
+    }
+  };
+  if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long row0 = t * TW;
 #pragma unroll
     for (int i = 0; i < NVZ; ++i) {
       const int row = zr0 + i * RZ;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < R) a = load_dz<POOLED>(dy, arg, S, zk, row0 + row, CK, ckb0 + z4 * 4, g, k0, k1);
+      f32x4 d = rd[i];
+      if (POOLED) {
+        d[0] = rg[i].x == rs[i] ? d[0] : 0.f;
+        d[1] = rg[i].y == rs[i] ? d[1] : 0.f;
+        d[2] = rg[i].z == rs[i] ? d[2] : 0.f;
+        d[3] = rg[i].w == rs[i] ? d[3] : 0.f;
+      }
+      f32x4 a = g * d + k0 - k1 * rz[i];
+      if (row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
       st4(&s_dz[row * LDZ + z4 * 4], a);
     }
 #pragma unroll
     for (int i = 0; i < NVA; ++i) {
       const int row = ar0 + i * RA;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < R) {
-        const f32x4 v = ld4(zp + (size_t)(row0 + row) * CP + a4 * 4);
+      f32x4 a;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = fmaxf((v[u] - pm[u]) * ps[u] + pb[u], 0.f);
-      }
+      for (int u = 0; u < 4; ++u) a[u] = fmaxf((ra[i][u] - pm[u]) * ps[u] + pb[u], 0.f);
+      if (row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
       st4(&s_a[row * LDA + a4 * 4], a);
     }
     __syncthreads();
+    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
 #pragma unroll
     for (int ks = 0; ks < TW / 4; ++ks) {
       float af[MT];
