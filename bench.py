@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="sample inside the step instead of one step ahead")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--no-streams", action="store_true", help="keep the relation head and the detection losses on the main stream")
+    ap.add_argument("--streams", action="store_true", help="run the detection losses as a side-stream branch (slower since they are fused)")
     ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
                                                  "relation head, 'caption' the whole captioner")
     ap.add_argument("--cpu-sample", type=int, default=2, help="scenes in the CPU-baseline sample")
@@ -136,7 +136,7 @@ def main():
         model.caption.check_relation = False
         model.caption.model.encoder.layers[-1].self_attn.keep_value = False
     trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"),
-                      multi_stream=not args.no_streams)
+                      multi_stream=args.streams)
     # each rank owns its own shard of scenes (seed + rank), resident in HBM before the timed region
     data = synthetic_batch(per_gpu, cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
 

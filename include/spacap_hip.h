@@ -334,6 +334,30 @@ int spacap_scene_votes_f32(const float *pc, const int32_t *ins, const uint8_t *i
 int spacap_adam_flat_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, const float *step, float grad_scale, spacap_stream_t stream);
 
+/* ---- detection losses of the training step (csrc/losses.hip) ----------------------------------------------------
+ * Replaces compute_vote_loss / compute_objectness_loss / compute_box_and_sem_cls_loss (lib/loss_helper.py:35-197,
+ * utils/nn_distance.py:32-62).  net f32 [B,K,CH] = the proposal head's output rows [objectness 2 | centre offset 3 |
+ * heading scores NH | heading residuals NH | size scores NS | size residuals NS*3 | class scores NC]; center, agg_xyz
+ * f32 [B,K,3]; gt_center f32 [B,M,3] (M <= 256); box_mask f32 [B,M]; *_label per ground-truth box; seed_xyz, vote_xyz
+ * f32 [B,NSEED,3]; seed_inds i32 [B,NSEED]; vote_label f32 [B,N,9]; vote_mask i64 [B,N].
+ * Outputs: obj_label i64 / obj_mask f32 / assignment i64 [B,K]; losses f32 [8] (vote, objectness, center, heading_cls,
+ * heading_reg, size_cls, size_reg, sem_cls); gradient numerators dnet_num [B,K,CH], dcenter_num [B,K,6], dvote_num
+ * [B,NSEED,3]; part f32 [B*(spacap_det_npart()+2)] scratch; inv_den f32 [4].  The backward turns the numerators and
+ * the upstream gradient grad_losses f32 [8] into dnet [B,K,CH], dcenter [B,K,3], dvote [B,NSEED,3]. */
+int spacap_det_npart(void);
+int spacap_det_losses_fwd_f32(const float *net, const float *center, const float *agg_xyz, const float *gt_center,
+                              const float *box_mask, const int64_t *heading_cls_label, const float *heading_res_label,
+                              const int64_t *size_cls_label, const float *size_res_label, const int64_t *sem_cls_label,
+                              const float *mean_size, const float *seed_xyz, const float *vote_xyz,
+                              const int32_t *seed_inds, const float *vote_label, const int64_t *vote_mask, int B, int K,
+                              int M, int NSEED, int N, int NH, int NS, int NC, float near_thr, float far_thr, float w0,
+                              float w1, int64_t *obj_label, float *obj_mask, int64_t *assignment, float *dnet_num,
+                              float *dcenter_num, float *dvote_num, float *part, float *losses, float *inv_den,
+                              spacap_stream_t stream);
+int spacap_det_losses_bwd_f32(const float *dnet_num, const float *dcenter_num, const float *dvote_num,
+                              const float *grad_losses, const float *inv_den, int B, int K, int NSEED, int NH, int NS,
+                              int NC, float *dnet, float *dcenter, float *dvote, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

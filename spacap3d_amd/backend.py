@@ -30,6 +30,8 @@ class HipBackend:
         self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
+        from . import fused_losses as _fl
+        self.detection_losses = _fl.detection_losses
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout
         self.dropout_add = _fd.dropout_add

@@ -1,0 +1,318 @@
+// Detection losses of the training step as three launches forward and one backward, for gfx950 (MI355X).
+//
+// Replaces lib/loss_helper.py:35-197 of the reference (compute_vote_loss, compute_objectness_loss,
+// compute_box_and_sem_cls_loss with utils/nn_distance.py:32-62): ~150 PyTorch launches forward and as many backward,
+// every one a few microseconds of latency on (B, 256) tensors.  Same arithmetic in float32 without FMA contraction
+// (this file is built with -ffp-contract=off): squared distances as ((dx^2 + dy^2) + dz^2), first minimum wins, the
+// objectness thresholds are applied to sqrt(d + 1e-6) -- the integer outputs (objectness label, assignment) are
+// therefore the ones the PyTorch composition produces.
+//
+// Forward: det_proposal_kernel (one workgroup per scene) assigns proposals to ground-truth boxes and evaluates every
+// per-proposal loss term together with the UNNORMALISED gradient of that term; det_vote_kernel does the same for the
+// vote loss; det_finalize_kernel adds the per-scene partial sums (fixed order) into the eight losses and the inverse
+// denominators.  Backward: det_scale_kernel multiplies the stored gradient numerators by (upstream gradient x inverse
+// denominator) and lays them out as d(net) (B, K, CH), d(center), d(vote_xyz).
+//
+// loss index: 0 vote, 1 objectness, 2 center, 3 heading_cls, 4 heading_reg, 5 size_cls, 6 size_reg, 7 sem_cls
+// denominators: 0: sum vote mask + 1e-6, 1: sum objectness mask + 1e-6, 2: n_obj + 1e-6, 3: sum box mask + 1e-6
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int MAXM = 256;   // ground-truth boxes per scene (the reference: 128)
+constexpr int NPARTL = 12;  // partial sums per scene: 8 loss numerators (center split in two) + 3 counts
+
+struct DetArgs {
+  // proposal head output nt (B, K, CH) = [objectness 2 | centre offset 3 | heading scores NH | heading residuals NH |
+  // size scores NS | size residuals NS*3 | class scores NC]
+  const float *net;
+  const float *center;       // (B,K,3) decoded centres
+  const float *agg_xyz;      // (B,K,3) aggregated vote positions
+  const float *gt_center;    // (B,M,3)
+  const float *box_mask;     // (B,M)
+  const int64_t *heading_cls_label, *size_cls_label, *sem_cls_label;  // (B,M)
+  const float *heading_res_label;                                     // (B,M)
+  const float *size_res_label;                                        // (B,M,3)
+  const float *mean_size;                                             // (NS,3)
+  int B, K, M, CH, NH, NS, NC;
+  float near_thr, far_thr, w0, w1, heading_scale;  // heading_scale = pi / NH
+  // outputs
+  int64_t *obj_label, *assignment;  // (B,K)
+  float *obj_mask;                  // (B,K)
+  float *dnet;                      // (B,K,CH) gradient numerators (every element written)
+  float *dcenter;                   // (B,K,6): [0:3] obj-weighted pred->gt term, [3:6] gt->pred term
+  float *part;                      // (B, NPARTL)
+};
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, const float *b) {
+  const float dx = ax - b[0], dy = ay - b[1], dz = az - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+__device__ __forceinline__ float huber1(float err, float &grad) {  // delta = 1 (lib/loss_helper.py:20-33)
+  const float a = fabsf(err), q = fminf(a, 1.0f), lin = a - q;
+  grad = fminf(fmaxf(err, -1.0f), 1.0f);
+  return 0.5f * q * q + lin;
+}
+
+// cross-entropy over C logits with stride 1; writes (softmax - onehot) * scale into g
+__device__ __forceinline__ float ce_grad(const float *s, int C, int label, float scale, float *g) {
+  float m = s[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, s[c]);
+  float l = 0.f;
+  for (int c = 0; c < C; ++c) l += expf(s[c] - m);
+  const float lse = m + logf(l);
+  for (int c = 0; c < C; ++c) g[c] = (expf(s[c] - lse) - (c == label ? 1.f : 0.f)) * scale;
+  return lse - s[label];
+}
+
+__device__ float block_sum(float v, float *s_red) {  // 256 threads, fixed order
+  const int tid = threadIdx.x;
+  v = spacap::wave_sum_f32(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+__global__ __launch_bounds__(256) void det_proposal_kernel(const DetArgs A) {
+  extern __shared__ float smem[];
+  float *s_gt = smem;                 // [M][3]
+  float *s_c = s_gt + 3 * A.M;        // [K][3] predicted centres
+  int *s_i2 = reinterpret_cast<int *>(s_c + 3 * A.K);  // [M] nearest proposal of every gt box
+  float *s_w2 = reinterpret_cast<float *>(s_i2 + A.M); // [M] box mask
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, K = A.K, M = A.M, CH = A.CH;
+  for (int i = tid; i < 3 * M; i += 256) s_gt[i] = A.gt_center[(size_t)b * M * 3 + i];
+  for (int i = tid; i < 3 * K; i += 256) s_c[i] = A.center[(size_t)b * K * 3 + i];
+  for (int j = tid; j < M; j += 256) s_w2[j] = A.box_mask[(size_t)b * M + j];
+  __syncthreads();
+  // gt -> nearest predicted centre (dist2 / idx2 of nn_distance(center, gt_center))
+  float num_c2 = 0.f, n_box = 0.f;
+  for (int j = tid; j < M; j += 256) {
+    float best = INFINITY;
+    int bi = 0;
+    for (int k = 0; k < K; ++k) {
+      const float d = sqdist(s_c[3 * k], s_c[3 * k + 1], s_c[3 * k + 2], s_gt + 3 * j);
+      if (d < best) best = d, bi = k;
+    }
+    s_i2[j] = bi;
+    num_c2 += best * s_w2[j];
+    n_box += s_w2[j];
+  }
+  __syncthreads();
+  float n_obj = 0.f, n_mask = 0.f, num_obj = 0.f, num_c1 = 0.f, num_hc = 0.f, num_hr = 0.f, num_sc = 0.f, num_sr = 0.f,
+        num_sem = 0.f;
+  const int o_hs = 5, o_hr = 5 + A.NH, o_ss = 5 + 2 * A.NH, o_sr = o_ss + A.NS, o_sem = o_sr + 3 * A.NS;
+  for (int k = tid; k < K; k += 256) {
+    const size_t bk = (size_t)b * K + k;
+    const float *ag = A.agg_xyz + bk * 3;
+    // objectness label from the aggregated vote position (lib/loss_helper.py:117-133)
+    float d1 = INFINITY;
+    int i1 = 0;
+    for (int j = 0; j < M; ++j) {
+      const float d = sqdist(ag[0], ag[1], ag[2], s_gt + 3 * j);
+      if (d < d1) d1 = d, i1 = j;
+    }
+    const float eu = sqrtf(d1 + 1e-6f);
+    const int label = eu < A.near_thr ? 1 : 0;
+    const float mask = (label || eu > A.far_thr) ? 1.f : 0.f, obj = (float)label;
+    A.obj_label[bk] = label;
+    A.obj_mask[bk] = mask;
+    A.assignment[bk] = i1;
+    n_obj += obj;
+    n_mask += mask;
+    const float *row = A.net + bk * CH;
+    float *g = A.dnet + bk * CH;
+    // objectness: weighted 2-class cross-entropy
+    num_obj += ce_grad(row, 2, label, (label ? A.w1 : A.w0) * mask, g) * (label ? A.w1 : A.w0) * mask;
+    g[2] = g[3] = g[4] = 0.f;  // centre offsets: their gradient arrives through `center`
+    // centre: pred -> nearest gt, weighted by objectness
+    const float cx = s_c[3 * k], cy = s_c[3 * k + 1], cz = s_c[3 * k + 2];
+    float dc = INFINITY;
+    int ic = 0;
+    for (int j = 0; j < M; ++j) {
+      const float d = sqdist(cx, cy, cz, s_gt + 3 * j);
+      if (d < dc) dc = d, ic = j;
+    }
+    num_c1 += dc * obj;
+    float *dcn = A.dcenter + bk * 6;
+    dcn[0] = 2.f * (cx - s_gt[3 * ic]) * obj;
+    dcn[1] = 2.f * (cy - s_gt[3 * ic + 1]) * obj;
+    dcn[2] = 2.f * (cz - s_gt[3 * ic + 2]) * obj;
+    float gx = 0.f, gy = 0.f, gz = 0.f;  // gt -> pred term: every gt box whose nearest proposal is k, ascending j
+    for (int j = 0; j < M; ++j)
+      if (s_i2[j] == k) {
+        gx += 2.f * (cx - s_gt[3 * j]) * s_w2[j];
+        gy += 2.f * (cy - s_gt[3 * j + 1]) * s_w2[j];
+        gz += 2.f * (cz - s_gt[3 * j + 2]) * s_w2[j];
+      }
+    dcn[3] = gx, dcn[4] = gy, dcn[5] = gz;
+    // heading
+    const size_t bj = (size_t)b * M + i1;
+    const int hl = (int)A.heading_cls_label[bj];
+    num_hc += ce_grad(row + o_hs, A.NH, hl, obj, g + o_hs) * obj;
+    float hg;
+    const float hv = huber1(row[o_hr + hl] - A.heading_res_label[bj] / A.heading_scale, hg);
+    num_hr += hv * obj;
+    for (int c = 0; c < A.NH; ++c) g[o_hr + c] = c == hl ? hg * obj : 0.f;
+    // size
+    const int sl = (int)A.size_cls_label[bj];
+    num_sc += ce_grad(row + o_ss, A.NS, sl, obj, g + o_ss) * obj;
+    float sr = 0.f;
+    for (int c = 0; c < 3 * A.NS; ++c) g[o_sr + c] = 0.f;
+    for (int d = 0; d < 3; ++d) {
+      float sg;
+      sr += huber1(row[o_sr + 3 * sl + d] - A.size_res_label[bj * 3 + d] / A.mean_size[3 * sl + d], sg);
+      g[o_sr + 3 * sl + d] = sg * obj / 3.0f;
+    }
+    num_sr += sr / 3.0f * obj;
+    // semantic class
+    num_sem += ce_grad(row + o_sem, A.NC, (int)A.sem_cls_label[bj], obj, g + o_sem) * obj;
+  }
+  float *p = A.part + (size_t)b * NPARTL;
+  const float v[NPARTL] = {0.f, num_obj, num_c1, num_c2, num_hc, num_hr, num_sc, num_sr, num_sem, n_obj, n_mask, n_box};
+#pragma unroll
+  for (int i = 1; i < NPARTL; ++i) {
+    const float s = block_sum(v[i], s_red);
+    if (tid == 0) p[i] = s;
+  }
+}
+
+// vote loss (lib/loss_helper.py:35-114): per seed the smallest L1 distance between its vote and its 3 ground-truth votes
+__global__ __launch_bounds__(256) void det_vote_kernel(const float *__restrict__ seed_xyz, const float *__restrict__ vote_xyz,
+                                                       const int32_t *__restrict__ seed_inds,
+                                                       const float *__restrict__ vote_label,
+                                                       const int64_t *__restrict__ vote_mask, int NS, int N,
+                                                       float *__restrict__ dvote, float *__restrict__ part) {
+  __shared__ float s_red[4];
+  const int b = blockIdx.x;
+  float num = 0.f, cnt = 0.f;
+  for (int s = threadIdx.x; s < NS; s += 256) {
+    const size_t bs = (size_t)b * NS + s;
+    const int p = seed_inds[bs];
+    const float m = (float)vote_mask[(size_t)b * N + p];
+    const float *vl = vote_label + ((size_t)b * N + p) * 9, *sx = seed_xyz + bs * 3, *vx = vote_xyz + bs * 3;
+    float best = INFINITY;
+    int bi = 0;
+    for (int v = 0; v < 3; ++v) {
+      const float d = (fabsf(vx[0] - (vl[3 * v] + sx[0])) + fabsf(vx[1] - (vl[3 * v + 1] + sx[1]))) +
+                      fabsf(vx[2] - (vl[3 * v + 2] + sx[2]));
+      if (d < best) best = d, bi = v;
+    }
+    num += best * m;
+    cnt += m;
+    for (int d = 0; d < 3; ++d) {
+      const float e = vx[d] - (vl[3 * bi + d] + sx[d]);
+      dvote[bs * 3 + d] = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * m;
+    }
+  }
+  const float a = block_sum(num, s_red), c = block_sum(cnt, s_red);
+  if (threadIdx.x == 0) part[(size_t)b * 2] = a, part[(size_t)b * 2 + 1] = c;
+}
+
+// losses[8], inv_den[4] from the per-scene partial sums (ascending scene order)
+__global__ void det_finalize_kernel(const float *__restrict__ part, const float *__restrict__ vpart, int B,
+                                    float *__restrict__ losses, float *__restrict__ inv_den) {
+  if (threadIdx.x != 0) return;
+  float s[NPARTL] = {0.f}, vn = 0.f, vc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    for (int i = 1; i < NPARTL; ++i) s[i] += part[(size_t)b * NPARTL + i];
+    vn += vpart[2 * b], vc += vpart[2 * b + 1];
+  }
+  const float d_vote = vc + 1e-6f, d_mask = s[10] + 1e-6f, d_obj = s[9] + 1e-6f, d_box = s[11] + 1e-6f;
+  losses[0] = vn / d_vote;
+  losses[1] = s[1] / d_mask;
+  losses[2] = s[2] / d_obj + s[3] / d_box;
+  losses[3] = s[4] / d_obj;
+  losses[4] = s[5] / d_obj;
+  losses[5] = s[6] / d_obj;
+  losses[6] = s[7] / d_obj;
+  losses[7] = s[8] / d_obj;
+  inv_den[0] = 1.f / d_vote, inv_den[1] = 1.f / d_mask, inv_den[2] = 1.f / d_obj, inv_den[3] = 1.f / d_box;
+}
+
+// gradients = numerators x upstream gradient of the owning loss x inverse denominator
+__global__ __launch_bounds__(256) void det_scale_kernel(const float *__restrict__ dnet_n, const float *__restrict__ dcen_n,
+                                                        const float *__restrict__ dvote_n, const float *__restrict__ gout,
+                                                        const float *__restrict__ inv_den, long rows, int CH, int NH, int NS,
+                                                        long nvote, float *__restrict__ dnet, float *__restrict__ dcenter,
+                                                        float *__restrict__ dvote) {
+  const float g_obj = gout[1] * inv_den[1], g_hc = gout[3] * inv_den[2], g_hr = gout[4] * inv_den[2],
+              g_sc = gout[5] * inv_den[2], g_sr = gout[6] * inv_den[2], g_sem = gout[7] * inv_den[2];
+  const float g_c1 = gout[2] * inv_den[2], g_c2 = gout[2] * inv_den[3], g_v = gout[0] * inv_den[0];
+  const int o_hr = 5 + NH, o_ss = 5 + 2 * NH, o_sr = o_ss + NS, o_sem = o_sr + 3 * NS;
+  const long n_net = rows * CH, n_cen = rows * 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_net + n_cen + nvote; i += (long)gridDim.x * 256) {
+    if (i < n_net) {
+      const int c = (int)(i % CH);
+      const float s = c < 2 ? g_obj : c < 5 ? 0.f : c < o_hr ? g_hc : c < o_ss ? g_hr : c < o_sr ? g_sc : c < o_sem ? g_sr : g_sem;
+      dnet[i] = dnet_n[i] * s;
+    } else if (i < n_net + n_cen) {
+      const long j = i - n_net, r = j / 3;
+      const int d = (int)(j % 3);
+      dcenter[j] = dcen_n[r * 6 + d] * g_c1 + dcen_n[r * 6 + 3 + d] * g_c2;
+    } else {
+      const long j = i - n_net - n_cen;
+      dvote[j] = dvote_n[j] * g_v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int spacap_det_npart(void) { return NPARTL; }
+
+extern "C" int spacap_det_losses_fwd_f32(
+    const float *net, const float *center, const float *agg_xyz, const float *gt_center, const float *box_mask,
+    const int64_t *heading_cls_label, const float *heading_res_label, const int64_t *size_cls_label,
+    const float *size_res_label, const int64_t *sem_cls_label, const float *mean_size, const float *seed_xyz,
+    const float *vote_xyz, const int32_t *seed_inds, const float *vote_label, const int64_t *vote_mask, int B, int K,
+    int M, int NSEED, int N, int NH, int NS, int NC, float near_thr, float far_thr, float w0, float w1,
+    int64_t *obj_label, float *obj_mask, int64_t *assignment, float *dnet_num, float *dcenter_num, float *dvote_num,
+    float *part, float *losses, float *inv_den, spacap_stream_t stream) {
+  const char *what = "spacap_det_losses_fwd_f32";
+  SPACAP_REQUIRE(B >= 1 && K >= 1 && M >= 1 && M <= MAXM && NSEED >= 1 && NH >= 1 && NS >= 1 && NC >= 1 && B <= 65535,
+                 "%s: bad sizes", what);
+  SPACAP_REQUIRE(net && center && agg_xyz && gt_center && box_mask && heading_cls_label && heading_res_label &&
+                     size_cls_label && size_res_label && sem_cls_label && mean_size && seed_xyz && vote_xyz && seed_inds &&
+                     vote_label && vote_mask && obj_label && obj_mask && assignment && dnet_num && dcenter_num &&
+                     dvote_num && part && losses && inv_den, "%s: null pointer", what);
+  DetArgs A;
+  A.net = net; A.center = center; A.agg_xyz = agg_xyz; A.gt_center = gt_center; A.box_mask = box_mask;
+  A.heading_cls_label = heading_cls_label; A.size_cls_label = size_cls_label; A.sem_cls_label = sem_cls_label;
+  A.heading_res_label = heading_res_label; A.size_res_label = size_res_label; A.mean_size = mean_size;
+  A.B = B; A.K = K; A.M = M; A.NH = NH; A.NS = NS; A.NC = NC; A.CH = 5 + 2 * NH + 4 * NS + NC;
+  A.near_thr = near_thr; A.far_thr = far_thr; A.w0 = w0; A.w1 = w1; A.heading_scale = (float)(M_PI / NH);
+  A.obj_label = obj_label; A.assignment = assignment; A.obj_mask = obj_mask; A.dnet = dnet_num; A.dcenter = dcenter_num;
+  A.part = part;
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t lds = sizeof(float) * (3 * (size_t)M + 3 * (size_t)K + 2 * (size_t)M);
+  SPACAP_REQUIRE(lds <= 60000, "%s: K=%d too large", what, K);
+  hipLaunchKernelGGL(det_proposal_kernel, dim3(B), dim3(256), lds, s, A);
+  float *vpart = part + (size_t)B * NPARTL;
+  hipLaunchKernelGGL(det_vote_kernel, dim3(B), dim3(256), 0, s, seed_xyz, vote_xyz, seed_inds, vote_label, vote_mask, NSEED, N,
+                     dvote_num, vpart);
+  hipLaunchKernelGGL(det_finalize_kernel, dim3(1), dim3(64), 0, s, part, vpart, B, losses, inv_den);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_det_losses_bwd_f32(const float *dnet_num, const float *dcenter_num, const float *dvote_num,
+                                         const float *grad_losses, const float *inv_den, int B, int K, int NSEED, int NH,
+                                         int NS, int NC, float *dnet, float *dcenter, float *dvote,
+                                         spacap_stream_t stream) {
+  const char *what = "spacap_det_losses_bwd_f32";
+  SPACAP_REQUIRE(dnet_num && dcenter_num && dvote_num && grad_losses && inv_den && dnet && dcenter && dvote && B >= 1 && K >= 1,
+                 "%s: bad arguments", what);
+  const int CH = 5 + 2 * NH + 4 * NS + NC;
+  const long rows = (long)B * K, nvote = (long)B * NSEED * 3, total = rows * CH + rows * 3 + nvote;
+  long g = (total + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(det_scale_kernel, dim3((unsigned)g), dim3(256), 0, spacap::as_stream(stream), dnet_num, dcenter_num,
+                     dvote_num, grad_losses, inv_den, rows, CH, NH, NS, nvote, dnet, dcenter, dvote);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

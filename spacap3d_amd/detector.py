@@ -175,6 +175,7 @@ class ProposalModule(nn.Module):
         size_residuals_normalized = nt[:, :, 5 + NH * 2 + NS:5 + NH * 2 + NS * 4].view(B, P, NS, 3)
         sem_cls_scores = nt[:, :, 5 + NH * 2 + NS * 4:]
         msa = self.mean_size_f32.unsqueeze(0).unsqueeze(0)
+        data_dict["_proposal_net"] = nt   # the raw rows: the fused detection losses read / differentiate them directly
         data_dict["objectness_scores"] = objectness_scores
         data_dict["center"] = center
         data_dict["heading_scores"] = heading_scores

@@ -14,7 +14,7 @@ from .loss_helper import get_scene_cap_loss, start_detection_losses
 
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = True):
+                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = False):
         self.model = model
         self.mean_size_arr = mean_size_arr
         self.use_relation = use_relation
@@ -30,7 +30,8 @@ class Trainer:
         self._graph_grads = None
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
-        # independent branches of the step (relation head, detection losses) on side streams: spacap3d_amd/streams.py
+        # independent branches of the step (relation head, detection losses) on side streams (spacap3d_amd/streams.py);
+        # off by default: with the detection losses fused into four launches the single-stream graph is faster
         self.multi_stream = multi_stream
         broadcast_parameters(model)
 

@@ -1,0 +1,80 @@
+"""Vote / objectness / box / class losses as one autograd op on libspacap_hip.so (csrc/losses.hip).
+
+Counterpart of ``compute_vote_loss``, ``compute_objectness_loss`` and ``compute_box_and_sem_cls_loss``
+(lib/loss_helper.py:35-197) -- about 300 tiny PyTorch launches forward + backward -- as three launches forward and
+one backward.  The unfused composition in ``spacap3d_amd/loss_helper.py`` is the specification; the tests require both
+to agree on the eight loss values, the integer labels (bit-exact) and every gradient.
+"""
+import torch
+from torch.autograd import Function
+
+from ._native import check, lib
+
+
+class DetectionLosses(Function):
+    """(net (B,K,CH), center (B,K,3), vote_xyz (B,NSEED,3), <non-differentiable inputs>) ->
+    (losses (8,), objectness_label (B,K) i64, objectness_mask (B,K) f32, object_assignment (B,K) i64)."""
+
+    @staticmethod
+    def forward(ctx, net, center, vote_xyz, agg_xyz, gt_center, box_mask, heading_cls_label, heading_res_label,
+                size_cls_label, size_res_label, sem_cls_label, mean_size, seed_xyz, seed_inds, vote_label, vote_mask,
+                NH, NS, near_thr, far_thr, w0, w1):
+        dev = net.device
+        net, center, vote_xyz = net.contiguous(), center.contiguous(), vote_xyz.contiguous()
+        B, K, CH = net.shape
+        M, NSEED, N = gt_center.shape[1], seed_xyz.shape[1], vote_label.shape[1]
+        NC = CH - 5 - 2 * NH - 4 * NS
+        f32 = dict(dtype=torch.float32, device=dev)
+        c = lambda t: t.contiguous()
+        with torch.cuda.device(dev):
+            obj_label = torch.empty(B, K, dtype=torch.int64, device=dev)
+            assignment = torch.empty(B, K, dtype=torch.int64, device=dev)
+            obj_mask = torch.empty(B, K, **f32)
+            dnet_n = torch.empty(B, K, CH, **f32)
+            dcen_n = torch.empty(B, K, 6, **f32)
+            dvote_n = torch.empty(B, NSEED, 3, **f32)
+            part = torch.empty(B * (int(lib.spacap_det_npart()) + 2), **f32)
+            losses = torch.empty(8, **f32)
+            inv_den = torch.empty(4, **f32)
+            args = [c(agg_xyz), c(gt_center[:, :, 0:3]), c(box_mask), c(heading_cls_label), c(heading_res_label),
+                    c(size_cls_label), c(size_res_label), c(sem_cls_label), c(mean_size), c(seed_xyz)]
+            si, vl, vm = c(seed_inds.to(torch.int32)), c(vote_label), c(vote_mask)
+            check(lib.spacap_det_losses_fwd_f32(
+                net.data_ptr(), center.data_ptr(), *[a.data_ptr() for a in args], vote_xyz.data_ptr(), si.data_ptr(),
+                vl.data_ptr(), vm.data_ptr(), B, K, M, NSEED, N, int(NH), int(NS), int(NC), float(near_thr), float(far_thr),
+                float(w0), float(w1), obj_label.data_ptr(), obj_mask.data_ptr(), assignment.data_ptr(), dnet_n.data_ptr(),
+                dcen_n.data_ptr(), dvote_n.data_ptr(), part.data_ptr(), losses.data_ptr(), inv_den.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream), "spacap_det_losses_fwd_f32")
+        ctx.save_for_backward(dnet_n, dcen_n, dvote_n, inv_den)
+        ctx.meta = (B, K, NSEED, int(NH), int(NS), int(NC))
+        ctx.mark_non_differentiable(obj_label, obj_mask, assignment)
+        return losses, obj_label, obj_mask, assignment
+
+    @staticmethod
+    def backward(ctx, g_losses, _a, _b, _c):
+        dnet_n, dcen_n, dvote_n, inv_den = ctx.saved_tensors
+        B, K, NSEED, NH, NS, NC = ctx.meta
+        dev = dnet_n.device
+        g = g_losses.contiguous()
+        with torch.cuda.device(dev):
+            dnet = torch.empty_like(dnet_n)
+            dcenter = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+            dvote = torch.empty_like(dvote_n)
+            check(lib.spacap_det_losses_bwd_f32(dnet_n.data_ptr(), dcen_n.data_ptr(), dvote_n.data_ptr(), g.data_ptr(),
+                                                inv_den.data_ptr(), B, K, NSEED, NH, NS, NC, dnet.data_ptr(),
+                                                dcenter.data_ptr(), dvote.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream), "spacap_det_losses_bwd_f32")
+        return (dnet, dcenter, dvote) + (None,) * 19
+
+
+def detection_losses(d, num_heading_bin, num_size_cluster, mean_size_f32, near_thr, far_thr, w):
+    """The 12-tuple ``loss_helper.start_detection_losses`` stores, from the fused op.  ``d`` must hold the proposal
+    head's raw output rows ``_proposal_net`` (B,K,CH) next to the decoded entries."""
+    losses, label, mask, oa = DetectionLosses.apply(
+        d["_proposal_net"], d["center"], d["vote_xyz"], d["aggregated_vote_xyz"], d["center_label"], d["box_label_mask"],
+        d["heading_class_label"], d["heading_residual_label"], d["size_class_label"], d["size_residual_label"],
+        d["sem_cls_label"], mean_size_f32, d["seed_xyz"], d["seed_inds"], d["vote_label"], d["vote_label_mask"],
+        num_heading_bin, num_size_cluster, near_thr, far_thr, w[0], w[1])
+    vote, objn, center, hcls, hreg, scls, sreg, sem = losses.unbind(0)
+    box = center + 0.1 * hcls + hreg + 0.1 * scls + sreg
+    return vote, objn, label, mask, oa, center, hcls, hreg, scls, sreg, sem, box

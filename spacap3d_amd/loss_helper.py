@@ -173,6 +173,18 @@ def start_detection_losses(d, num_heading_bin=1, num_size_cluster=18, mean_size_
     calls this right after the proposal module so that the ~300 tiny launches run beside the Transformer -- and
     joined in ``get_scene_cap_loss``."""
     from . import streams
+    from .backend import ops
+    fused = getattr(ops(), "detection_losses", None) if d["seed_xyz"].is_cuda else None
+    if (fused is not None and "_proposal_net" in d and d["vote_xyz"].shape[1] == d["seed_xyz"].shape[1]
+            and d["center_label"].shape[1] <= 256):
+        # one autograd op on the HIP library (fused_losses.py): 3 launches forward, 1 backward
+        msa = _const(("msa", id(mean_size_arr)), d["seed_xyz"].device,
+                     lambda: torch.as_tensor(mean_size_arr, dtype=torch.float32).clone())
+        with streams.branch("detection_loss", d["seed_xyz"]):
+            t = fused(d, num_heading_bin, num_size_cluster, msa, NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS)
+        d["object_assignment"], d["objectness_label"] = t[4], t[2]
+        d["_detection_losses"] = t
+        return
     with streams.branch("detection_loss", d["seed_xyz"]):
         vote_loss = compute_vote_loss(d)
         objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)

@@ -22,7 +22,9 @@ import torch
 import os
 
 _enabled = False
-# Measured on MI355X (cfg2, hipGraph replay): the detection-loss branch gains 0.16 ms / step; the relation-head
+# Measured on MI355X (cfg2, hipGraph replay): the detection-loss branch gained 0.16 ms / step while those losses were
+# ~300 tiny launches and LOSES 0.3 ms now that they are four (fused_losses.py), so the engine leaves branches off by
+# default (Trainer(multi_stream=True) / bench.py --streams turn them on); the relation-head
 # branch LOSES 0.7 ms (its HBM-bound kernels fill every CU and the decoder's tiny kernels queue behind them), so
 # it stays on the main stream unless asked for (SPACAP_BRANCHES=relation,detection_loss).
 _only = set(os.environ.get("SPACAP_BRANCHES", "detection_loss").split(","))

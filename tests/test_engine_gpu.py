@@ -28,11 +28,11 @@ def _run(mode, steps=6):
     # tiny learning rate: the first Adam steps at the reference's 1e-3 are chaotic on a repeated synthetic batch
     # (two identical eager runs drift apart by 3 % after three steps), which would hide real discrepancies
     tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=(mode == "graph-split"),
-                 multi_stream=not mode.endswith("single-stream"))
+                 multi_stream=mode.endswith("side-stream"))
     data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
-    nxt = data if mode in ("prefetch", "graph", "graph-split", "graph-single-stream") else None
+    nxt = data if mode in ("prefetch", "graph", "graph-split", "graph-side-stream") else None
     losses = [float(tr.step(data, next_data=nxt))]
-    if mode in ("graph", "graph-split", "graph-single-stream"):
+    if mode in ("graph", "graph-split", "graph-side-stream"):
         # enable_graph runs `warmup` real optimizer steps itself; account for them
         assert tr.enable_graph(data, warmup=2), tr.graph_error
         losses += [None, None]
@@ -49,13 +49,12 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
     c = _run("prefetch")
     g = _run("graph")
     gs = _run("graph-split")  # what a multi-rank run does: fwd+bwd in the graph, gradient packing + Adam outside
-    # every mode above runs the relation head and the detection losses as side-stream branches
-    # (spacap3d_amd/streams.py); these two keep the whole step on one stream
-    e1 = _run("eager-single-stream")
-    g1 = _run("graph-single-stream")
+    # the detection losses as a side-stream branch (spacap3d_amd/streams.py; optional, off by default)
+    e1 = _run("eager-side-stream")
+    g1 = _run("graph-side-stream")
     assert all(x == x and abs(x) < 1e5 for x in a)
     for name, other in (("eager-again", b), ("prefetch", c), ("graph", g), ("graph-split", gs),
-                        ("eager-single-stream", e1), ("graph-single-stream", g1)):
+                        ("eager-side-stream", e1), ("graph-side-stream", g1)):
         for i, (x, y) in enumerate(zip(a, other)):
             if y is None:
                 continue
@@ -85,3 +84,58 @@ def test_flat_adam_matches_torch_adam():
         ref.step()
         for p, q in zip(pa, pb):
             assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (step, float((p - q).abs().max()))
+
+
+def test_fused_detection_losses_match_the_torch_composition():
+    """csrc/losses.hip (3 launches forward, 1 backward) against the op-by-op composition of
+    spacap3d_amd/loss_helper.py (= lib/loss_helper.py:35-197): eight loss values, integer labels bit-exact, gradients
+    w.r.t. the proposal head output, the centres and the votes."""
+    from spacap3d_amd import backend
+    from spacap3d_amd.engine import synthetic_batch
+    from spacap3d_amd.loss_helper import start_detection_losses
+    from spacap3d_amd.spacapnet import build_default
+    torch.manual_seed(1)
+    model = build_default(vocab_size=200, num_proposal=256, N=1, d_ff=64).to(DEV).train()
+    data = synthetic_batch(3, 8192, DEV, seed=5, vocab=200)
+    hip = backend.ops()
+    saved = hip.detection_losses
+    msa = S.mean_size_arr().numpy()
+    results = []
+    for fused in (True, False):
+        torch.manual_seed(2)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        d = model.backbone_net(dict(data))
+        xyz, feats = d["fp2_xyz"], d["fp2_features"]
+        d["seed_inds"], d["seed_xyz"], d["seed_features"] = d["fp2_inds"], xyz, feats
+        vx, vf = model.vgen(xyz, feats)
+        vf = vf.div(torch.norm(vf, p=2, dim=1).unsqueeze(1))
+        vx = vx.detach().requires_grad_(True)
+        d["vote_xyz"], d["vote_features"] = vx, vf
+        d = model.proposal(vx, vf.detach(), d)
+        net = d["_proposal_net"].detach().requires_grad_(True)
+        # rebuild the decoded views from the leaf so both paths differentiate w.r.t. the same tensors
+        model.proposal.decode_scores(net.transpose(2, 1), d)
+        cen = d["center"].detach().requires_grad_(True)
+        d["center"] = cen
+        net2 = d["_proposal_net"]
+        try:
+            hip.detection_losses = saved if fused else None
+            start_detection_losses(d, S.NUM_HEADING_BIN, S.NUM_SIZE_CLUSTER, msa)
+        finally:
+            hip.detection_losses = saved
+        t = d["_detection_losses"]
+        losses = torch.stack([t[0], t[1], t[5], t[6], t[7], t[8], t[9], t[10]])
+        w = torch.tensor([1.0, 0.5, 1.0, 0.1, 1.0, 0.1, 1.0, 0.1], device=DEV)
+        (losses * w).sum().backward()
+        gnet = net.grad if net.grad is not None else torch.zeros_like(net)
+        results.append((losses.detach(), t[2], t[3], t[4], gnet.clone(), cen.grad.clone(), vx.grad.clone()))
+    (la, laba, maska, oaa, gna, gca, gva), (lb, labb, maskb, oab, gnb, gcb, gvb) = results
+    assert torch.equal(laba, labb) and torch.equal(maska, maskb) and torch.equal(oaa, oab)
+    assert 0 < int(laba.sum()) < laba.numel()
+    assert torch.allclose(la, lb, rtol=2e-5, atol=1e-6), (la, lb)
+    for name, a, b in (("dnet", gna, gnb), ("dcenter", gca, gcb), ("dvote", gva, gvb)):
+        scale = float(b.abs().max())
+        assert scale > 1e-6, name
+        assert float((a - b).abs().max()) / scale < 2e-5, (name, float((a - b).abs().max()), scale)
