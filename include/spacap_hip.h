@@ -358,6 +358,19 @@ int spacap_det_losses_bwd_f32(const float *dnet_num, const float *dcenter_num, c
                               const float *grad_losses, const float *inv_den, int B, int K, int NSEED, int NH, int NS,
                               int NC, float *dnet, float *dcenter, float *dvote, spacap_stream_t stream);
 
+/* Relation loss (lib/loss_helper.py:240-289).  pred f32 [B,K,K,9] = [x 3 | y 3 | z 3 logits]; assignment, obj_label
+ * i64 [B,K]; box_mask_int i64 [B,M]; x/y/z_label i64 [B,M,M].  A pair (i,j) counts iff both proposals are positive and
+ * assigned to valid boxes; its label is rel_a[b, assignment_i, assignment_j].  out f32 [7] = x,y,z loss, x,y,z accuracy,
+ * 1/max(#pairs,1); dnum f32 [B,K,K,9] gradient numerators; part f32 [spacap_rel_loss_nparts(B,K)*7] scratch.  The
+ * backward maps the upstream gradients of the three losses (grad_losses f32 [3]) to dpred. */
+long spacap_rel_loss_nparts(int B, int K);
+int spacap_rel_loss_fwd_f32(const float *pred, const int64_t *assignment, const int64_t *box_mask_int,
+                            const int64_t *obj_label, const int64_t *x_label, const int64_t *y_label,
+                            const int64_t *z_label, int B, int K, int M, float *dnum, float *part, float *out,
+                            spacap_stream_t stream);
+int spacap_rel_loss_bwd_f32(const float *dnum, const float *grad_losses, const float *out, int B, int K, float *dpred,
+                            spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

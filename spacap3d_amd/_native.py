@@ -79,6 +79,9 @@ SIGNATURES = {
     "spacap_det_npart": (_i, []),
     "spacap_det_losses_fwd_f32": (_i, [_p] * 16 + [_i] * 8 + [_f] * 4 + [_p] * 9 + [_p]),
     "spacap_det_losses_bwd_f32": (_i, [_p] * 5 + [_i] * 6 + [_p] * 3 + [_p]),
+    "spacap_rel_loss_nparts": (_l, [_i, _i]),
+    "spacap_rel_loss_fwd_f32": (_i, [_p] * 7 + [_i] * 3 + [_p] * 3 + [_p]),
+    "spacap_rel_loss_bwd_f32": (_i, [_p] * 3 + [_i] * 2 + [_p, _p]),
     "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),

@@ -32,6 +32,7 @@ class HipBackend:
         self.bn_relu_train = _fbn.bn_relu_train
         from . import fused_losses as _fl
         self.detection_losses = _fl.detection_losses
+        self.relation_losses = _fl.relation_losses
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout
         self.dropout_add = _fd.dropout_add

@@ -261,7 +261,115 @@ __global__ __launch_bounds__(256) void det_scale_kernel(const float *__restrict_
   }
 }
 
+
+// ---- relation loss (lib/loss_helper.py:240-289): 3-way cross-entropy per axis on the selected proposal pairs -----
+// pred (B,K,K,9) = [x 3 | y 3 | z 3]; pair (i, j) counts iff both proposals are positive and assigned to valid boxes;
+// label_a = rel_a[b, oa_i, oa_j].  One launch: losses / accuracies (per-workgroup partial sums) and the unnormalised
+// gradient W * (softmax - onehot); rel_finalize_kernel adds the partials in order.
+constexpr int REL_THREADS = 256;
+
+__global__ __launch_bounds__(REL_THREADS) void rel_loss_kernel(const float *__restrict__ pred, const int64_t *__restrict__ oa,
+                                                              const int64_t *__restrict__ box_mask_int,
+                                                              const int64_t *__restrict__ obj_label,
+                                                              const int64_t *__restrict__ xl, const int64_t *__restrict__ yl,
+                                                              const int64_t *__restrict__ zl, int K, int M,
+                                                              float *__restrict__ dnum, float *__restrict__ part) {
+  __shared__ float s_red[4];
+  const int b = blockIdx.y;
+  const long pair = (long)blockIdx.x * REL_THREADS + threadIdx.x;
+  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // loss x,y,z, acc x,y,z, sum W
+  if (pair < (long)K * K) {
+    const int i = (int)(pair / K), j = (int)(pair - (long)i * K);
+    const int oi = (int)oa[(size_t)b * K + i], oj = (int)oa[(size_t)b * K + j];
+    const bool si = (box_mask_int[(size_t)b * M + oi] & obj_label[(size_t)b * K + i]) != 0;
+    const bool sj = (box_mask_int[(size_t)b * M + oj] & obj_label[(size_t)b * K + j]) != 0;
+    const float W = (si && sj) ? 1.f : 0.f;
+    const size_t o = ((size_t)b * K * K + pair) * 9;
+    const size_t lo = ((size_t)b * M + oi) * M + oj;
+    const int lab[3] = {(int)xl[lo], (int)yl[lo], (int)zl[lo]};
+    v[6] = W;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float s0 = pred[o + 3 * a], s1 = pred[o + 3 * a + 1], s2 = pred[o + 3 * a + 2];
+      const float m = fmaxf(s0, fmaxf(s1, s2));
+      const float e0 = expf(s0 - m), e1 = expf(s1 - m), e2 = expf(s2 - m);
+      const float lse = m + logf((e0 + e1) + e2);
+      const float sl = lab[a] == 0 ? s0 : (lab[a] == 1 ? s1 : s2);
+      const int am = (s0 >= s1 && s0 >= s2) ? 0 : (s1 >= s2 ? 1 : 2);  // first maximum
+      v[a] = (lse - sl) * W;
+      v[3 + a] = (am == lab[a] ? 1.f : 0.f) * W;
+      dnum[o + 3 * a] = (expf(s0 - lse) - (lab[a] == 0 ? 1.f : 0.f)) * W;
+      dnum[o + 3 * a + 1] = (expf(s1 - lse) - (lab[a] == 1 ? 1.f : 0.f)) * W;
+      dnum[o + 3 * a + 2] = (expf(s2 - lse) - (lab[a] == 2 ? 1.f : 0.f)) * W;
+    }
+  }
+  float *p = part + ((size_t)b * gridDim.x + blockIdx.x) * 7;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    const float t = block_sum(v[q], s_red);
+    if (threadIdx.x == 0) p[q] = t;
+  }
+}
+
+// out[0..2] losses x,y,z; out[3..5] accuracies; out[6] = 1 / n
+__global__ __launch_bounds__(256) void rel_finalize_kernel(const float *__restrict__ part, int nparts, float *__restrict__ out) {
+  __shared__ float s_red[4];
+  float v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int p = threadIdx.x; p < nparts; p += 256)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) v[q] += part[(size_t)p * 7 + q];
+  float t[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) t[q] = block_sum(v[q], s_red);
+  if (threadIdx.x == 0) {
+    const float n = fmaxf(t[6], 1.0f);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) out[q] = t[q] / n;
+    out[6] = 1.0f / n;
+  }
+}
+
+__global__ __launch_bounds__(256) void rel_scale_kernel(const float *__restrict__ dnum, const float *__restrict__ gout,
+                                                        const float *__restrict__ out, long n, float *__restrict__ dpred) {
+  const float inv = out[6], g0 = gout[0] * inv, g1 = gout[1] * inv, g2 = gout[2] * inv;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % 9);
+    dpred[i] = dnum[i] * (c < 3 ? g0 : (c < 6 ? g1 : g2));
+  }
+}
+
 }  // namespace
+
+extern "C" long spacap_rel_loss_nparts(int B, int K) { return (long)B * (((long)K * K + REL_THREADS - 1) / REL_THREADS); }
+
+extern "C" int spacap_rel_loss_fwd_f32(const float *pred, const int64_t *assignment, const int64_t *box_mask_int,
+                                       const int64_t *obj_label, const int64_t *x_label, const int64_t *y_label,
+                                       const int64_t *z_label, int B, int K, int M, float *dnum, float *part, float *out,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_rel_loss_fwd_f32";
+  SPACAP_REQUIRE(B >= 1 && K >= 1 && M >= 1 && B <= 65535, "%s: bad sizes", what);
+  SPACAP_REQUIRE(pred && assignment && box_mask_int && obj_label && x_label && y_label && z_label && dnum && part && out,
+                 "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const unsigned gx = (unsigned)(((long)K * K + REL_THREADS - 1) / REL_THREADS);
+  hipLaunchKernelGGL(rel_loss_kernel, dim3(gx, B), dim3(REL_THREADS), 0, s, pred, assignment, box_mask_int, obj_label, x_label,
+                     y_label, z_label, K, M, dnum, part);
+  hipLaunchKernelGGL(rel_finalize_kernel, dim3(1), dim3(256), 0, s, part, (int)(gx * B), out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_rel_loss_bwd_f32(const float *dnum, const float *grad_losses, const float *out, int B, int K,
+                                       float *dpred, spacap_stream_t stream) {
+  const char *what = "spacap_rel_loss_bwd_f32";
+  SPACAP_REQUIRE(dnum && grad_losses && out && dpred && B >= 1 && K >= 1, "%s: bad arguments", what);
+  const long n = (long)B * K * K * 9;
+  long g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(rel_scale_kernel, dim3((unsigned)g), dim3(256), 0, spacap::as_stream(stream), dnum, grad_losses, out, n, dpred);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
 
 extern "C" int spacap_det_npart(void) { return NPARTL; }
 

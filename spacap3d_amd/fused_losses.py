@@ -78,3 +78,45 @@ def detection_losses(d, num_heading_bin, num_size_cluster, mean_size_f32, near_t
     vote, objn, center, hcls, hreg, scls, sreg, sem = losses.unbind(0)
     box = center + 0.1 * hcls + hreg + 0.1 * scls + sreg
     return vote, objn, label, mask, oa, center, hcls, hreg, scls, sreg, sem, box
+
+
+class RelationLoss(Function):
+    """relation_pred (B,K,K,9) + labels -> out (7,) = (x, y, z loss, x, y, z accuracy, 1 / #pairs); differentiable in
+    the three losses w.r.t. relation_pred."""
+
+    @staticmethod
+    def forward(ctx, pred, assignment, box_mask_int, obj_label, xl, yl, zl):
+        dev = pred.device
+        pred = pred.contiguous()
+        B, K = pred.shape[0], pred.shape[1]
+        M = box_mask_int.shape[1]
+        with torch.cuda.device(dev):
+            dnum = torch.empty_like(pred)
+            part = torch.empty(int(lib.spacap_rel_loss_nparts(B, K)) * 7, dtype=torch.float32, device=dev)
+            out = torch.empty(7, dtype=torch.float32, device=dev)
+            check(lib.spacap_rel_loss_fwd_f32(pred.data_ptr(), assignment.contiguous().data_ptr(),
+                                              box_mask_int.contiguous().data_ptr(), obj_label.contiguous().data_ptr(),
+                                              xl.contiguous().data_ptr(), yl.contiguous().data_ptr(), zl.contiguous().data_ptr(),
+                                              B, K, M, dnum.data_ptr(), part.data_ptr(), out.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "spacap_rel_loss_fwd_f32")
+        ctx.save_for_backward(dnum, out)
+        ctx.bk = (B, K)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dnum, out = ctx.saved_tensors
+        B, K = ctx.bk
+        g3 = g[0:3].contiguous()
+        with torch.cuda.device(dnum.device):
+            dpred = torch.empty_like(dnum)
+            check(lib.spacap_rel_loss_bwd_f32(dnum.data_ptr(), g3.data_ptr(), out.data_ptr(), B, K, dpred.data_ptr(),
+                                              torch.cuda.current_stream(dnum.device).cuda_stream), "spacap_rel_loss_bwd_f32")
+        return dpred, None, None, None, None, None, None
+
+
+def relation_losses(d):
+    """{x,y,z}_loss and {x,y,z}_acc as ``loss_helper.compute_relation_loss`` returns them."""
+    out = RelationLoss.apply(d["relation_pred"], d["object_assignment"], d["box_label_mask_int"], d["objectness_label"],
+                             d["x_label"], d["y_label"], d["z_label"])
+    return {"x_loss": out[0], "y_loss": out[1], "z_loss": out[2], "x_acc": out[3], "y_acc": out[4], "z_acc": out[5]}

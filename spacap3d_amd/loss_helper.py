@@ -230,7 +230,9 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         torch.sum(objectness_mask) + 1e-6)
 
     if use_relation:
-        rel = compute_relation_loss(d)
+        from .backend import ops
+        frel = getattr(ops(), "relation_losses", None) if d["relation_pred"].is_cuda else None
+        rel = frel(d) if frel is not None else compute_relation_loss(d)
         d.update(rel)
         d["relation_loss"] = rel["y_loss"] + rel["z_loss"] + rel["x_loss"]
     else:

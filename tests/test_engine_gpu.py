@@ -139,3 +139,33 @@ def test_fused_detection_losses_match_the_torch_composition():
         scale = float(b.abs().max())
         assert scale > 1e-6, name
         assert float((a - b).abs().max()) / scale < 2e-5, (name, float((a - b).abs().max()), scale)
+
+
+def test_fused_relation_loss_matches_the_torch_composition():
+    """csrc/losses.hip rel_* kernels against loss_helper.compute_relation_loss (= lib/loss_helper.py:240-289)."""
+    from spacap3d_amd.fused_losses import relation_losses
+    from spacap3d_amd.loss_helper import compute_relation_loss
+    g = torch.Generator().manual_seed(4)
+    B, K, M = 3, 64, 128
+    d = {"relation_pred": (torch.randn(B, K, K, 9, generator=g) * 2).to(DEV),
+         "object_assignment": torch.randint(0, 20, (B, K), generator=g).to(DEV),
+         "objectness_label": torch.randint(0, 2, (B, K), generator=g).to(DEV),
+         "box_label_mask_int": (torch.arange(M)[None, :] < torch.tensor([[12], [20], [5]])).long().to(DEV)}
+    for a in "xyz":
+        d[f"{a}_label"] = torch.randint(0, 3, (B, M, M), generator=g).to(DEV)
+    d["relation_pred"][0, 0, 1, 0:3] = 1.5          # a three-way tie: argmax must pick the first class
+    pa = d["relation_pred"].clone().requires_grad_(True)
+    pb = d["relation_pred"].clone().requires_grad_(True)
+    ra = relation_losses(dict(d, relation_pred=pa))
+    rb = compute_relation_loss(dict(d, relation_pred=pb))
+    w = {"x_loss": 0.3, "y_loss": 1.0, "z_loss": 2.0}
+    sum(ra[k] * v for k, v in w.items()).backward()
+    sum(rb[k] * v for k, v in w.items()).backward()
+    for k in ("x_loss", "y_loss", "z_loss", "x_acc", "y_acc", "z_acc"):
+        assert torch.allclose(ra[k], rb[k], rtol=1e-5, atol=1e-7), (k, float(ra[k]), float(rb[k]))
+    assert float(pb.grad.abs().max()) > 0
+    assert torch.allclose(pa.grad, pb.grad, rtol=1e-4, atol=1e-9)
+    # no selected pair at all: losses 0, gradients 0 (n is clamped to 1)
+    d0 = dict(d, objectness_label=torch.zeros_like(d["objectness_label"]), relation_pred=pa.detach().clone().requires_grad_(True))
+    r0 = relation_losses(d0)
+    assert float(r0["x_loss"]) == 0.0 and float(r0["z_acc"]) == 0.0
