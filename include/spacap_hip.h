@@ -273,11 +273,12 @@ int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float 
 int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *zp, const float *st_p, long R, int CK, int CP, float *partW,
                         spacap_stream_t stream);
-/* dy1 <- dz1 in place; partW f32 [spacap_sa_nparts(), C1, 4] partial dW1 (rel x, y, z, inline feature);
+/* dy1 <- dz1 in place when write_dz != 0; partW f32 [spacap_sa_nparts(), C1, 4] partial dW1 (rel x, y, z, inline feature);
  * drel f32 [R,3] (d loss / d (xyz[idx] - new_xyz)) or NULL. */
 int spacap_sa_l1_bwd_f32(float *dy1, const float *z1, const float *coef, const float *feat, const float *xyz,
                          const float *new_xyz, const int32_t *idx, const float *W1, int ldw, float rdiv, int B,
-                         int Np, int N, int S, int C1, float *partW, float *drel, spacap_stream_t stream);
+                         int Np, int N, int S, int C1, float *partW, float *drel, int write_dz,
+                         spacap_stream_t stream);
 /* out[b,p,:] = sum over rows r = (b,e), e < E, with idx[b,e] = p of dz[r,:] in ascending r (inverted index). */
 size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E);
 int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,

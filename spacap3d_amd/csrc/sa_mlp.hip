@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void sa_l1_bwd_kernel(float *__restrict__ dy1,
                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                         const int32_t *__restrict__ idx, const float *__restrict__ W1,
                                                         int ldw, float rdiv, int Np, int N, int S, long R,
-                                                        float *__restrict__ partW, float *__restrict__ drel) {
+                                                        float *__restrict__ partW, float *__restrict__ drel, int write_dz) {
   constexpr int C4 = C1 / 4, RP = 256 / C4;
   __shared__ float s_red[4][RP][C1];
   const int tid = threadIdx.x, c4 = tid % C4, rs = tid / C4;
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void sa_l1_bwd_kernel(float *__restrict__ dy1,
       const float rx = (q[0] - c[0]) / rdiv, ry = (q[1] - c[1]) / rdiv, rz = (q[2] - c[2]) / rdiv;
       const size_t o = (size_t)r * C1 + c4 * 4;
       const f32x4 dz = g * ld4(dy1 + o) + k0 - k1 * ld4(z1 + o);
-      st4(dy1 + o, dz);
+      if (write_dz) st4(dy1 + o, dz);
       ax += dz * rx, ay += dz * ry, az += dz * rz;
       if (feat) af += dz * feat[(size_t)b * Np + p];
       if (drel) {
@@ -958,19 +958,21 @@ extern "C" int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, c
   return SPACAP_OK;
 }
 
-// dy1 is overwritten with dz1; partW [spacap_sa_nparts()][C1][4] (columns: rel x, y, z, inline feature)
+// dy1 is overwritten with dz1 when write_dz != 0 (only the rows -> source points scatter of the feature gradient
+// needs it); partW [spacap_sa_nparts()][C1][4] (columns: rel x, y, z, inline feature)
 extern "C" int spacap_sa_l1_bwd_f32(float *dy1, const float *z1, const float *coef, const float *feat, const float *xyz,
                                     const float *new_xyz, const int32_t *idx, const float *W1, int ldw, float rdiv, int B,
-                                    int Np, int N, int S, int C1, float *partW, float *drel, spacap_stream_t stream) {
+                                    int Np, int N, int S, int C1, float *partW, float *drel, int write_dz,
+                                    spacap_stream_t stream) {
   const char *what = "spacap_sa_l1_bwd_f32";
   SPACAP_REQUIRE(dy1 && z1 && coef && xyz && new_xyz && idx && W1 && partW && rdiv > 0.f, "%s: bad arguments", what);
   SPACAP_REQUIRE(C1 == 64 || C1 == 128, "%s: C1=%d unsupported", what, C1);
   const long R = (long)B * N * S;
   hipStream_t s = spacap::as_stream(stream);
   if (C1 == 64)
-    hipLaunchKernelGGL((sa_l1_bwd_kernel<64>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel);
+    hipLaunchKernelGGL((sa_l1_bwd_kernel<64>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel, write_dz);
   else
-    hipLaunchKernelGGL((sa_l1_bwd_kernel<128>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel);
+    hipLaunchKernelGGL((sa_l1_bwd_kernel<128>), dim3(NPART), dim3(256), 0, s, dy1, z1, coef, feat, xyz, new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, partW, drel, write_dz);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -127,7 +127,8 @@ class _SAMLP(Function):
             drel = torch.empty(R, 3, **f32) if ctx.need_xyz else None
             check(lib.spacap_sa_l1_bwd_f32(dy1.data_ptr(), z1.data_ptr(), coef[0].data_ptr(), _ptr(feat), xyz.data_ptr(),
                                            new_xyz.data_ptr(), idx.data_ptr(), W1.data_ptr(), W1.shape[1], ctx.rdiv, B, Np,
-                                           N, S, C1, pw1.data_ptr(), _ptr(drel), st), "spacap_sa_l1_bwd_f32")
+                                           N, S, C1, pw1.data_ptr(), _ptr(drel), int(ctx.has_Y and ctx.needs_input_grad[4]), st),
+                  "spacap_sa_l1_bwd_f32")
             dW1 = pw1.sum(0)[:, :W1.shape[1]].contiguous()
             dY = None
             if ctx.has_Y and ctx.needs_input_grad[4]:
