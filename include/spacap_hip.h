@@ -269,6 +269,14 @@ int spacap_sa_bwd_finalize_f32(const double *part, int C, long count, const floa
 int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *Wk, const float *zp, const float *st_p, long R, int CK, int CP, float *dyp,
                         double *part, spacap_stream_t stream);
+/* SA1 form of the layer-2 data gradient (first layer = 3 relative coordinates + one inline feature, CK = CP = 64):
+ * dy_prev is not written; part_l1 f32 [spacap_sa_nparts()][64*8+4] receives, per workgroup, S1[c,0:4] = sum dy_prev
+ * in_d, S3[c,0:4] = sum z_prev in_d (8 floats per channel) and S2[0:4] = sum in_d, from which
+ * dW1[c,d] = g_c S1[c,d] + k0_c S2[d] - k1_c S3[c,d] with the layer-1 coef row (g, k0, k1). */
+int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *zp,
+                           const float *st_p, const float *feat, const float *xyz, const float *new_xyz,
+                           const int32_t *idx, float rdiv, int B, int Np, int N, int S, int CK, int CP, double *part,
+                           float *part_l1, spacap_stream_t stream);
 /* partW f32 [spacap_sa_wgrad_slabs(R,CK,CP,arg != NULL), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
 int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *zp, const float *st_p, long R, int CK, int CP, float *partW,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_bwd_finalize_f32": (_i, [_p, _i, _l, _p, _p, _p, _p, _p]),
     "spacap_sa_dgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_dgrad_l1_f32": (_i, [_p] * 10 + [_f] + [_i] * 6 + [_p, _p, _p]),
     "spacap_sa_wgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _l, _i, _i, _p, _p]),
     "spacap_sa_l1_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _i, _p]),
     "spacap_sa_rows_scatter_workspace_bytes": (ctypes.c_size_t, [_i, _i, _l]),

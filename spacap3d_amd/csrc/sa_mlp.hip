@@ -375,12 +375,26 @@ __device__ __forceinline__ f32x4 load_dz(const float *__restrict__ dy, const uin
 // (mask by relu'(bn(z_prev)), BN sums, store) reads z_prev and writes dy_prev as full rows.
 // PREFETCH: register prefetch (off for CK = 256, where it would cost the second resident workgroup).
 // ALIAS: the output tile reuses the staging buffer (one more barrier, 18 KB less LDS; CK = 256).
-template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS>
+// L1 (first-layer fusion, SA1): z_prev is the first layer's pre-activation.  Its weight gradient
+//   dW1[c, d] = sum_r dz1[r, c] in_d(r),  dz1 = g dy1 + k0 - k1 z1,  in = (rel x, rel y, rel z, inline feature)
+// is linear in three sums that do not need the (not yet known) BN-backward constants g, k0, k1:
+//   S1[c,d] = sum dy1 in_d,  S2[d] = sum in_d,  S3[c,d] = sum z1 in_d   =>   dW1 = g S1 + k0 S2 - k1 S3.
+// The epilogue accumulates them from the tile it already holds, dy1 is never written and the separate first-layer
+// backward pass (read dy1 + z1: 536 MB at SA1) disappears.
+struct L1Args {
+  const float *feat, *xyz, *new_xyz;
+  const int32_t *idx;
+  float rdiv;
+  int Np, N, S;
+  float *part;  // [NPART][COB*8 + 4]
+};
+
+template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS, bool L1 = false>
 __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
                                                        const float *__restrict__ zk, const float *__restrict__ coef,
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
                                                        const float *__restrict__ st_p, long R, float *__restrict__ dyp,
-                                                       double *__restrict__ part) {
+                                                       double *__restrict__ part, const L1Args L = L1Args{}) {
   constexpr int LD = CK + 4, KS = CK / 4, C4 = CK / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
   constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
   constexpr bool DENSE_PF = PREFETCH && !POOLED;
@@ -406,6 +420,12 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
   f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
   const int lgS = (S > 0 && (S & (S - 1)) == 0) ? __builtin_ctz((unsigned)S) : -1;
   const long ntiles = (R + TM - 1) / TM, nfull = R / TM;
+  float *s_rel = smem + (ALIAS ? TM * LD : TM * LD + TM * LDO);  // [TM][4] first-layer inputs of the tile's rows (L1)
+  f32x4 q1[L1 ? 4 : 1], q3[L1 ? 4 : 1], q2 = {0.f, 0.f, 0.f, 0.f};
+  if (L1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q1[u] = q3[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f32x4 pz[PREFETCH ? NV : 1], pd[DENSE_PF ? NV : 1];
   auto fetch = [&](long t) {
 #pragma unroll
@@ -456,6 +476,19 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
       }
       st4(&s_a[row * LD + c4 * 4], a);
     }
+    if (L1 && tid < TM) {
+      f32x4 in = {0.f, 0.f, 0.f, 0.f};
+      const long grow = row0 + tid;
+      if (FULL || grow < R) {
+        const long b = grow / ((long)L.N * L.S), gi = grow / L.S;
+        const int p = L.idx[grow];
+        const float *q = L.xyz + ((size_t)b * L.Np + p) * 3, *c = L.new_xyz + (size_t)gi * 3;
+        in[0] = (q[0] - c[0]) / L.rdiv, in[1] = (q[1] - c[1]) / L.rdiv, in[2] = (q[2] - c[2]) / L.rdiv;
+        if (L.feat) in[3] = L.feat[(size_t)b * L.Np + p];
+      }
+      st4(&s_rel[tid * 4], in);
+      q2 += in;
+    }
     __syncthreads();
     if (PREFETCH && FULL) fetch(t + gridDim.x);
     f32x4 acc[TM / 16][NT];
@@ -493,7 +526,16 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
           s1[u] += d[u];
           s2[u] += d[u] * ((z[u] - pm[u]) * pi[u]);
         }
-        st4(dyp + o, d);
+        if (L1) {
+          const f32x4 in = ld4(&s_rel[row * 4]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            q1[u] += in * d[u];
+            q3[u] += in * z[u];
+          }
+        } else {
+          st4(dyp + o, d);
+        }
       }
     }
     if (ALIAS) __syncthreads();  // the output tile is consumed before the next tile is staged over it
@@ -530,6 +572,32 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     for (int i = 0; i < OSTEP; ++i) a += s_red[(k * OSTEP + i) * COB + c];
     part[((size_t)blockIdx.x * 2 + k) * CP + cbb + c] = (double)a;
     for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x) part[((size_t)pr * 2 + k) * CP + cbb + c] = 0.0;
+  }
+  if (L1) {  // S1 / S3: combine the OSTEP row groups; S2: combine the TM row slots
+    __syncthreads();
+    float *s_q = smem;  // [OSTEP][COB][8]
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      st4(&s_q[((or0 * COB) + o4 * 4 + u) * 8], q1[u]);
+      st4(&s_q[((or0 * COB) + o4 * 4 + u) * 8 + 4], q3[u]);
+    }
+    __syncthreads();
+    float *out = L.part + (size_t)blockIdx.x * (COB * 8 + 4);
+    for (int e = tid; e < COB * 8; e += 256) {
+      float a = 0.f;
+      for (int i = 0; i < OSTEP; ++i) a += s_q[i * COB * 8 + e];
+      out[e] = a;
+    }
+    __syncthreads();
+    if (tid < TM) st4(&s_q[tid * 4], q2);
+    __syncthreads();
+    if (tid < 4) {
+      float a = 0.f;
+      for (int i = 0; i < TM; ++i) a += s_q[i * 4 + tid];
+      out[COB * 8 + tid] = a;
+    }
+    for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)
+      for (int e = tid; e < COB * 8 + 4; e += 256) L.part[(size_t)pr * (COB * 8 + 4) + e] = 0.f;
   }
 }
 
@@ -933,6 +1001,29 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   else if (!arg && CK == 128 && CP == 128) DG(128, 2, false, true, false, 1)
   else SPACAP_REQUIRE(false, "%s: (CK=%d, CP=%d, pooled=%d) unsupported", what, CK, CP, arg ? 1 : 0);
 #undef DG
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// Layer-2 data gradient of an SA module whose first layer reads (rel xyz, one inline feature) directly (SA1):
+// as spacap_sa_dgrad_f32 with dense dy [R,64], but dy_prev is not written; instead part_l1 f32
+// [spacap_sa_nparts()][64*8+4] receives per-workgroup sums (per channel c: S1[c,0:4], S3[c,0:4]; then S2[0:4]) from which
+// the caller forms dW1 = g S1 + k0 S2 - k1 S3 once the layer-1 constants are known.
+extern "C" int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *zp,
+                                      const float *st_p, const float *feat, const float *xyz, const float *new_xyz,
+                                      const int32_t *idx, float rdiv, int B, int Np, int N, int S, int CK, int CP,
+                                      double *part, float *part_l1, spacap_stream_t stream) {
+  const char *what = "spacap_sa_dgrad_l1_f32";
+  SPACAP_REQUIRE(dy && zk && coef && Wk && zp && st_p && xyz && new_xyz && idx && part && part_l1 && rdiv > 0.f,
+                 "%s: bad arguments", what);
+  SPACAP_REQUIRE(CK == 64 && CP == 64, "%s: (CK=%d, CP=%d) unsupported", what, CK, CP);
+  const long R = (long)B * N * S;
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
+  static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
+  L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1};
+  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(res, 1, (R + TM - 1) / TM), 1),
+                     dim3(256), lds, s, dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, CP, zp, st_p, R, (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

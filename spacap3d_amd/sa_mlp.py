@@ -116,6 +116,23 @@ class _SAMLP(Function):
             check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
                                           st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
             dW2 = pw.sum(0)
+            fuse_l1 = (not ctx.has_Y) and (not ctx.need_xyz) and C1 == 64 and C2 == 64
+            if fuse_l1:
+                # SA1: the first layer's weight gradient comes out of this kernel's epilogue as three sums
+                # (csrc/sa_mlp.hip, L1Args); dy1 is never written and the first-layer backward pass is skipped
+                pl1 = torch.empty(nparts, C1 * 8 + 4, **f32)
+                check(lib.spacap_sa_dgrad_l1_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
+                                                 z1.data_ptr(), st1.data_ptr(), _ptr(feat), xyz.data_ptr(),
+                                                 new_xyz.data_ptr(), idx.data_ptr(), ctx.rdiv, B, Np, N, S, C2, C1,
+                                                 part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1_f32")
+                del dy2
+                finalize(0, C1, st1)
+                P = pl1.double().sum(0)
+                S13 = P[:C1 * 8].view(C1, 2, 4)
+                cf = coef[0].double()
+                dW1 = (cf[:, 0:1] * S13[:, 0] + cf[:, 1:2] * P[C1 * 8:].view(1, 4) - cf[:, 2:3] * S13[:, 1]).float()
+                dW1 = dW1[:, :W1.shape[1]].contiguous()
+                return (None, None, None, None, None, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
             dy1 = torch.empty(R, C1, **f32)
             check(lib.spacap_sa_dgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
                                           z1.data_ptr(), st1.data_ptr(), R, C2, C1, dy1.data_ptr(), part.data_ptr(), st),
