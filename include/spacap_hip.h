@@ -380,6 +380,10 @@ int spacap_rel_loss_fwd_f32(const float *pred, const int64_t *assignment, const 
 int spacap_rel_loss_bwd_f32(const float *dnum, const float *grad_losses, const float *out, int B, int K, float *dpred,
                             spacap_stream_t stream);
 
+/* out[i] = sum_s part[s][i] in ascending s: the second stage of the split reductions (weight-gradient slabs, partial
+ * bias sums).  part f32 [nslab, n] dense, n a multiple of 4, pointers 16-byte aligned. */
+int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,7 @@ SIGNATURES = {
     "spacap_rel_loss_nparts": (_l, [_i, _i]),
     "spacap_rel_loss_fwd_f32": (_i, [_p] * 7 + [_i] * 3 + [_p] * 3 + [_p]),
     "spacap_rel_loss_bwd_f32": (_i, [_p] * 3 + [_i] * 2 + [_p, _p]),
+    "spacap_sum_slabs_f32": (_i, [_p, _i, _l, _p, _p]),
     "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
@@ -121,3 +122,19 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib.spacap_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def sum_slabs(part):
+    """part (nslab, ...) float32 contiguous -> sum over dim 0 in ascending order (csrc/elementwise.hip); falls back to
+    torch.sum when the row size is not a multiple of 4."""
+    import torch
+    n = part[0].numel()
+    if part.shape[0] == 1:
+        return part[0]
+    if not part.is_cuda or n % 4 or part.dtype != torch.float32 or not part.is_contiguous():
+        return part.sum(0)
+    with torch.cuda.device(part.device):
+        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        check(lib.spacap_sum_slabs_f32(part.data_ptr(), part.shape[0], n, out.data_ptr(),
+                                       torch.cuda.current_stream(part.device).cuda_stream), "spacap_sum_slabs_f32")
+    return out

@@ -16,7 +16,7 @@ import math
 import torch
 from torch.autograd import Function
 
-from ._native import check, lib
+from ._native import check, lib, sum_slabs
 
 
 def _strides3(t):
@@ -339,7 +339,7 @@ class RelationLayer1(Function):
             check(lib.spacap_relation_l1_bwd_f32(dH1.data_ptr(), H1.data_ptr(), P.data_ptr(), U.data_ptr(), B, H, K, C,
                                                  dP.data_ptr(), dU.data_ptr(), part.data_ptr(),
                                                  torch.cuda.current_stream(P.device).cuda_stream), "spacap_relation_l1_bwd_f32")
-        return dP, dU.sum(0), part.sum(0)
+        return dP, sum_slabs(dU), sum_slabs(part)
 
 
 def relation_layer1(P, V, weight, bias):

@@ -190,3 +190,38 @@ extern "C" int spacap_adam_flat_f32(float *p, const float *g, float *m, float *v
   SPACAP_CHECK_LAUNCH("spacap_adam_flat_f32");
   return SPACAP_OK;
 }
+
+// ---- sum of per-slab partial results ----------------------------------------------------------------------------
+// out[i] = sum_s part[s][i], s ascending (the fixed-order second stage of every split reduction in this library:
+// weight-gradient slabs, partial bias / dU sums).  torch.sum(0) on these [<= 1024, 16 K .. 270 K] buffers takes ~9 us
+// of mostly launch geometry; here 4 row groups x 64 float4 columns per workgroup, combined through LDS.
+namespace {
+__global__ __launch_bounds__(256) void sum_slabs_kernel(const float *__restrict__ part, int nslab, long n4,
+                                                        float *__restrict__ out) {
+  __shared__ f32x4 s[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + c;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4) {
+    const int per = (nslab + 3) / 4, s0 = grp * per, s1 = min(nslab, s0 + per);
+#pragma unroll 8
+    for (int k = s0; k < s1; ++k) a += *reinterpret_cast<const f32x4 *>(part + ((size_t)k * n4 + i) * 4);
+  }
+  s[grp][c] = a;
+  __syncthreads();
+  if (grp == 0 && i < n4) *reinterpret_cast<f32x4 *>(out + 4 * i) = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+}
+}  // namespace
+
+// part f32 [nslab][n] dense (n a multiple of 4, 16-byte aligned) -> out f32 [n]
+extern "C" int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spacap_stream_t stream) {
+  SPACAP_REQUIRE(nslab >= 1 && n >= 0 && (n & 3) == 0, "spacap_sum_slabs_f32: bad sizes (nslab=%d, n=%ld)", nslab, n);
+  if (n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(part && out && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                 "spacap_sum_slabs_f32: null or unaligned pointer");
+  const long n4 = n >> 2;
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, spacap::as_stream(stream), part, nslab, n4,
+                     out);
+  SPACAP_CHECK_LAUNCH("spacap_sum_slabs_f32");
+  return SPACAP_OK;
+}

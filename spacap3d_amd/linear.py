@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._native import check, lib
+from ._native import check, lib, sum_slabs
 
 
 class FusedLinear(Function):
@@ -34,7 +34,7 @@ class FusedLinear(Function):
             part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
             check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
                                               torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-            s = part.sum(0) if nslab > 1 else part[0]
+            s = sum_slabs(part)
         return dx, s[:CK * CP].view(CK, CP), s[CK * CP:]
 
 

@@ -51,6 +51,13 @@ def _linear_wb(x, w, b):
     return f(x, w, b) if (f is not None and x.is_cuda) else F.linear(x, w, b)
 
 
+def _sum_slabs(t):
+    if not t.is_cuda:
+        return t.sum(0)
+    from ._native import sum_slabs
+    return sum_slabs(t.contiguous())
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x W^T + b for inputs with very many rows (the relation head runs its MLP on B*K*K = 524 288 pair
     features).  Forward and dX are ordinary GEMMs; the weight gradient dW = G^T X reduces over all rows into a
@@ -73,7 +80,7 @@ class _TallLinear(torch.autograd.Function):
         rows, S = g2.shape[0], _TallLinear.SLABS
         dx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
         if rows % S == 0 and rows >= 64 * S:
-            dw = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)).sum(0)
+            dw = _sum_slabs(torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1)))
         else:
             dw = g2.t() @ x2
         # column sums of a very tall, narrow matrix: torch's reduction takes 0.66 ms for 524 288 x 9; two stages 17 us
