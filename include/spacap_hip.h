@@ -384,6 +384,12 @@ int spacap_rel_loss_bwd_f32(const float *dnum, const float *grad_losses, const f
  * bias sums).  part f32 [nslab, n] dense, n a multiple of 4, pointers 16-byte aligned. */
 int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spacap_stream_t stream);
 
+/* Feed-forward block, backward of w_2(dropout(relu(.))) w.r.t. the hidden pre-activation in one launch:
+ * dx[r,n] = (y[r,n] > 0) ? scale * sum_k g[r,k] W[k,n] : 0 with g f32 [R,128] (gradient of the block output), W f32
+ * [128,CP] = w_2.weight (CP a multiple of 128), y f32 [R,CP] the saved dropout(relu(.)) output, scale = 1/(1-p). */
+int spacap_linear_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int CK, int CP,
+                                 float *dx, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

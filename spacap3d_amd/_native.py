@@ -85,6 +85,7 @@ SIGNATURES = {
     "spacap_rel_loss_bwd_f32": (_i, [_p] * 3 + [_i] * 2 + [_p, _p]),
     "spacap_sum_slabs_f32": (_i, [_p, _i, _l, _p, _p]),
     "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
+    "spacap_linear_dgrad_mask_f32": (_i, [_p, _p, _p, _f, _l, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),

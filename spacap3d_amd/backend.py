@@ -38,6 +38,7 @@ class HipBackend:
         self.dropout_add = _fd.dropout_add
         from . import linear as _lin
         self.linear = _lin.linear
+        self.ffn_tail = _lin.ffn_tail
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
 

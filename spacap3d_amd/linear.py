@@ -41,3 +41,59 @@ class FusedLinear(Function):
 def linear(x, weight, bias):
     """F.linear with the fused weight/bias gradient (bias required)."""
     return FusedLinear.apply(x, weight, bias)
+
+
+class FFNTail(Function):
+    """out = w_2(dropout(relu(h)))  (models/transformer_captioner.py:117-126, the part after w_1) as one autograd node:
+    forward = the fused relu+dropout kernel + a BLAS GEMM; backward = one launch for d h (data gradient of w_2 with the
+    relu / dropout mask applied in its epilogue, csrc/sa_mlp.hip: linear_dgrad_mask_kernel) + the one-launch weight /
+    bias gradient."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, p, seed):
+        from .attention import rng_state
+        h = h.contiguous()
+        dev = h.device
+        with torch.cuda.device(dev):
+            y = torch.empty_like(h)
+            check(lib.spacap_relu_dropout_fwd_f32(h.data_ptr(), h.numel(), float(p), int(seed),
+                                                  rng_state(dev).data_ptr() if p > 0.0 else None, y.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), "spacap_relu_dropout_fwd_f32")
+        ctx.save_for_backward(y, weight)
+        ctx.p = float(p)
+        return F.linear(y, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, weight = ctx.saved_tensors
+        CK, CP = weight.shape            # (d_model, d_ff)
+        g2 = g.reshape(-1, CK).contiguous()
+        y2 = y.reshape(-1, CP)
+        R = g2.shape[0]
+        dev = g2.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        scale = 1.0 / (1.0 - ctx.p)
+        with torch.cuda.device(dev):
+            dh = torch.empty_like(y2)
+            check(lib.spacap_linear_dgrad_mask_f32(g2.data_ptr(), weight.contiguous().data_ptr(), y2.data_ptr(), scale, R, CK,
+                                                   CP, dh.data_ptr(), st), "spacap_linear_dgrad_mask_f32")
+            nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
+            if nslab == 0:
+                dw, db = g2.t() @ y2, g2.sum(0)
+            else:
+                part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=dev)
+                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), y2.data_ptr(), R, CK, CP, 1, part.data_ptr(), st),
+                      "spacap_linear_wgrad_f32")
+                s = sum_slabs(part)
+                dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
+        return dh.view_as(y), dw, db, None, None
+
+
+def ffn_tail(h, weight, bias, p, training):
+    """w_2(dropout(relu(h))) -- ``None`` when the shapes have no fused kernel (d_model must be 128, d_ff a multiple of
+    128); the caller then composes relu_dropout + linear."""
+    if not h.is_cuda or weight.shape[0] != 128 or weight.shape[1] % 128 or bias is None:
+        return None
+    from .attention import _next_seed
+    pp = float(p) if training else 0.0
+    return FFNTail.apply(h, weight, bias, pp, _next_seed() if pp > 0.0 else 0)

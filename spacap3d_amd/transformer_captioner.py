@@ -159,6 +159,11 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         h = _linear(x, self.w_1)
+        tail = getattr(ops(), "ffn_tail", None)
+        if tail is not None and h.is_cuda:
+            out = tail(h, self.w_2.weight, self.w_2.bias, self.dropout.p, self.dropout.training)
+            if out is not None:
+                return out
         f = getattr(ops(), "relu_dropout", None)
         h = f(h, self.dropout.p, self.dropout.training) if (f is not None and h.is_cuda) else self.dropout(F.relu(h))
         return _linear(h, self.w_2)

@@ -272,3 +272,34 @@ def test_fused_relu_dropout_and_dropout_add(n):
         assert not torch.equal(y2 != 0, kept)
     assert torch.equal(fd.relu_dropout(x, p, False), torch.relu(x))
     assert torch.equal(fd.dropout_add(r, x, 0.0, True), r + x)
+
+
+@pytest.mark.parametrize("R,dff", [(2048, 2048), (256, 2048), (100, 256), (1, 128)])
+def test_ffn_tail_matches_the_composition(R, dff):
+    """linear.FFNTail (relu+dropout kernel, BLAS GEMM; backward: masked data gradient in one launch + one-launch weight /
+    bias gradient) against relu -> (same mask) -> F.linear in float64 autograd."""
+    from spacap3d_amd.linear import ffn_tail
+    g = torch.Generator().manual_seed(R + dff)
+    h = torch.randn(R, dff, generator=g).to(DEV).requires_grad_(True)
+    W = (torch.randn(128, dff, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(128, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(R, 128, generator=g).to(DEV)
+    for p in (0.0, 0.1):
+        for t in (h, W, b):
+            t.grad = None
+        out = ffn_tail(h, W, b, p, True)
+        (out * w).sum().backward()
+        # recover the mask from the gradient w.r.t. h: non-zero exactly where the unit was active and kept
+        keep = (h.grad != 0)
+        hd, Wd, bd = (t.detach().double().requires_grad_(True) for t in (h, W, b))
+        y = torch.relu(hd) * keep.double() / (1 - p)
+        (torch.nn.functional.linear(y, Wd, bd) * w.double()).sum().backward()
+        assert torch.allclose(out.double(), torch.nn.functional.linear(y, Wd, bd), rtol=1e-4, atol=1e-4)
+        for got, want in ((h.grad, hd.grad), (W.grad, Wd.grad), (b.grad, bd.grad)):
+            err = float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+            assert err < 3e-5, (p, err)
+        if p == 0.0:
+            assert torch.equal(keep, h.detach() > 0) or float((keep ^ (h.detach() > 0)).float().mean()) < 1e-3
+        elif R * dff > 10000:
+            frac = float(keep.sum()) / float((h.detach() > 0).sum())
+            assert abs(frac - 0.9) < 0.02
