@@ -104,7 +104,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--config", default="cfg2", choices=sorted(CFG))
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the config's 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
