@@ -86,7 +86,8 @@ def test_flat_adam_matches_torch_adam():
             assert torch.allclose(p, q, rtol=2e-6, atol=2e-7), (step, float((p - q).abs().max()))
 
 
-def test_fused_detection_losses_match_the_torch_composition():
+@pytest.mark.parametrize("num_proposal", [256, 512, 40])
+def test_fused_detection_losses_match_the_torch_composition(num_proposal):
     """csrc/losses.hip (3 launches forward, 1 backward) against the op-by-op composition of
     spacap3d_amd/loss_helper.py (= lib/loss_helper.py:35-197): eight loss values, integer labels bit-exact, gradients
     w.r.t. the proposal head output, the centres and the votes."""
@@ -95,7 +96,7 @@ def test_fused_detection_losses_match_the_torch_composition():
     from spacap3d_amd.loss_helper import start_detection_losses
     from spacap3d_amd.spacapnet import build_default
     torch.manual_seed(1)
-    model = build_default(vocab_size=200, num_proposal=256, N=1, d_ff=64).to(DEV).train()
+    model = build_default(vocab_size=200, num_proposal=num_proposal, N=1, d_ff=64).to(DEV).train()
     data = synthetic_batch(3, 8192, DEV, seed=5, vocab=200)
     hip = backend.ops()
     saved = hip.detection_losses
@@ -132,7 +133,12 @@ def test_fused_detection_losses_match_the_torch_composition():
         gnet = net.grad if net.grad is not None else torch.zeros_like(net)
         results.append((losses.detach(), t[2], t[3], t[4], gnet.clone(), cen.grad.clone(), vx.grad.clone()))
     (la, laba, maska, oaa, gna, gca, gva), (lb, labb, maskb, oab, gnb, gcb, gvb) = results
-    assert torch.equal(laba, labb) and torch.equal(maska, maskb) and torch.equal(oaa, oab)
+    assert torch.equal(laba, labb) and torch.equal(maska, maskb)
+    # padded ground-truth rows are identical, so a proposal nearest to one of them is tied between all of them: the
+    # fused kernel takes the first, torch.min an unspecified one -- compare the assignment where it names a real box
+    real_a = torch.gather(data["box_label_mask"], 1, oaa) > 0
+    real_b = torch.gather(data["box_label_mask"], 1, oab) > 0
+    assert torch.equal(real_a, real_b) and torch.equal(oaa[real_a], oab[real_b])
     assert 0 < int(laba.sum()) < laba.numel()
     assert torch.allclose(la, lb, rtol=2e-5, atol=1e-6), (la, lb)
     for name, a, b in (("dnet", gna, gnb), ("dcenter", gca, gcb), ("dvote", gva, gvb)):
