@@ -106,6 +106,7 @@ class Trainer:
         d["loss"].backward()
         if pc.is_cuda:
             streams.join_all(pc.device)  # side-stream branches (relation head, detection losses) re-join here
+        streams.enable(False)            # the switch is process-wide: do not leak it to callers outside the step
         if with_optimizer:
             self._optimizer_step(None)
         return d["loss"].detach()
