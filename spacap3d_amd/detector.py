@@ -149,7 +149,8 @@ class ProposalModule(nn.Module):
     def forward(self, xyz, features, data_dict):
         xyz, features, fps_inds = self.vote_aggregation(xyz, features)
         data_dict["aggregated_vote_xyz"] = xyz
-        data_dict["aggregated_vote_features"] = features.permute(0, 2, 1).contiguous()
+        pm = getattr(features, "_point_major", None)   # the fused SA op's own (B,K,128) result
+        data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
         net = self.proposal(features)
         return self.decode_scores(net, data_dict)

@@ -89,21 +89,28 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = SharedMLP(mlp_spec, bn=bn)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
-        xyz_flipped = xyz.transpose(1, 2).contiguous()
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
-        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
+        from .backend import ops
+        fused = getattr(ops(), "sa_mlp_train", None) if self.training else None
+        if fused is not None and xyz.is_cuda:
+            # centres as a row gather of the (B,N,3) coordinates (same values as gather_operation on the transposed
+            # copy, :239-241, without the two transposes)
+            new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        else:
+            xyz_flipped = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
         idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
-        if self.training:
+        if fused is not None:
             # training step: grouping + SharedMLP + pooling as one point-major op of the backend (sa_mlp.py)
-            from .backend import ops
-            fused = getattr(ops(), "sa_mlp_train", None)
             out = fused(xyz, new_xyz, features, idx, self.mlp_module, self.radius if self.normalize_xyz else 1.0,
-                        self.use_xyz) if fused is not None else None
+                        self.use_xyz)
             if out is not None:
                 return new_xyz, out, inds
+        if features is not None:
+            features = features.contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=idx)  # (B, C+3, npoint, nsample)
         # SharedMLP + F.max_pool2d(x, [1, nsample]).squeeze(-1)  (pointnet2_modules.py:253-271)
         new_features = self.mlp_module(grouped_features, pool=True)             # (B, mlp[-1], npoint)
@@ -123,7 +130,7 @@ class PointnetFPModule(nn.Module):
             dist_recip = 1.0 / (dist + 1e-8)
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated

@@ -173,7 +173,7 @@ def supported(mlp_module, nsample):
 
 
 def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
-    """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N).  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
+    """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N) [a view of the point-major (B,N,C3) result, also attached as ``._point_major``].  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
     updated.  Returns None when this MLP has no fused kernels (the caller then uses the per-operator path)."""
     if not use_xyz or not xyz.is_cuda or not supported(mlp_module, idx.shape[2]):
         return None
@@ -187,7 +187,8 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
             feat, W1a = features.reshape(features.shape[0], -1), W1          # inline: no (B,Np,C1) product needed
         else:
             # the first layer commutes with the gather: multiply once per source point
-            Y = torch.matmul(features.transpose(1, 2), W1[:, 3:].t())
+            pm = getattr(features, "_point_major", None)   # (B,Np,Cf) form of a previous module's output, if any
+            Y = torch.matmul(pm if pm is not None else features.transpose(1, 2), W1[:, 3:].t())
             W1a = W1[:, :3]
     else:
         assert Cf == 0
@@ -196,4 +197,8 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
     out = _SAMLP.apply(xyz, new_xyz, idx, feat, Y, W1a, l2.conv.weight.view(l2.conv.out_channels, -1),
                        l3.conv.weight.view(l3.conv.out_channels, -1), bns[0].weight, bns[0].bias, bns[1].weight,
                        bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv)
-    return out.transpose(1, 2).contiguous()
+    # (B,C3,N) as a transposed VIEW of the point-major result: the next SA module and the proposal head read the
+    # point-major tensor itself (``_point_major``), so no transposed copy is made unless a consumer asks for one
+    res = out.transpose(1, 2)
+    res._point_major = out
+    return res

@@ -73,7 +73,7 @@ def test_fused_sa_mlp_matches_float64_reference(name, Np, N, Sn, Cf, mlp, radius
     feats_in = feats.clone().requires_grad_(Cf > 1)
     rm0 = [l.bn.bn.running_mean.clone() for l in sa.mlp_module.children()]
     new_xyz, out, inds = sa(xyz_in, feats_in)
-    assert out.shape == (B, mlp[-1], N) and out.is_contiguous()
+    assert out.shape == (B, mlp[-1], N) and out._point_major.is_contiguous()
     dout = torch.randn_like(out)
     (out * dout).sum().backward()
     idx = PU.ball_query(radius, Sn, xyz, new_xyz.detach())
