@@ -86,13 +86,39 @@ class Trainer:
         used = used_parameters(self.model, d["loss"])
         # gradients are assigned by autograd (no per-parameter accumulate kernels) and packed into the flat
         # bucket only when there is something to all-reduce
+        used = self._group_qkv(used)
         self.bucket = FlatGradBucket(used, views=False)
         kw = dict(lr=self.lr, weight_decay=self.weight_decay)
         if used[0].is_cuda:
             from .optim import FlatAdam   # one launch over a flat parameter buffer (spacap3d_amd/optim.py)
             self.optimizer = FlatAdam(self.bucket, **kw)
+            self._attach_packed_qkv()
         else:
             self.optimizer = torch.optim.Adam(used, **kw)
+
+    def _attention_modules(self):
+        from .transformer_captioner import MultiHeadedAttention
+        return [m for m in self.model.modules() if isinstance(m, MultiHeadedAttention)]
+
+    def _group_qkv(self, used):
+        """Order the flat buffer so that the q, k, v weights of every attention module are adjacent (then their
+        biases): the packed projection reads them as ONE (3*d, d) matrix without a concatenation per step."""
+        pos = {id(p): i for i, p in enumerate(used)}
+        moved, groups = set(), []
+        for m in self._attention_modules():
+            ws = [l.weight for l in m.linears[:3]]
+            bs = [l.bias for l in m.linears[:3]]
+            if all(id(p) in pos for p in ws + bs):
+                groups.append(ws + bs)
+                moved.update(id(p) for p in ws + bs)
+        rest = [p for p in used if id(p) not in moved]
+        return rest + [p for g in groups for p in g]
+
+    def _attach_packed_qkv(self):
+        from .linear import packed_views
+        for m in self._attention_modules():
+            pk = packed_views(self.optimizer.flat_p, [l.weight for l in m.linears[:3]], [l.bias for l in m.linears[:3]])
+            m._packed_qkv = pk
 
     def _core(self, data_dict, with_optimizer=True):
         """zero grads -> forward -> loss -> backward [-> all-reduce -> Adam]; no host sync, capturable."""

@@ -97,3 +97,51 @@ def ffn_tail(h, weight, bias, p, training):
     from .attention import _next_seed
     pp = float(p) if training else 0.0
     return FFNTail.apply(h, weight, bias, pp, _next_seed() if pp > 0.0 else 0)
+
+
+class PackedLinear(Function):
+    """y = x [W0; W1; W2]^T + [b0; b1; b2] where the three weights (and the three biases) are ADJACENT in memory, so
+    ``packed_w`` / ``packed_b`` are plain views of them (spacap3d_amd/engine.py lays the parameters out that way in the
+    flat optimizer buffer): the self-attention q | k | v projection without concatenating the weights every step.
+    The parameters themselves are passed too, only so that autograd routes the gradient slices to them."""
+
+    @staticmethod
+    def forward(ctx, x, packed_w, packed_b, w0, w1, w2, b0, b1, b2):
+        ctx.save_for_backward(x, packed_w)
+        ctx.split = (w0.shape[0], w1.shape[0], w2.shape[0])
+        return F.linear(x, packed_w, packed_b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        CK, CP = weight.shape
+        g2 = g.reshape(-1, CK).contiguous()
+        x2 = x.reshape(-1, CP).contiguous()
+        R = g2.shape[0]
+        dx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
+        if nslab == 0:
+            dw, db = g2.t() @ x2, g2.sum(0)
+        else:
+            with torch.cuda.device(g2.device):
+                part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
+                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
+                                                  torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
+                s = sum_slabs(part)
+            dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
+        a, b, _ = ctx.split
+        return (dx, None, None, dw[:a], dw[a:a + b], dw[a + b:], db[:a], db[a:a + b], db[a + b:])
+
+
+def packed_views(flat, params_w, params_b):
+    """(packed_w, packed_b) views INTO ``flat`` over three weights / biases that sit back to back inside it, else None."""
+    def adjacent(ps):
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        return all(p.is_contiguous() and lo <= p.data_ptr() < hi for p in ps) and \
+            all(ps[i + 1].data_ptr() == ps[i].data_ptr() + ps[i].numel() * ps[i].element_size() for i in range(len(ps) - 1))
+    if not (adjacent(params_w) and adjacent(params_b)) or any(p.shape[1:] != params_w[0].shape[1:] for p in params_w):
+        return None
+    rows, cols = sum(p.shape[0] for p in params_w), params_w[0].shape[1]
+    ow = (params_w[0].data_ptr() - flat.data_ptr()) // flat.element_size()
+    ob = (params_b[0].data_ptr() - flat.data_ptr()) // flat.element_size()
+    return flat[ow:ow + rows * cols].view(rows, cols), flat[ob:ob + rows]

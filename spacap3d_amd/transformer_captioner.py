@@ -113,9 +113,16 @@ class MultiHeadedAttention(nn.Module):
             # self-attention: q, k, v from ONE GEMM over the concatenated weights; the kernels read the packed result
             # through strides and write one packed gradient (see attention.FusedSelfAttentionPacked)
             hd = self.h * self.d_k
-            w = torch.cat([l.weight for l in self.linears[:3]], dim=0)
-            b = torch.cat([l.bias for l in self.linears[:3]], dim=0)
-            qkv = _linear_wb(query, w, b)
+            pk = getattr(self, "_packed_qkv", None)
+            if pk is not None and pk[0].data_ptr() == self.linears[0].weight.data_ptr():
+                # the three weights are adjacent in the optimizer's flat buffer (engine.py): no concatenation
+                from .linear import PackedLinear
+                qkv = PackedLinear.apply(query, pk[0], pk[1], *[l.weight for l in self.linears[:3]],
+                                         *[l.bias for l in self.linears[:3]])
+            else:
+                w = torch.cat([l.weight for l in self.linears[:3]], dim=0)
+                b = torch.cat([l.bias for l in self.linears[:3]], dim=0)
+                qkv = _linear_wb(query, w, b)
             need_p = self.keep_value if self.store_attn is None else (self.store_attn or self.keep_value)
             p = self.dropout.p
             x, self.attn = packed(qkv, self.h, mask=mask, dropout_p=p, training=self.dropout.training, need_p=need_p)

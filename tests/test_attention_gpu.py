@@ -233,6 +233,33 @@ def test_fused_linear_weight_and_bias_gradients(R, CK, CP):
         assert err < 2e-5, err
 
 
+def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
+    """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
+    gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
+    packed_views must refuse parameters that are not inside the flat buffer."""
+    from spacap3d_amd.linear import PackedLinear, packed_views
+    d, R = 128, 640
+    g = torch.Generator().manual_seed(5)
+    flat = (torch.randn(3 * d * d + 3 * d + 7, generator=g) * 0.1).to(DEV)
+    ws = [torch.nn.Parameter(flat[i * d * d:(i + 1) * d * d].view(d, d)) for i in range(3)]
+    bs = [torch.nn.Parameter(flat[3 * d * d + i * d:3 * d * d + (i + 1) * d]) for i in range(3)]
+    pk = packed_views(flat, ws, bs)
+    assert pk is not None and pk[0].shape == (3 * d, d) and pk[0].data_ptr() == ws[0].data_ptr()
+    assert packed_views(flat, [ws[0], ws[2], ws[1]], bs) is None
+    assert packed_views(flat, [w.detach().clone() for w in ws], bs) is None
+    x = torch.randn(R, d, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(R, 3 * d, generator=g).to(DEV)
+    (PackedLinear.apply(x, pk[0], pk[1], *ws, *bs) * w).sum().backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    wr = [p.detach().double().cpu().requires_grad_(True) for p in ws]
+    br = [p.detach().double().cpu().requires_grad_(True) for p in bs]
+    y = torch.cat([torch.nn.functional.linear(xr, a, b) for a, b in zip(wr, br)], 1)
+    (y * w.double().cpu()).sum().backward()
+    for got, want in [(x, xr)] + list(zip(ws, wr)) + list(zip(bs, br)):
+        err = float((got.grad.double().cpu() - want.grad).abs().max()) / (float(want.grad.abs().max()) + 1e-12)
+        assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("n", [2048 * 2048, 2048 * 128, 1003, 5])
 def test_fused_relu_dropout_and_dropout_add(n):
     """csrc/elementwise.hip: kept fraction ~ 1-p, kept values scaled by 1/(1-p), the backward uses the same mask as
