@@ -390,6 +390,14 @@ int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spaca
 int spacap_linear_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int CK, int CP,
                                  float *dx, spacap_stream_t stream);
 
+/* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
+ * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
+ * a f32 [R,K], Wop[k,n] = trans_w ? W[n,k] (W f32 [CO,K]: y = x W^T) : W[k,n] (W f32 [K,CO]: dx = g W), bias f32 [CO]
+ * or null, out f32 [R,CO]; K in {128,256,384,512}, CO a multiple of 64 (spacap_linear_rows_supported says so). */
+int spacap_linear_rows_supported(long R, int K, int CO);
+int spacap_linear_rows_f32(const float *a, const float *W, const float *bias, long R, int K, int CO, int trans_w,
+                           float *out, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

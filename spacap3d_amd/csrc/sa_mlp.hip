@@ -1275,3 +1275,99 @@ extern "C" int spacap_linear_dgrad_mask_f32(const float *g, const float *W, cons
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ===========================================================================================================
+// Row-panel products of the Transformer's d_model = 128 projections (models/transformer_captioner.py:63-99):
+//   out[r, n] = sum_k a[r, k] Wop[k, n] (+ bias[n])
+//   Wop[k, n] = TRANS_W ? W[n, k]  (forward  y = x W^T,  W [CO, K])
+//                       : W[k, n]  (data gradient dx = g W,  W [K, CO])
+// The BLAS library's heuristics pick one or two 128 x 256 macro tiles for these shapes when R is a few hundred rows
+// (the caption decoder: 8 x 32 tokens; 20 - 60 us per product on 1 - 3 workgroups).  Here: one (16 MT rows) x 64 column tile per workgroup, each wave 16 columns, the
+// activations of a 128-wide K chunk in LDS and that chunk's weights in registers, so a few-hundred-row product is tens
+// of workgroups of ~100 MFMA each (3 - 7 us).  Same summation order for every row: results do not depend on R.
+// a dense [R, K], K a multiple of 128.  (The vocabulary projection's gradients, 248 x 3 001, were tried in this
+// form too -- K-split partial sums for dx, a transposed loader for dW -- and lost to the BLAS kernels, 40 vs 35 us.)
+namespace {
+template <bool TRANS_W, int MT>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float *__restrict__ a, const float *__restrict__ W,
+                                                          const float *__restrict__ bias, long R, int K, int CO,
+                                                          float *__restrict__ out) {
+  constexpr int KC = 128, LD = KC + 4, KS = KC / 4, TMR = 16 * MT, C4 = KC / 4, RSTEP = 256 / C4, NV = TMR * C4 / 256;
+  __shared__ __attribute__((aligned(16))) float s_a[TMR * LD];
+  __shared__ __attribute__((aligned(16))) float s_w[TRANS_W ? 64 * LD : 4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int cbb = blockIdx.y * 64, cb = cbb + w * 16;
+  const long row0 = (long)blockIdx.x * TMR;
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = 0; kc < K; kc += KC) {
+    if (kc) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < R) v = ld4(a + (size_t)(row0 + row) * K + kc + c4 * 4);
+      st4(&s_a[row * LD + c4 * 4], v);
+    }
+    float wf[KS];
+    if (TRANS_W) {
+      // the 64 x 128 weight panel through LDS: full-row loads instead of 16-byte runs per lane
+#pragma unroll
+      for (int i = 0; i < 64 * C4 / 256; ++i) {
+        const int n = r0 + i * RSTEP;
+        st4(&s_w[n * LD + c4 * 4], ld4(W + (size_t)(cbb + n) * K + kc + c4 * 4));
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[ks] = W[(size_t)(kc + ks * 4 + lg) * CO + cb + l15];
+    }
+    __syncthreads();
+    if (TRANS_W) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[ks] = s_w[(w * 16 + l15) * LD + ks * 4 + lg];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(wf[ks], s_a[(mt * 16 + l15) * LD + ks * 4 + lg], acc[mt]);
+  }
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = ld4(bias + cb + 4 * lg);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long row = row0 + mt * 16 + l15;
+    if (row < R) st4(out + (size_t)row * CO + cb + 4 * lg, acc[mt] + bv);
+  }
+}
+}  // namespace
+
+// 1 when (R, K, CO) has a dense row-panel kernel (spacap_linear_rows_f32)
+extern "C" int spacap_linear_rows_supported(long R, int K, int CO) {
+  return R >= 1 && K >= 128 && K <= 512 && K % 128 == 0 && CO >= 64 && CO % 64 == 0;
+}
+
+// a f32 [R,K], W f32 [CO,K] (trans_w) or [K,CO], bias f32 [CO] or null, out f32 [R,CO]; all dense, 16-byte aligned
+extern "C" int spacap_linear_rows_f32(const float *a, const float *W, const float *bias, long R, int K, int CO, int trans_w,
+                                      float *out, spacap_stream_t stream) {
+  const char *what = "spacap_linear_rows_f32";
+  SPACAP_REQUIRE(R >= 0 && K >= 128 && K <= 512 && K % 128 == 0 && CO >= 64 && CO % 64 == 0,
+                 "%s: (R=%ld, K=%d, CO=%d) unsupported", what, R, K, CO);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(a && W && out, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const bool small = R <= 1024;
+  const long tiles = small ? (R + 31) / 32 : (R + 63) / 64;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)tiles, CO / 64);
+  if (trans_w) {
+    if (small) hipLaunchKernelGGL((linear_rows_kernel<true, 2>), grid, dim3(256), 0, s, a, W, bias, R, K, CO, out);
+    else hipLaunchKernelGGL((linear_rows_kernel<true, 4>), grid, dim3(256), 0, s, a, W, bias, R, K, CO, out);
+  } else {
+    if (small) hipLaunchKernelGGL((linear_rows_kernel<false, 2>), grid, dim3(256), 0, s, a, W, bias, R, K, CO, out);
+    else hipLaunchKernelGGL((linear_rows_kernel<false, 4>), grid, dim3(256), 0, s, a, W, bias, R, K, CO, out);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

@@ -12,11 +12,52 @@ from torch.autograd import Function
 from ._native import check, lib, sum_slabs
 
 
+def rows_product(a2, W, bias, trans_w):
+    """out = a2 W^T (+ bias) when ``trans_w`` else a2 W, by the row-panel kernel (csrc/sa_mlp.hip: linear_rows_kernel);
+    a2 (R, K) dense.  The caller checks ``use_rows``."""
+    R, K = a2.shape
+    CO = W.shape[0] if trans_w else W.shape[1]
+    dev = a2.device
+    with torch.cuda.device(dev):
+        out = torch.empty(R, CO, dtype=torch.float32, device=dev)
+        check(lib.spacap_linear_rows_f32(a2.data_ptr(), W.data_ptr(), bias.data_ptr() if bias is not None else None, R, K, CO,
+                                         1 if trans_w else 0, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "spacap_linear_rows_f32")
+    return out
+
+
+def use_rows(R, K, CO):
+    """Shapes where the row-panel kernel beats the BLAS GEMM (measured, tools/lab/linear_bench.py)."""
+    return bool(lib.spacap_linear_rows_supported(R, K, CO)) and _ROWS_RULE(R, K, CO)
+
+
+# the BLAS heuristics are erratic below a few hundred rows (R = 256: 20 - 60 us on one or two workgroups for the
+# d_model-wide products, 4 - 6 us at R = 264 or 2 048); the row-panel kernel takes 3 - 7 us there
+_ROWS_RULE = lambda R, K, CO: R <= 512
+
+
+def _forward_product(x, weight, bias):
+    """x W^T + b: the row-panel kernel where it is the faster one, else the BLAS GEMM."""
+    CO, K = weight.shape
+    R = x.numel() // K
+    if x.is_cuda and x.dtype == torch.float32 and use_rows(R, K, CO) and weight.is_contiguous():
+        return rows_product(x.reshape(R, K).contiguous(), weight, bias, True).view(*x.shape[:-1], CO)
+    return F.linear(x, weight, bias)
+
+
+def _data_gradient(g2, weight):
+    """g2 W for g2 (R, CK) dense and W (CK, CP)."""
+    R, CK = g2.shape
+    if g2.is_cuda and g2.dtype == torch.float32 and use_rows(R, CK, weight.shape[1]) and weight.is_contiguous():
+        return rows_product(g2.contiguous(), weight, None, False)
+    return g2 @ weight
+
+
 class FusedLinear(Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        return F.linear(x, weight, bias)
+        return _forward_product(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
@@ -25,7 +66,7 @@ class FusedLinear(Function):
         g2 = g.reshape(-1, CK)
         x2 = x.reshape(-1, CP)
         R = g2.shape[0]
-        dx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        dx = _data_gradient(g2, weight).view_as(x) if ctx.needs_input_grad[0] else None
         nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP)) if g2.is_cuda else 0
         if nslab == 0:
             return dx, g2.t() @ x2, g2.sum(0)
@@ -61,7 +102,7 @@ class FFNTail(Function):
                                                   torch.cuda.current_stream(dev).cuda_stream), "spacap_relu_dropout_fwd_f32")
         ctx.save_for_backward(y, weight)
         ctx.p = float(p)
-        return F.linear(y, weight, bias)
+        return F.linear(y, weight, bias)   # K = d_ff: a long reduction, the BLAS split-K kernels are the right tool
 
     @staticmethod
     def backward(ctx, g):
@@ -109,7 +150,7 @@ class PackedLinear(Function):
     def forward(ctx, x, packed_w, packed_b, w0, w1, w2, b0, b1, b2):
         ctx.save_for_backward(x, packed_w)
         ctx.split = (w0.shape[0], w1.shape[0], w2.shape[0])
-        return F.linear(x, packed_w, packed_b)
+        return _forward_product(x, packed_w, packed_b)
 
     @staticmethod
     def backward(ctx, g):
@@ -118,7 +159,7 @@ class PackedLinear(Function):
         g2 = g.reshape(-1, CK).contiguous()
         x2 = x.reshape(-1, CP).contiguous()
         R = g2.shape[0]
-        dx = (g2 @ weight).view_as(x) if ctx.needs_input_grad[0] else None
+        dx = _data_gradient(g2, weight).view_as(x) if ctx.needs_input_grad[0] else None
         nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
         if nslab == 0:
             dw, db = g2.t() @ x2, g2.sum(0)
@@ -145,3 +186,4 @@ def packed_views(flat, params_w, params_b):
     ow = (params_w[0].data_ptr() - flat.data_ptr()) // flat.element_size()
     ob = (params_b[0].data_ptr() - flat.data_ptr()) // flat.element_size()
     return flat[ow:ow + rows * cols].view(rows, cols), flat[ob:ob + rows]
+

@@ -233,6 +233,40 @@ def test_fused_linear_weight_and_bias_gradients(R, CK, CP):
         assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("R,K,CO,trans", [(256, 128, 384, 1), (256, 128, 128, 1), (256, 384, 128, 0), (256, 128, 128, 0),
+                                          (33, 512, 64, 0), (1, 128, 128, 1), (1500, 256, 192, 1), (2048, 128, 384, 1),
+                                          (1025, 384, 128, 0)])
+def test_row_panel_product_matches_float64(R, K, CO, trans):
+    """spacap_linear_rows_f32 (forward x W^T + b / data gradient g W of the d_model-wide projections)."""
+    from spacap3d_amd.linear import rows_product
+    g = torch.Generator().manual_seed(R * 7 + K + CO)
+    a = torch.randn(R, K, generator=g)
+    W = torch.randn((CO, K) if trans else (K, CO), generator=g) * 0.1
+    b = torch.randn(CO, generator=g) if trans else None
+    want = torch.nn.functional.linear(a.double(), W.double(), b.double()) if trans else a.double() @ W.double()
+    got = rows_product(a.to(DEV), W.to(DEV), b.to(DEV) if trans else None, bool(trans))
+    err = float((got.double().cpu() - want).abs().max()) / float(want.abs().max())
+    assert err < 2e-6, err
+
+
+def test_small_row_linears_take_the_row_panel_kernel_and_keep_their_gradients():
+    """FusedLinear at the caption decoder's 8 x 32 rows (row-panel forward and data gradient) against float64."""
+    from spacap3d_amd.linear import linear, use_rows
+    assert use_rows(256, 128, 128) and not use_rows(2048, 128, 128) and not use_rows(256, 2048, 128)
+    g = torch.Generator().manual_seed(11)
+    x, W, b = torch.randn(8, 32, 128, generator=g), torch.randn(384, 128, generator=g) * 0.1, torch.randn(384, generator=g)
+    w = torch.randn(8, 32, 384, generator=g)
+    xr, Wr, br = (t.double().requires_grad_(True) for t in (x, W, b))
+    (torch.nn.functional.linear(xr, Wr, br) * w.double()).sum().backward()
+    xg, Wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, W, b))
+    y = linear(xg, Wg, bg)
+    assert float((y.double().cpu() - torch.nn.functional.linear(xr, Wr, br).detach()).abs().max()) < 1e-5
+    (y * w.to(DEV)).sum().backward()
+    for got, want in ((xg.grad, xr.grad), (Wg.grad, Wr.grad), (bg.grad, br.grad)):
+        err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 2e-5, err
+
+
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
     """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
     gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
