@@ -172,6 +172,38 @@ def supported(mlp_module, nsample):
     return bool(lib.spacap_sa_mlp_supported(*c)) and 1 <= nsample <= 255
 
 
+class _FeatureProduct(Function):
+    """Y = F W1[:, 3:]^T for the point-major features F (B,Np,Cf) of the source points (the first shared-MLP layer
+    commutes with the gather).  The weight gradient reduces over all B*Np rows into a (C1, Cf) matrix -- the BLAS
+    heuristics run that without a K split (96 us at SA2) -- so it takes the slab kernel of the Linear layers
+    (csrc/sa_mlp.hip: linear_wgrad_kernel, ~15 us) and lands in columns 3.. of a W1-shaped gradient."""
+
+    @staticmethod
+    def forward(ctx, pm, W1):
+        ctx.save_for_backward(pm, W1)
+        return torch.matmul(pm, W1[:, 3:].t())
+
+    @staticmethod
+    def backward(ctx, g):
+        pm, W1 = ctx.saved_tensors
+        C1, Cf = W1.shape[0], W1.shape[1] - 3
+        g2 = g.reshape(-1, C1).contiguous()
+        x2 = pm.reshape(-1, Cf)
+        R = g2.shape[0]
+        dpm = torch.matmul(g2, W1[:, 3:]).view_as(pm) if ctx.needs_input_grad[0] else None
+        dW = torch.zeros_like(W1)
+        nslab = int(lib.spacap_linear_wgrad_slabs(R, C1, Cf)) if x2.is_contiguous() else 0
+        if nslab == 0:
+            dW[:, 3:] = g2.t() @ x2
+        else:
+            with torch.cuda.device(g2.device):
+                part = torch.empty(nslab, C1 * Cf, dtype=torch.float32, device=g2.device)
+                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, C1, Cf, 0, part.data_ptr(),
+                                                  torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
+                dW[:, 3:] = sum_slabs(part).view(C1, Cf)
+        return dpm, dW
+
+
 def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
     """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N) [a view of the point-major (B,N,C3) result, also attached as ``._point_major``].  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
     updated.  Returns None when this MLP has no fused kernels (the caller then uses the per-operator path)."""
@@ -188,7 +220,7 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
         else:
             # the first layer commutes with the gather: multiply once per source point
             pm = getattr(features, "_point_major", None)   # (B,Np,Cf) form of a previous module's output, if any
-            Y = torch.matmul(pm if pm is not None else features.transpose(1, 2), W1[:, 3:].t())
+            Y = _FeatureProduct.apply(pm if pm is not None else features.transpose(1, 2), W1)
             W1a = W1[:, :3]
     else:
         assert Cf == 0
