@@ -390,6 +390,15 @@ int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spaca
 int spacap_linear_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int CK, int CP,
                                  float *dx, spacap_stream_t stream);
 
+/* Weight gradient of a 1x1 convolution on channel-major tensors (vote net: models/voting_module.py:33-60; feature
+ * propagation MLPs: lib/pointnet2/pointnet2_modules.py:376-421): dW[co,ci] = sum_b sum_n g[b,co,n] x[b,ci,n] with
+ * g f32 [B,CO,N], x f32 [B,CI,N] (CO, CI multiples of 128, N a multiple of 32).  part f32
+ * [spacap_conv1x1_wgrad_slabs(B,CO,CI,N)][CO*CI] receives per-slab partial sums that the caller adds in slab order
+ * (spacap_sum_slabs_f32); the slab count is 0 for shapes without a kernel. */
+int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N);
+int spacap_conv1x1_wgrad_f32(const float *g, const float *x, int B, int CO, int CI, int N, float *part,
+                             spacap_stream_t stream);
+
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
  * a f32 [R,K], Wop[k,n] = trans_w ? W[n,k] (W f32 [CO,K]: y = x W^T) : W[k,n] (W f32 [K,CO]: dx = g W), bias f32 [CO]

@@ -39,6 +39,7 @@ class HipBackend:
         from . import linear as _lin
         self.linear = _lin.linear
         self.ffn_tail = _lin.ffn_tail
+        self.conv1x1 = _lin.conv1x1
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
 

@@ -85,6 +85,14 @@ class Pointnet2Backbone(nn.Module):
         return data_dict
 
 
+def _conv(conv, x, training):
+    """``conv(x)``; in training mode through the backend's 1x1 convolution (slab weight gradient) when it has one."""
+    from .backend import ops
+    f = getattr(ops(), "conv1x1", None) if training else None
+    y = f(x, conv) if f is not None else None
+    return conv(x) if y is None else y
+
+
 class VotingModule(nn.Module):
     """Conv1d 256->256->256->(3+256)*vote_factor with BN+ReLU on the first two, residual votes
     (voting_module.py:28-61)."""
@@ -103,8 +111,8 @@ class VotingModule(nn.Module):
     def forward(self, seed_xyz, seed_features):
         B, num_seed = seed_xyz.shape[0], seed_xyz.shape[1]
         num_vote = num_seed * self.vote_factor
-        net = F.relu(self.bn1(self.conv1(seed_features)))
-        net = F.relu(self.bn2(self.conv2(net)))
+        net = F.relu(self.bn1(_conv(self.conv1, seed_features, self.training)))
+        net = F.relu(self.bn2(_conv(self.conv2, net, self.training)))
         net = self.conv3(net)
         net = net.transpose(2, 1).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, num_vote, 3)

@@ -187,3 +187,50 @@ def packed_views(flat, params_w, params_b):
     ob = (params_b[0].data_ptr() - flat.data_ptr()) // flat.element_size()
     return flat[ow:ow + rows * cols].view(rows, cols), flat[ob:ob + rows]
 
+
+
+class Conv1x1(Function):
+    """nn.Conv1d / nn.Conv2d with a 1x1 kernel on channel-major (B, C, N[, 1]) tensors -- the vote net and the
+    feature-propagation MLPs (models/voting_module.py:33-60, lib/pointnet2/pointnet2_modules.py:376-421).  Forward and
+    input gradient stay the library's kernels; the weight gradient (an implicit-GEMM kernel of 46 - 60 us, or one small
+    GEMM per scene) is csrc/sa_mlp.hip: conv1x1_wgrad_kernel + one sum over its slabs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.conv2d(x, weight, bias) if x.dim() == 4 else F.conv1d(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        B, CI = x.shape[0], x.shape[1]
+        CO = weight.shape[0]
+        N = x.numel() // (B * CI)
+        g = g.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
+                                                     [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
+                                                     [True, False, False])[0]
+        nslab = int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N))
+        with torch.cuda.device(g.device):
+            part = torch.empty(nslab, CO * CI, dtype=torch.float32, device=g.device)
+            check(lib.spacap_conv1x1_wgrad_f32(g.data_ptr(), x.data_ptr(), B, CO, CI, N, part.data_ptr(),
+                                               torch.cuda.current_stream(g.device).cuda_stream), "spacap_conv1x1_wgrad_f32")
+            dw = (sum_slabs(part) if nslab > 1 else part[0]).view_as(weight)
+        db = g.sum(dim=[0] + list(range(2, g.dim()))) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def conv1x1(x, conv):
+    """``conv(x)`` for a 1x1 nn.Conv1d / nn.Conv2d ``conv``; ``None`` when the shape has no weight-gradient kernel or
+    no gradient is being recorded (the caller then calls the module)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad):
+        return None
+    B, CI = x.shape[0], x.shape[1]
+    N = x.numel() // max(B * CI, 1)
+    if any(k != 1 for k in conv.kernel_size) or not x.is_contiguous() or \
+            int(lib.spacap_conv1x1_wgrad_slabs(B, conv.out_channels, CI, N)) == 0:
+        return None
+    return Conv1x1.apply(x, conv.weight, conv.bias)

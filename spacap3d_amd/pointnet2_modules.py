@@ -44,9 +44,14 @@ class _ConvBNReLU2d(nn.Sequential):
     def forward(self, x, pool=False):
         """conv -> BN -> ReLU; in training mode the BN -> ReLU (-> max over the last dim when ``pool``) tail is one
         fused op of the backend.  Eval mode (running statistics) uses the stock modules."""
-        z = self.conv(x)
+        from .backend import ops
+        z = None
+        if self.training:
+            f = getattr(ops(), "conv1x1", None)   # 1x1 convolution with the slab weight gradient (linear.Conv1x1)
+            z = f(x, self.conv) if f is not None else None
+        if z is None:
+            z = self.conv(x)
         if self.has_bn and self.training:
-            from .backend import ops
             S = z.size(3) if pool else None
             if not pool or S in (16, 32, 64, 128):
                 return ops().bn_relu_train(z, self.bn.bn, pool_S=S)

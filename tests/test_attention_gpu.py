@@ -267,6 +267,35 @@ def test_small_row_linears_take_the_row_panel_kernel_and_keep_their_gradients():
         assert err < 2e-5, err
 
 
+@pytest.mark.parametrize("B,CO,CI,N,dims", [(8, 256, 256, 1024, 3), (8, 256, 512, 512, 4), (2, 128, 128, 32, 3), (3, 256, 128, 96, 4),
+                                             (1, 384, 256, 2048, 3)])
+def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
+    """linear.Conv1x1 (1x1 Conv1d / Conv2d on channel-major tensors: vote net, feature-propagation MLPs): output and
+    the three gradients against float64 autograd of the same convolution."""
+    from spacap3d_amd.linear import conv1x1
+    g = torch.Generator().manual_seed(B + CO + N)
+    conv = (torch.nn.Conv1d(CI, CO, 1) if dims == 3 else torch.nn.Conv2d(CI, CO, 1, bias=False))
+    x = torch.randn(B, CI, N, generator=g) if dims == 3 else torch.randn(B, CI, N, 1, generator=g)
+    w = torch.randn(B, CO, N, generator=g) if dims == 3 else torch.randn(B, CO, N, 1, generator=g)
+    ref = type(conv)(CI, CO, 1, bias=conv.bias is not None).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    (ref(xr) * w.double()).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = conv1x1(xg, conv)
+    assert y is not None
+    assert float((y.double().cpu() - ref(xr).detach()).abs().max()) < 1e-4
+    (y * w.to(DEV)).sum().backward()
+    pairs = [(xg.grad, xr.grad), (conv.weight.grad, ref.weight.grad)] + ([(conv.bias.grad, ref.bias.grad)] if conv.bias is not None else [])
+    for got, want in pairs:
+        err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 2e-5, err
+    assert conv1x1(torch.zeros(2, CI, 33, device=DEV), torch.nn.Conv1d(CI, CO, 1).to(DEV)) is None   # N not a multiple of 32
+    with torch.no_grad():
+        assert conv1x1(xg, conv) is None
+
+
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
     """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
     gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
