@@ -390,6 +390,18 @@ int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spaca
 int spacap_linear_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int CK, int CP,
                                  float *dx, spacap_stream_t stream);
 
+/* Relation head, layers 2 and 3 (models/transformer_captioner.py:319-326, 392-397) on R = B*K*K pair rows in one pass:
+ * hid2 = relu(hid1 W2^T + b2) f32 [R,128] (kept for the backward) and pred = hid2 W3^T + b3 f32 [R,9];
+ * hid1 f32 [R,128] (the first layer's ReLU output), W2 f32 [128,128], b2 f32 [128], W3 f32 [9,128], b3 f32 [9]. */
+int spacap_rel_tail_fwd_f32(const float *hid1, const float *W2, const float *b2, const float *W3, const float *b3, long R,
+                            float *hid2, float *pred, spacap_stream_t stream);
+/* First backward stage of the same two layers, one streaming pass: dz2 = (dpred W3) * (hid2 > 0) f32 [R,128] plus
+ * part f32 [spacap_rel_tail_bwd_nparts(R)][9*128 + 128 + 16] = per-workgroup partial sums of dW3 = dpred^T hid2
+ * ([9][128]), db2 = sum_r dz2 ([128]) and db3 = sum_r dpred ([9], padded to 16); add the rows in order. */
+int spacap_rel_tail_bwd_nparts(long R);
+int spacap_rel_tail_bwd_f32(const float *dpred, const float *W3, const float *hid2, long R, float *dz2, float *part,
+                            spacap_stream_t stream);
+
 /* Weight gradient of a 1x1 convolution on channel-major tensors (vote net: models/voting_module.py:33-60; feature
  * propagation MLPs: lib/pointnet2/pointnet2_modules.py:376-421): dW[co,ci] = sum_b sum_n g[b,co,n] x[b,ci,n] with
  * g f32 [B,CO,N], x f32 [B,CI,N] (CO, CI multiples of 128, N a multiple of 32).  part f32

@@ -86,6 +86,9 @@ SIGNATURES = {
     "spacap_sum_slabs_f32": (_i, [_p, _i, _l, _p, _p]),
     "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
     "spacap_linear_dgrad_mask_f32": (_i, [_p, _p, _p, _f, _l, _i, _i, _p, _p]),
+    "spacap_rel_tail_fwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p]),
+    "spacap_rel_tail_bwd_nparts": (_i, [_l]),
+    "spacap_rel_tail_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _p]),
     "spacap_conv1x1_wgrad_slabs": (_i, [_i, _i, _i, _i]),
     "spacap_conv1x1_wgrad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_linear_rows_supported": (_i, [_l, _i, _i]),

@@ -40,6 +40,7 @@ class HipBackend:
         self.linear = _lin.linear
         self.ffn_tail = _lin.ffn_tail
         self.conv1x1 = _lin.conv1x1
+        self.relation_tail = _lin.relation_tail
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
 

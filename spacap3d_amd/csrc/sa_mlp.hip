@@ -158,10 +158,22 @@ __global__ __launch_bounds__(1024) void sa_bwd_finalize_kernel(const double *__r
 // Per 64-row tile: [prefetched registers -> BN+ReLU -> LDS] | sync | issue the next tile's loads | MFMA |
 // accumulators -> LDS (transposed staging) | sync | full-row 16-byte stores.  The loads of tile t+1 and the stores
 // of tile t are in flight while the matrix cores work on tile t.
-template <int CIN, int NT>
+// TAIL = true turns the same pipeline into the relation head's last two layers
+// (models/transformer_captioner.py:319-326, 392-397: Linear(128,128) -> ReLU -> Linear(128,9) on B*K*K pair rows):
+// rows are staged as they are (the first layer's ReLU output), the epilogue adds the bias and applies the ReLU, the
+// tile is stored (the backward needs it) and multiplied by the 9 x 128 output weights (padded to one 16-row MFMA
+// operand) while it is still in LDS.  No statistics.
+struct TailArgs {
+  const float *bias;   // [Cout]
+  const float *W3;     // [NO3][Cout]
+  const float *b3;     // [NO3]
+  float *pred;         // [R][NO3]
+  int NO3;             // <= 16
+};
+template <int CIN, int NT, bool TAIL = false>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
-                                                         float *__restrict__ zout, double *__restrict__ part) {
+                                                         float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
   constexpr int LD = CIN + 4, KS = CIN / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
   constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -175,11 +187,21 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) wf[j][ks] = W[(size_t)(cb + 16 * j + l15) * CIN + ks * 4 + lg];
   const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
-  f32x4 mean, sc, be;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sc = mean, be = mean;
+  if (!TAIL) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
-    mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+    for (int u = 0; u < 4; ++u) {
+      const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+      mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+    }
+  }
+  float wf3[TAIL ? COB / 4 : 1];
+  f32x4 bv[NT];
+  if (TAIL) {
+#pragma unroll
+    for (int ks = 0; ks < COB / 4; ++ks) wf3[TAIL ? ks : 0] = l15 < ta.NO3 ? ta.W3[(size_t)l15 * Cout + ks * 4 + lg] : 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = ld4(ta.bias + cb + 16 * j + 4 * lg);
   }
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
@@ -215,7 +237,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       const int row = r0 + i * RSTEP;
       f32x4 a;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+      for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
       if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
       st4(&s_a[row * LD + c4 * 4], a);
     }
@@ -239,10 +261,17 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        st4(&s_o[(mt * 16 + l15) * LDO + wc + 16 * j + 4 * lg], acc[mt][j]);
-        if (FULL || row0 + mt * 16 + l15 < R) {
-          ssum[j] += acc[mt][j];
-          ssq[j] += acc[mt][j] * acc[mt][j];
+        if (TAIL) {
+          f32x4 v = acc[mt][j] + bv[j];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+          st4(&s_o[(mt * 16 + l15) * LDO + wc + 16 * j + 4 * lg], v);
+        } else {
+          st4(&s_o[(mt * 16 + l15) * LDO + wc + 16 * j + 4 * lg], acc[mt][j]);
+          if (FULL || row0 + mt * 16 + l15 < R) {
+            ssum[j] += acc[mt][j];
+            ssq[j] += acc[mt][j] * acc[mt][j];
+          }
         }
       }
     __syncthreads();
@@ -250,6 +279,17 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     for (int i = 0; i < NO; ++i) {
       const int row = or0 + i * OSTEP;
       if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
+    }
+    if (TAIL) {   // wave w: rows 16 w .. 16 w + 15 of the tile times the padded output weights
+      f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < COB / 4; ++ks) a3 = MFMA16(wf3[TAIL ? ks : 0], s_o[(w * 16 + l15) * LDO + ks * 4 + lg], a3);
+      const long row = row0 + w * 16 + l15;
+      if (FULL || row < R) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * lg + u < ta.NO3) ta.pred[(size_t)row * ta.NO3 + 4 * lg + u] = a3[u] + ta.b3[4 * lg + u];
+      }
     }
   };
   const long nfull = R / TM;
@@ -267,6 +307,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     fetch(nfull);
     tile(nfull, std::false_type{}, false);
   }
+  if (TAIL) return;
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -942,7 +983,7 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   {                                                                                                                  \
     static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV>, lds);                                         \
     hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256), lds, s, zin,    \
-                       st_in, W, Cout, R, zout, part);                                                               \
+                       st_in, W, Cout, R, zout, part, TailArgs{});                                                   \
   }
   if (Cin == 64 && Cout == 64) MF(64, 1, 1)
   else if (Cin == 64 && Cout % 128 == 0) MF(64, 2, Cout / 128)
@@ -1358,6 +1399,131 @@ extern "C" int spacap_linear_dgrad_mask_f32(const float *g, const float *W, cons
   SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
   hipLaunchKernelGGL(linear_dgrad_mask_kernel, dim3((unsigned)tiles, CP / 128), dim3(256), 0, spacap::as_stream(stream), g, W, y,
                      scale, R, CP, dx);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// ===========================================================================================================
+// Relation head, layers 2 and 3 (models/transformer_captioner.py:319-326, 392-397) on R = B*K*K pair rows:
+//   hid2 = relu(hid1 W2^T + b2) [R,128],  pred = hid2 W3^T + b3 [R,NO3 = 9]
+// Forward: sa_mid_fwd_kernel<128, 2, TAIL> (one pass: read hid1, write hid2 and pred; the composition of a BLAS GEMM,
+// a ReLU pass and a second GEMM moves 5x the bytes).  Backward, first stage (this kernel): one streaming pass over
+// hid2 that produces dz2 = (dpred W3) * (hid2 > 0) and per-workgroup partial sums of dW3 = dpred^T hid2,
+// db2 = sum dz2 and db3 = sum dpred -- replacing a GEMM, a transposed GEMM, a masking pass and two column sums, each
+// a full pass over a 268 MB tensor.  dhid1 = dz2 W2 and dW2 = dz2^T hid1 stay BLAS GEMMs (MFMA-bound).
+namespace {
+constexpr int RT_NO = 9, RT_TM = 64;
+// part f32 [gridDim.x][RT_NO*128 + 128 + 16]: dW3 (row-major [9][128]), db2 [128], db3 [9 (+7 pad)]
+__global__ __launch_bounds__(256) void rel_tail_bwd_kernel(const float *__restrict__ dpred, const float *__restrict__ W3,
+                                                           const float *__restrict__ hid2, long R, float *__restrict__ dz2,
+                                                           float *__restrict__ part) {
+  constexpr int C = 128, PW = RT_NO * C + C + 16;
+  __shared__ __attribute__((aligned(16))) float s_dp[RT_TM * RT_NO];
+  __shared__ float s_red[8 * 32 * 41];
+  const int tid = threadIdx.x, c4 = tid & 31, r0 = tid >> 5;
+  float w3[RT_NO][4], aw[RT_NO][4], ab2[4] = {0.f, 0.f, 0.f, 0.f}, ab3[RT_NO];
+#pragma unroll
+  for (int o = 0; o < RT_NO; ++o) {
+    ab3[o] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[o][u] = W3[o * C + c4 * 4 + u], aw[o][u] = 0.f;
+  }
+  const long ntiles = (R + RT_TM - 1) / RT_TM;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * RT_TM;
+    __syncthreads();
+    for (int i = tid; i < RT_TM * RT_NO; i += 256) s_dp[i] = (row0 * RT_NO + i < R * RT_NO) ? dpred[row0 * RT_NO + i] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT_TM / 8; ++i) {
+      const int row = r0 + 8 * i;
+      if (row0 + row >= R) continue;
+      const f32x4 h = ld4(hid2 + (size_t)(row0 + row) * C + c4 * 4);
+      float d[RT_NO];
+#pragma unroll
+      for (int o = 0; o < RT_NO; ++o) d[o] = s_dp[row * RT_NO + o];
+      f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < RT_NO; ++o)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dz[u] = fmaf(d[o], w3[o][u], dz[u]);
+          aw[o][u] = fmaf(d[o], h[u], aw[o][u]);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dz[u] = h[u] > 0.f ? dz[u] : 0.f;
+        ab2[u] += dz[u];
+      }
+      st4(dz2 + (size_t)(row0 + row) * C + c4 * 4, dz);
+      if (c4 == 0) {
+#pragma unroll
+        for (int o = 0; o < RT_NO; ++o) ab3[o] += d[o];
+      }
+    }
+  }
+  // the 8 row groups of a column quad, added in a fixed order
+  __syncthreads();
+  float *mine = &s_red[(r0 * 32 + c4) * 41];
+#pragma unroll
+  for (int o = 0; o < RT_NO; ++o)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mine[o * 4 + u] = aw[o][u];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mine[36 + u] = ab2[u];
+  __syncthreads();
+  float *o_part = part + (size_t)blockIdx.x * PW;
+  for (int i = tid; i < 32 * 40; i += 256) {
+    const int q = i / 40, e = i % 40;
+    float a = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) a += s_red[(g * 32 + q) * 41 + e];
+    if (e < 36) o_part[(e >> 2) * C + q * 4 + (e & 3)] = a;
+    else o_part[RT_NO * C + q * 4 + (e - 36)] = a;
+  }
+  __syncthreads();
+  if (c4 == 0) {
+#pragma unroll
+    for (int o = 0; o < RT_NO; ++o) s_red[r0 * 16 + o] = ab3[o];
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float a = 0.f;
+    if (tid < RT_NO)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) a += s_red[g * 16 + tid];
+    o_part[RT_NO * C + C + tid] = a;
+  }
+}
+}  // namespace
+
+// hid1 f32 [R,128], W2 f32 [128,128], b2 f32 [128], W3 f32 [9,128], b3 f32 [9] -> hid2 f32 [R,128], pred f32 [R,9]
+extern "C" int spacap_rel_tail_fwd_f32(const float *hid1, const float *W2, const float *b2, const float *W3, const float *b3,
+                                       long R, float *hid2, float *pred, spacap_stream_t stream) {
+  const char *what = "spacap_rel_tail_fwd_f32";
+  SPACAP_REQUIRE(hid1 && W2 && b2 && W3 && b3 && hid2 && pred && R >= 1, "%s: bad arguments", what);
+  const size_t lds = (size_t)TM * ((128 + 4) + (128 + 4)) * sizeof(float);
+  const long tiles = (R + TM - 1) / TM;
+  static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
+  hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds, spacap::as_stream(stream),
+                     hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr, TailArgs{b2, W3, b3, pred, RT_NO});
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// number of partial rows the backward writes (each 9*128 + 128 + 16 floats)
+extern "C" int spacap_rel_tail_bwd_nparts(long R) {
+  const long tiles = (R + RT_TM - 1) / RT_TM;
+  return (int)(tiles < 1024 ? (tiles < 1 ? 1 : tiles) : 1024);
+}
+
+// dpred f32 [R,9], W3 f32 [9,128], hid2 f32 [R,128] -> dz2 f32 [R,128], part f32 [nparts][9*128 + 128 + 16]
+extern "C" int spacap_rel_tail_bwd_f32(const float *dpred, const float *W3, const float *hid2, long R, float *dz2, float *part,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_rel_tail_bwd_f32";
+  SPACAP_REQUIRE(dpred && W3 && hid2 && dz2 && part && R >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(rel_tail_bwd_kernel, dim3(spacap_rel_tail_bwd_nparts(R)), dim3(256), 0, spacap::as_stream(stream), dpred, W3,
+                     hid2, R, dz2, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -160,7 +160,9 @@ class ProposalModule(nn.Module):
         pm = getattr(features, "_point_major", None)   # the fused SA op's own (B,K,128) result
         data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
-        net = self.proposal(features)
+        net = features.contiguous() if self.training else features
+        for layer in self.proposal:
+            net = _conv(layer, net, self.training) if isinstance(layer, nn.Conv1d) else layer(net)
         return self.decode_scores(net, data_dict)
 
     def decode_pred_box(self, data_dict):

@@ -234,3 +234,63 @@ def conv1x1(x, conv):
             int(lib.spacap_conv1x1_wgrad_slabs(B, conv.out_channels, CI, N)) == 0:
         return None
     return Conv1x1.apply(x, conv.weight, conv.bias)
+
+
+class RelationTail(Function):
+    """pred = W3 relu(W2 hid1 + b2) + b3 on the B*K*K pair rows of the relation head
+    (models/transformer_captioner.py:319-326, 392-397; hid1 = the first layer's ReLU output, 524 288 x 128 at the
+    benchmark shape).  Forward: ONE kernel reads hid1 and writes hid2 and pred (csrc/sa_mlp.hip: sa_mid_fwd_kernel, TAIL).
+    Backward: one streaming kernel gives dz2 = (dpred W3) * (hid2 > 0) and the partial sums of dW3, db2, db3
+    (rel_tail_bwd_kernel); dhid1 = dz2 W2 and dW2 = dz2^T hid1 are MFMA-bound BLAS GEMMs (the latter cut into 64 row
+    slabs: the BLAS heuristics do not split that reduction)."""
+
+    SLABS = 64
+
+    @staticmethod
+    def forward(ctx, hid1, W2, b2, W3, b3):
+        shape = hid1.shape
+        h1 = hid1.reshape(-1, 128).contiguous()
+        R = h1.shape[0]
+        dev = h1.device
+        W2c, W3c = W2.contiguous(), W3.contiguous()
+        with torch.cuda.device(dev):
+            hid2 = torch.empty_like(h1)
+            pred = torch.empty(R, W3.shape[0], dtype=torch.float32, device=dev)
+            check(lib.spacap_rel_tail_fwd_f32(h1.data_ptr(), W2c.data_ptr(), b2.data_ptr(), W3c.data_ptr(), b3.data_ptr(), R,
+                                              hid2.data_ptr(), pred.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_rel_tail_fwd_f32")
+        ctx.save_for_backward(h1, hid2, W2c, W3c)
+        ctx.shape = shape
+        return pred.view(*shape[:-1], W3.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        h1, hid2, W2, W3 = ctx.saved_tensors
+        NO = W3.shape[0]
+        g2 = g.reshape(-1, NO).contiguous()
+        R = g2.shape[0]
+        dev = g2.device
+        with torch.cuda.device(dev):
+            nparts = int(lib.spacap_rel_tail_bwd_nparts(R))
+            PW = NO * 128 + 128 + 16
+            part = torch.empty(nparts, PW, dtype=torch.float32, device=dev)
+            dz2 = torch.empty_like(hid2)
+            check(lib.spacap_rel_tail_bwd_f32(g2.data_ptr(), W3.data_ptr(), hid2.data_ptr(), R, dz2.data_ptr(), part.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "spacap_rel_tail_bwd_f32")
+            s = sum_slabs(part)
+            dW3, db2, db3 = s[:NO * 128].view(NO, 128), s[NO * 128:NO * 128 + 128], s[NO * 128 + 128:NO * 128 + 128 + NO]
+            dh1 = (dz2 @ W2).view(ctx.shape) if ctx.needs_input_grad[0] else None
+            S = RelationTail.SLABS
+            if R % S == 0 and R >= 64 * S:
+                dW2 = sum_slabs(torch.bmm(dz2.view(S, R // S, 128).transpose(1, 2), h1.view(S, R // S, 128)).view(S, -1)).view(128, 128)
+            else:
+                dW2 = dz2.t() @ h1
+        return dh1, dW2, db2, dW3, db3
+
+
+def relation_tail(hid1, lin2, lin3):
+    """``lin3(relu(lin2(hid1)))`` for the relation head's 128 -> 128 -> 9 tail; ``None`` for other shapes."""
+    if not hid1.is_cuda or hid1.dtype != torch.float32 or tuple(lin2.weight.shape) != (128, 128) or \
+            tuple(lin3.weight.shape) != (9, 128) or lin2.bias is None or lin3.bias is None or hid1.shape[-1] != 128:
+        return None
+    return RelationTail.apply(hid1, lin2.weight, lin2.bias, lin3.weight, lin3.bias)

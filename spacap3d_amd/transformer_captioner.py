@@ -472,8 +472,11 @@ class TransformerDecoderModel(nn.Module):
         with streams.branch("relation", sa.attn):
             # feature (P (x) V) + first Linear + ReLU in one kernel: the (B,K,K,128) feature is never formed
             hid = ops().relation_layer1(sa.attn, sa.value, rp[0].weight, rp[0].bias)
-            hid = F.relu(tall_linear(hid, rp[2]))
-            ep["relation_pred"] = tall_linear(hid, rp[4])
+            tail = getattr(ops(), "relation_tail", None)
+            pred = tail(hid, rp[2], rp[4]) if (tail is not None and torch.is_grad_enabled()) else None
+            if pred is None:
+                pred = tall_linear(F.relu(tall_linear(hid, rp[2])), rp[4])
+            ep["relation_pred"] = pred
 
     def forward_eval(self, ep, use_cache=True):
         """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder AND the whole

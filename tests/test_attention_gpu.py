@@ -296,6 +296,34 @@ def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
         assert conv1x1(xg, conv) is None
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 64, 128), (1, 50, 50, 128), (8192, 128), (77, 128), (1, 128)])
+def test_relation_tail_matches_the_three_module_composition(shape):
+    """linear.RelationTail (Linear(128,128) -> ReLU -> Linear(128,9) of the relation head, one forward kernel + one
+    streaming backward kernel + two GEMMs) against float64 autograd of the nn.Module composition."""
+    from spacap3d_amd.linear import relation_tail
+    g = torch.Generator().manual_seed(sum(shape))
+    lin2, lin3 = torch.nn.Linear(128, 128), torch.nn.Linear(128, 9)
+    hid1 = torch.relu(torch.randn(*shape, generator=g))
+    w = torch.randn(*shape[:-1], 9, generator=g)
+    r2, r3 = torch.nn.Linear(128, 128).double(), torch.nn.Linear(128, 9).double()
+    r2.load_state_dict({k: v.double() for k, v in lin2.state_dict().items()})
+    r3.load_state_dict({k: v.double() for k, v in lin3.state_dict().items()})
+    hr = hid1.double().requires_grad_(True)
+    want = r3(torch.relu(r2(hr)))
+    (want * w.double()).sum().backward()
+    lin2, lin3 = lin2.to(DEV), lin3.to(DEV)
+    hg = hid1.to(DEV).requires_grad_(True)
+    got = relation_tail(hg, lin2, lin3)
+    assert got is not None and got.shape == want.shape
+    assert float((got.double().cpu() - want.detach()).abs().max()) < 2e-5
+    (got * w.to(DEV)).sum().backward()
+    for a, b in ((hg.grad, hr.grad), (lin2.weight.grad, r2.weight.grad), (lin2.bias.grad, r2.bias.grad),
+                 (lin3.weight.grad, r3.weight.grad), (lin3.bias.grad, r3.bias.grad)):
+        err = float((a.double().cpu() - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err < 3e-5, err
+    assert relation_tail(hg, torch.nn.Linear(128, 64).to(DEV), torch.nn.Linear(64, 9).to(DEV)) is None
+
+
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
     """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
     gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
