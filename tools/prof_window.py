@@ -39,6 +39,25 @@ def main():
     busy = sum(tot.values()) / 1e6 / K
     print(f"timed window: {K} steps, {wall:.2f} ms/step wall, {busy:.2f} ms/step summed kernel time, "
           f"{len(win) / K:.0f} kernels/step")
+    # idle time of the step's own stream: gaps between consecutive kernels (the side-stream sampling pyramid excluded)
+    main = sorted(e for e in win if "fps_" not in e[2])
+    idle, end, gaps = 0, main[0][1], collections.Counter()
+    for s, e, n in main[1:]:
+        if s > end:
+            idle += s - end
+            gaps[min((s - end) // 1000, 20)] += 1
+        end = max(end, e)
+    print(f"main stream: {idle / 1e6 / K:.2f} ms/step idle between kernels; gap histogram (us: count/step) "
+          + ", ".join(f"{k}{'+' if k == 20 else ''}: {v / K:.0f}" for k, v in sorted(gaps.items())))
+    big = collections.Counter()
+    end, prev = main[0][1], main[0][2]
+    for s_, e, n in main[1:]:
+        if s_ - end > 20_000:
+            big[(prev[:60], n[:60])] += s_ - end
+        if e > end:
+            end, prev = e, n
+    for (a, b), v in big.most_common(12):
+        print(f"   idle {v / 1e3 / K:7.1f} us/step between  {a}  ->  {b}")
     print("ms/step,calls/step,avg_us,kernel")
     for n, v in tot.most_common(top):
         print(f"{v / 1e6 / K:.3f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},{n[:150]}")
