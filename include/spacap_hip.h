@@ -79,6 +79,13 @@ int spacap_gather_points_grad_f32(const float *grad_out, const int32_t *idx, int
 int spacap_ball_query_f32(const float *new_xyz, const float *xyz, int B, int N, int m,
                           float radius, int nsample, int32_t *idx, spacap_stream_t stream);
 
+/* Same contract and bit-identical output through a cell grid (points binned into cells >= radius wide, only the
+ * 27 neighbouring cells of a centre are tested): for large clouds (SA1: 40 000 points).  workspace: device scratch of
+ * spacap_ball_query_grid_workspace_bytes(B, N) bytes; N <= 131 000 (hit bitmap in LDS), radius > 0. */
+size_t spacap_ball_query_grid_workspace_bytes(int B, int N);
+int spacap_ball_query_grid_f32(const float *new_xyz, const float *xyz, int B, int N, int m, float radius, int nsample,
+                               int32_t *idx, void *workspace, size_t workspace_bytes, spacap_stream_t stream);
+
 /* ---- grouping (replaces src/group_points.cpp) ------------------------------------------------ */
 
 /* group_points(points f32[B,C,N], idx i32[B,P,S]) -> f32[B,C,P,S]   (src/group_points.cpp:12-36) */

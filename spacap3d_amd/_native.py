@@ -34,6 +34,8 @@ SIGNATURES = {
     "spacap_gather_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_gather_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_ball_query_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p]),
+    "spacap_ball_query_grid_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
+    "spacap_ball_query_grid_f32": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, ctypes.c_size_t, _p]),
     "spacap_group_points_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "spacap_group_points_grad_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i, _i]),
     "spacap_group_points_grad_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),

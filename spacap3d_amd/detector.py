@@ -39,6 +39,32 @@ def sampling_pyramid(xyz, npoints=SA_NPOINTS):
     return inds_all
 
 
+SA_RADII = (0.2, 0.4, 0.8, 1.2)       # backbone_module.py:30,39,48,57
+SA_NSAMPLES = (64, 32, 16, 16)        # backbone_module.py:31,40,49,58
+
+
+def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPLES):
+    """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 tensors:
+    the four sampling index sets (``sampling_pyramid``), the four ball-query groupings of the SA modules
+    (pointnet2_modules.py:241-247) and (idx, weight) of the two feature-propagation modules' three-nearest-neighbour
+    interpolation (:399-405; fp1: SA3 points from SA4's, fp2: SA2 points from SA3's, backbone_module.py:115-119).
+    A trainer runs it for the NEXT batch on a side stream; the modules take the results through their ``inds`` /
+    ``idx`` / ``nn`` arguments and compute exactly these values themselves when they get none."""
+    from . import pointnet2_utils as pu
+    inds_all, idx_all, xyzs = [], [], [xyz]
+    cur = xyz
+    for n, r, ns in zip(npoints, radii, nsamples):
+        inds = pu.furthest_point_sample(cur, n)
+        new_xyz = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        idx_all.append(pu.ball_query(r, ns, cur, new_xyz))
+        inds_all.append(inds)
+        xyzs.append(new_xyz)
+        cur = new_xyz
+    fp1 = PointnetFPModule.neighbours(xyzs[3], xyzs[4])
+    fp2 = PointnetFPModule.neighbours(xyzs[2], xyzs[3])
+    return tuple(inds_all) + tuple(idx_all) + (fp1[0], fp1[1], fp2[0], fp2[1])
+
+
 class Pointnet2Backbone(nn.Module):
     """4 set-abstraction + 2 feature-propagation layers (backbone_module.py:28-66)."""
 
@@ -65,18 +91,21 @@ class Pointnet2Backbone(nn.Module):
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
         # optional precomputed sampling pyramid (see sampling_pyramid); None -> each SA module samples itself
-        pyr = data_dict.get("fps_pyramid") or (None, None, None, None)
-        xyz, features, fps_inds = self.sa1(xyz, features, pyr[0])
+        # (4 tensors: sampling_pyramid; 12: geometry_pyramid, which adds the groupings and interpolation weights)
+        pyr = tuple(data_dict.get("fps_pyramid") or ())
+        pyr = pyr + (None,) * (12 - len(pyr))
+        xyz, features, fps_inds = self.sa1(xyz, features, pyr[0], pyr[4])
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1])
+        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1], pyr[5])
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2])
+        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2], pyr[6])
         data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
-        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3])
+        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3], pyr[7])
         data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
-                            data_dict["sa4_features"])
-        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features)
+                            data_dict["sa4_features"], nn=(pyr[8], pyr[9]) if pyr[8] is not None else None)
+        features = self.fp2(data_dict["sa2_xyz"], data_dict["sa3_xyz"], data_dict["sa2_features"], features,
+                            nn=(pyr[10], pyr[11]) if pyr[10] is not None else None)
         data_dict["fp2_features"] = features
         data_dict["fp2_xyz"] = data_dict["sa2_xyz"]
         num_seed = data_dict["fp2_xyz"].shape[1]

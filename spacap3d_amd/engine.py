@@ -7,7 +7,7 @@ import torch
 
 from . import streams
 from . import synthetic as S
-from .detector import sampling_pyramid
+from .detector import geometry_pyramid, sampling_pyramid
 from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
 from .loss_helper import get_scene_cap_loss, start_detection_losses
 
@@ -22,6 +22,7 @@ class Trainer:
         self.bucket = None
         self.optimizer = None
         self.side_stream = None
+        self.prefetch_geometry = True   # False: prefetch the sampling indices only (sampling_pyramid)
         self.graph = None          # captured hipGraph of one training step (see enable_graph)
         self.graph_error = None
         self._static = None
@@ -50,7 +51,8 @@ class Trainer:
         cur = torch.cuda.current_stream(pc.device)
         self.side_stream.wait_stream(cur)
         with torch.cuda.stream(self.side_stream), torch.no_grad():
-            pyr = sampling_pyramid(pc[..., :3].contiguous())
+            # sampling indices + ball-query groupings + interpolation weights: all functions of the coordinates
+            pyr = (geometry_pyramid if self.prefetch_geometry else sampling_pyramid)(pc[..., :3].contiguous())
             ev = torch.cuda.Event()
             ev.record(self.side_stream)
         next_data["_fps_prefetch"] = (pyr, ev)

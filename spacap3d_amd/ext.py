@@ -132,6 +132,9 @@ def three_interpolate_grad(grad_out, idx, weight, m):
 
 
 # ---- ball_query.cpp --------------------------------------------------------------------------
+BALL_QUERY_GRID_MIN_N = 8192   # below this the exhaustive kernel is as fast as building the grid
+
+
 def ball_query(new_xyz, xyz, radius, nsample):
     _chk_contig(new_xyz, "new_xyz"); _chk_contig(xyz, "xyz")
     _chk_float(new_xyz, "new_xyz"); _chk_float(xyz, "xyz")
@@ -140,6 +143,13 @@ def ball_query(new_xyz, xyz, radius, nsample):
     N = xyz.shape[1]
     with torch.cuda.device(new_xyz.device):
         idx = torch.empty(B, m, int(nsample), dtype=torch.int32, device=new_xyz.device)
+        if BALL_QUERY_GRID_MIN_N <= N <= 131000 and B >= 1 and m >= 1 and nsample >= 1 and radius > 0:
+            # large clouds (SA1): cell grid, same output (csrc/ball_query.hip)
+            nbytes = int(lib.spacap_ball_query_grid_workspace_bytes(B, N))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=new_xyz.device)
+            check(lib.spacap_ball_query_grid_f32(new_xyz.data_ptr(), xyz.data_ptr(), B, N, m, float(radius), int(nsample),
+                                                 idx.data_ptr(), ws.data_ptr(), nbytes, _stream(new_xyz)), "ball_query_grid")
+            return idx
         check(lib.spacap_ball_query_f32(new_xyz.data_ptr(), xyz.data_ptr(), B, N, m, float(radius), int(nsample),
                                         idx.data_ptr(), _stream(new_xyz)), "ball_query")
     return idx

@@ -93,7 +93,10 @@ class PointnetSAModuleVotes(nn.Module):
             mlp_spec[0] += 3
         self.mlp_module = SharedMLP(mlp_spec, bn=bn)
 
-    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None,
+                idx: torch.Tensor = None):
+        """``inds`` (B,npoint) / ``idx`` (B,npoint,nsample): optionally precomputed sampling and grouping indices
+        (they depend on the coordinates only: detector.geometry_pyramid computes them ahead of the step)."""
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
@@ -107,7 +110,10 @@ class PointnetSAModuleVotes(nn.Module):
         else:
             xyz_flipped = xyz.transpose(1, 2).contiguous()
             new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
-        idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if idx is None:
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+        else:
+            assert idx.shape[1:] == (self.npoint, self.nsample)
         if fused is not None:
             # training step: grouping + SharedMLP + pooling as one point-major op of the backend (sa_mlp.py)
             out = fused(xyz, new_xyz, features, idx, self.mlp_module, self.radius if self.normalize_xyz else 1.0,
@@ -129,12 +135,18 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = SharedMLP(list(mlp), bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    @staticmethod
+    def neighbours(unknown, known):
+        """(idx, weight) of the three nearest known points and their normalised inverse distances (:399-405)."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        dist_recip = 1.0 / (dist + 1e-8)
+        norm = torch.sum(dist_recip, dim=2, keepdim=True)
+        return idx, dist_recip / norm
+
+    def forward(self, unknown, known, unknow_feats, known_feats, nn=None):
+        """``nn``: optionally the precomputed ``neighbours(unknown, known)`` (coordinates only)."""
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
+            idx, weight = nn if nn is not None else self.neighbours(unknown, known)
             interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

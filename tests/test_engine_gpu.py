@@ -61,6 +61,29 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
             assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (name, i, a, other)
 
 
+def test_geometry_pyramid_equals_what_the_modules_compute_themselves():
+    """detector.geometry_pyramid (sampling indices, ball-query groupings, interpolation neighbours: everything the
+    trainer prefetches on the side stream) fed through the backbone must give bit-identical features to the backbone
+    computing them in line; 9 000 points so that SA1 takes the cell-grid ball query."""
+    from spacap3d_amd.detector import Pointnet2Backbone, geometry_pyramid, sampling_pyramid
+    torch.manual_seed(0)
+    net = Pointnet2Backbone(input_feature_dim=1).to(DEV).train()
+    pc = S.scene_batch(2, 9000, seed=5).to(DEV)
+    pyr = geometry_pyramid(pc[..., :3].contiguous())
+    assert len(pyr) == 12 and pyr[4].shape == (2, 2048, 64) and pyr[11].shape == (2, 1024, 3)
+    outs = []
+    for p in (None, sampling_pyramid(pc[..., :3].contiguous()), pyr):
+        d = {"point_clouds": pc}
+        if p is not None:
+            d["fps_pyramid"] = p
+        with torch.no_grad():
+            out = net(d)
+        outs.append((out["fp2_features"].clone(), out["sa1_inds"].clone(), out["sa4_features"].clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_flat_adam_matches_torch_adam():
     """spacap3d_amd/optim.py (one launch over a flat parameter buffer) vs torch.optim.Adam with the reference's
     settings (scripts/train.py:262), 5 steps of random gradients on oddly shaped tensors."""

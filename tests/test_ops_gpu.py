@@ -84,6 +84,41 @@ def test_ball_query_bit_exact(hip_ext, oracle_ext, N, m, radius, nsample):
     assert int(want[:, -1].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("N,m,radius,nsample", BQ_CASES + [(40001, 300, 0.2, 64), (9000, 200, 0.05, 32), (20000, 64, 3.0, 64)])
+def test_ball_query_cell_grid_is_bit_exact(hip_ext, oracle_ext, monkeypatch, N, m, radius, nsample):
+    """spacap_ball_query_grid_f32 (cell grid + hit bitmap) must give the exhaustive kernel's / the oracle's rows
+    exactly, also when it is forced onto small clouds, and for centres that are not points of the cloud."""
+    from spacap3d_amd import ext
+    monkeypatch.setattr(ext, "BALL_QUERY_GRID_MIN_N", 1)
+    xyz = _scene(N, seed=N + 1)
+    inds = oracle_ext.furthest_point_sampling(xyz, m).long()
+    new_xyz = torch.gather(xyz, 1, inds.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    g = torch.Generator().manual_seed(N)
+    new_xyz[:, : m // 2] += 0.3 * radius * torch.randn(new_xyz.shape[0], m // 2, 3, generator=g)   # off-cloud centres
+    new_xyz[:, -1] += 50.0     # empty ball, far outside the grid
+    new_xyz[:, -2] = xyz.amin(1) - 0.5 * radius   # just outside the bounding box
+    want = oracle_ext.ball_query(new_xyz, xyz, radius, nsample)
+    got = hip_ext.ball_query(new_xyz.to(DEV), xyz.to(DEV), radius, nsample).cpu()
+    assert torch.equal(got, want)
+
+
+def test_ball_query_cell_grid_degenerate_clouds(hip_ext, oracle_ext, monkeypatch):
+    """Duplicated points, a cloud that is one point, and an extent so large that the cell size is set by the
+    64 x 64 x 16 cap instead of the radius."""
+    from spacap3d_amd import ext
+    monkeypatch.setattr(ext, "BALL_QUERY_GRID_MIN_N", 1)
+    g = torch.Generator().manual_seed(3)
+    base = torch.rand(2, 50, 3, generator=g)
+    dup = base.repeat(1, 40, 1)                                   # every point 40 times
+    one = torch.full((2, 300, 3), 0.25)
+    wide = torch.rand(2, 5000, 3, generator=g) * torch.tensor([300.0, 200.0, 90.0])
+    for xyz, radius, nsample in ((dup, 0.2, 64), (one, 0.1, 16), (wide, 2.0, 32)):
+        new_xyz = xyz[:, ::7].contiguous()
+        want = oracle_ext.ball_query(new_xyz, xyz.contiguous(), radius, nsample)
+        got = hip_ext.ball_query(new_xyz.to(DEV), xyz.contiguous().to(DEV), radius, nsample).cpu()
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("C,N,P,Sn", [(1, 40000, 2048, 64), (3, 40000, 2048, 64), (128, 2048, 1024, 32),
                                       (7, 300, 17, 5), (256, 1024, 256, 16)])
 def test_group_points_and_grad(hip_ext, oracle_ext, C, N, P, Sn):
