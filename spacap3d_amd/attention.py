@@ -110,6 +110,7 @@ class FusedAttention(Function):
                 out.data_ptr(), p.data_ptr() if need_p else None, lse.data_ptr(),
                 torch.cuda.current_stream(q.device).cuda_stream), "spacap_mha_fwd_f32")
         ctx.save_for_backward(q, k, v, mask_u8, bias, lse)
+        ctx.set_materialize_grads(False)   # no zero tensor for the unused second output's gradient
         ctx.meta = (mask_sb, mask_sq, dropout_p, seed, scale, need_p)
         out_v = out.transpose(1, 2)
         if need_p:
@@ -123,6 +124,8 @@ class FusedAttention(Function):
         mask_sb, mask_sq, dropout_p, seed, scale, need_p = ctx.meta
         B, h, Lq, dk = q.shape
         Lk = k.shape[2]
+        if d_out is None:   # only the attention map was used downstream
+            d_out = torch.zeros(B, h, Lq, dk, dtype=torch.float32, device=q.device)
         with torch.cuda.device(q.device):
             d_out_c = d_out.transpose(1, 2).contiguous()  # (B, Lq, h, dk)
             d_p_c = d_p.contiguous() if (need_p and d_p is not None) else None
@@ -175,6 +178,7 @@ class FusedSelfAttentionPacked(Function):
                 out.data_ptr(), p.data_ptr() if need_p else None, lse.data_ptr(),
                 torch.cuda.current_stream(qkv.device).cuda_stream), "spacap_mha_fwd_f32")
         ctx.save_for_backward(qkv, mask_u8, lse)
+        ctx.set_materialize_grads(False)   # no zero tensor for the unused second output's gradient
         ctx.meta = (h, mask_sb, mask_sq, dropout_p, seed, scale, need_p)
         if need_p:
             return out, p
@@ -190,6 +194,8 @@ class FusedSelfAttentionPacked(Function):
         dk = hd // h
         es = qkv.element_size()
         strides = (L * three_hd, dk, three_hd)
+        if d_out is None:   # only the attention map was used downstream
+            d_out = torch.zeros(B, L, hd, dtype=torch.float32, device=qkv.device)
         with torch.cuda.device(qkv.device):
             d_out_c = d_out.contiguous()
             d_p_c = d_p.contiguous() if (need_p and d_p is not None) else None

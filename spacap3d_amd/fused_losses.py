@@ -48,6 +48,7 @@ class DetectionLosses(Function):
         ctx.save_for_backward(dnet_n, dcen_n, dvote_n, inv_den)
         ctx.meta = (B, K, NSEED, int(NH), int(NS), int(NC))
         ctx.mark_non_differentiable(obj_label, obj_mask, assignment)
+        ctx.set_materialize_grads(False)   # no zero tensors for the label outputs' gradients
         return losses, obj_label, obj_mask, assignment
 
     @staticmethod
