@@ -124,6 +124,55 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
   }
 }
 
+// 512 < N <= 1 024 (the vote-aggregation sampling, 1 024 votes -> 256 proposals, sits on the step's critical path):
+// ONE wavefront per scene, 16 points per lane in registers, all coordinates also in LDS so that the new centre is an
+// LDS broadcast read instead of a dependent global load, the tie-break keys precomputed per slot, no barriers and
+// no atomics: 0.92 -> ~0.4 us per round.  Same selection rule as fps_kernel (first maximum in the reference's tree
+// order through fps_key).
+template <int TPL>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ xyz_all, int N, int m, int lg,
+                                                      int32_t *__restrict__ idx_all) {
+  __shared__ float s_xyz[64 * TPL * 3];
+  const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * N * 3;
+  int32_t *__restrict__ idxs = idx_all + (size_t)blockIdx.x * m;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < N * 3; i += 64) s_xyz[i] = xyz[i];
+  float t[TPL], px[TPL], py[TPL], pz[TPL];
+  unsigned keys[TPL];
+#pragma unroll
+  for (int i = 0; i < TPL; ++i) {
+    const int k = lane + i * 64;
+    const int kk = k < N ? k : N - 1;
+    const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+    const float mag = (x * x) + (y * y) + (z * z);
+    const bool skip = (k >= N) || ((double)mag <= 1e-3);
+    t[i] = skip ? -1.0f : 1e10f;
+    px[i] = x; py[i] = y; pz[i] = z;
+    keys[i] = fps_key(k, lg);
+  }
+  if (lane == 0) idxs[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = s_xyz[old * 3 + 0], y1 = s_xyz[old * 3 + 1], z1 = s_xyz[old * 3 + 2];
+    int lmax = __float_as_int(-1.0f);
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) {
+      const float d = sqdist(px[i], py[i], pz[i], x1, y1, z1);
+      t[i] = vmin_f32(d, t[i]);
+      lmax = max(lmax, __float_as_int(t[i]));
+    }
+    const int M = wave_max_i32(lmax);
+    unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) key = (__float_as_int(t[i]) == M) ? min(key, keys[i]) : key;
+    key = wave_min_u32(key);
+    old = (M < 0) ? 0 : fps_unkey(key, lg);  // every point skipped: the reference returns index 0
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (lane == 0) idxs[j] = old;
+  }
+}
+
 // Any N: temp lives in the caller's workspace (as in the reference), same round structure.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fps_generic_kernel(const float *__restrict__ xyz_all,
@@ -222,6 +271,11 @@ extern "C" int spacap_fps_f32(const float *xyz, int B, int N, int m, void *works
   FPS_CASE(64, 2)
   FPS_CASE(64, 4)
   FPS_CASE(64, 8)
+  if (N <= 1024) {
+    hipLaunchKernelGGL((fps_wave_kernel<16>), dim3(B), dim3(64), 0, s, xyz, N, m, lg, idx);
+    SPACAP_CHECK_LAUNCH("spacap_fps_f32(wave)");
+    return SPACAP_OK;
+  }
   FPS_CASE(256, 4)
   FPS_CASE(256, 8)
   FPS_CASE(1024, 4)

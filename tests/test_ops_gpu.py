@@ -19,7 +19,7 @@ def _scene(n, seed, B=2):
 
 
 FPS_CASES = [  # (N, m) -- every kernel variant: 1-wave, 256-thread, 1024-thread register, bucketed (NB 3..16), generic
-    (37, 37), (64, 16), (100, 30), (128, 128), (300, 64), (512, 256), (700, 100), (1024, 256), (1024, 512),
+    (37, 37), (64, 16), (100, 30), (128, 128), (300, 64), (512, 256), (513, 512), (700, 100), (1000, 1000), (1024, 256), (1024, 512),
     (2048, 1024), (3000, 200), (4096, 512), (8192, 128), (8193, 100), (10000, 256), (12288, 64), (16000, 300),
     (20000, 256), (24576, 64),
     (30000, 128), (40000, 2048), (40960, 64), (50000, 64), (65535, 48), (65536, 48), (70000, 200), (80000, 96), (81920, 40), (81921, 24),
@@ -35,7 +35,7 @@ def test_fps_bit_exact(hip_ext, oracle_ext, N, m):
     assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[0].tolist()}"
 
 
-@pytest.mark.parametrize("N,m", [(512, 128), (700, 64), (2048, 256), (5000, 300), (40000, 400)])
+@pytest.mark.parametrize("N,m", [(512, 128), (700, 64), (1024, 256), (2048, 256), (5000, 300), (40000, 400)])
 def test_fps_ties_on_a_grid(hip_ext, oracle_ext, N, m):
     """Integer-lattice points: almost every round has many exactly equal maxima, so the result is decided
     by the reference's tree tie-break (sampling_gpu.cu:59-65)."""
