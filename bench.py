@@ -120,6 +120,8 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if os.environ.get("SPACAP_SHARE_GPU") == "1":   # test knob: all ranks on the GPUs that exist (with SPACAP_DIST_BACKEND=gloo)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cfg = CFG[args.config]

@@ -22,7 +22,8 @@ def init_from_env(backend: str = None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SPACAP_DIST_BACKEND=gloo: test knob (several ranks sharing one GPU, where RCCL refuses to start)
+            backend = os.environ.get("SPACAP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":

@@ -84,6 +84,34 @@ def test_geometry_pyramid_equals_what_the_modules_compute_themselves():
             assert torch.equal(a, b)
 
 
+def test_bench_runs_with_two_ranks_sharing_the_gpu():
+    """The multi-rank path of bench.py end to end on a one-GPU box: two ranks launched exactly as the driver does
+    (torch.distributed.run), both mapped onto cuda:0 and talking gloo instead of RCCL (test knobs SPACAP_SHARE_GPU /
+    SPACAP_DIST_BACKEND).  Covers: scene sharding by rank, parameter broadcast, hipGraph of forward + backward with the
+    gradient packing, flat all-reduce and Adam outside it, barrier + max-over-ranks timing, one JSON line from rank 0."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SPACAP_SHARE_GPU="1", SPACAP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and rec["final_loss"] == rec["final_loss"]
+    assert abs(rec["value"] - 2 * 2 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]   # whole-job scenes / s
+
+
 def test_flat_adam_matches_torch_adam():
     """spacap3d_amd/optim.py (one launch over a flat parameter buffer) vs torch.optim.Adam with the reference's
     settings (scripts/train.py:262), 5 steps of random gradients on oddly shaped tensors."""
