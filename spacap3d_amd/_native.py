@@ -100,6 +100,7 @@ SIGNATURES = {
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
+    "spacap_layernorm_bwd_add_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
     "spacap_mha_fwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
                            + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p]),
     "spacap_mha_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),

@@ -278,6 +278,58 @@ def layer_norm(x, a, b, eps=1e-6):
     return FusedLayerNorm.apply(x, a, b, eps)
 
 
+class FusedLayerNormResidual(Function):
+    """(norm(x), x) for the pre-norm residual block ``x + dropout(sublayer(norm(x)))``
+    (models/transformer_captioner.py:115-123): the second output is x itself, to be used as the residual operand, so
+    that BOTH gradient paths into x arrive at this node and the backward kernel adds them while it writes dx
+    (spacap_layernorm_bwd_add_f32) -- otherwise autograd sums them with one more pass per sub-layer."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        if not x.is_cuda:
+            raise RuntimeError("CPU not supported")
+        xc = x.contiguous()
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(xc)
+            stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device)
+            check(lib.spacap_layernorm_fwd_f32(xc.data_ptr(), a.data_ptr(), b.data_ptr(), rows, D, float(eps),
+                                               y.data_ptr(), stats.data_ptr(),
+                                               torch.cuda.current_stream(x.device).cuda_stream), "spacap_layernorm_fwd_f32")
+        ctx.save_for_backward(xc, a, stats)
+        ctx.eps = float(eps)
+        ctx.set_materialize_grads(False)
+        return y, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        xc, a, stats = ctx.saved_tensors
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        if dy is None:
+            return dres, None, None, None
+        dyc = dy.contiguous()
+        add = dres.contiguous() if dres is not None else None
+        with torch.cuda.device(xc.device):
+            dx = torch.empty_like(xc)
+            da = torch.empty(D, dtype=torch.float32, device=xc.device)
+            db = torch.empty(D, dtype=torch.float32, device=xc.device)
+            ws = torch.empty(max(int(lib.spacap_layernorm_bwd_workspace_bytes(rows, D)), 16), dtype=torch.uint8,
+                             device=xc.device)
+            check(lib.spacap_layernorm_bwd_add_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(),
+                                                   add.data_ptr() if add is not None else None, rows, D, ctx.eps,
+                                                   dx.data_ptr(), da.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                   torch.cuda.current_stream(xc.device).cuda_stream),
+                  "spacap_layernorm_bwd_add_f32")
+        return dx, da, db, None
+
+
+def layer_norm_residual(x, a, b, eps=1e-6):
+    """(norm(x), residual operand) -- see FusedLayerNormResidual."""
+    return FusedLayerNormResidual.apply(x, a, b, eps)
+
+
 class RelationFeature(Function):
     """R[b,i,j,h*D+d] = P[b,h,i,j] * V[b,h,j,d]  (models/transformer_captioner.py:393-396) in one launch each way."""
 

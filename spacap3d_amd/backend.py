@@ -26,6 +26,7 @@ class HipBackend:
         self.attention = _att.attention
         self.self_attention_packed = _att.self_attention_packed
         self.layer_norm = _att.layer_norm
+        self.layer_norm_residual = _att.layer_norm_residual
         self.relation_feature = _att.relation_feature
         self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float *__restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ a,
                                                             const float *__restrict__ stats,
                                                             const float *__restrict__ dy, long rows, int D, float eps,
-                                                            float *__restrict__ dx, float *__restrict__ part) {
+                                                            float *__restrict__ dx, float *__restrict__ part,
+                                                            const float *__restrict__ addend) {
   extern __shared__ float s_part[];  // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long wave = (long)blockIdx.x * 4 + wid;
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
     const float c2 = -(s2 * r * r) / (sd * (float)(D - 1));  // 0/0 = NaN on a constant row, as autograd gives
     const float c1 = r * s1 / (float)D;
     float *dr = dx + row * D;
-    for (int j = lane; j < D; j += 64) dr[j] = r * (gr[j] * a[j]) + c2 * (xr[j] - mu) - c1;
+    for (int j = lane; j < D; j += 64)
+      dr[j] = r * (gr[j] * a[j]) + c2 * (xr[j] - mu) - c1 + (addend ? addend[row * D + j] : 0.f);
   }
   __syncthreads();
   float *out = part + (size_t)blockIdx.x * 2 * D;
@@ -121,7 +123,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__restrict__ x, const float *__restrict__ a,
                                                                 const float *__restrict__ stats,
                                                                 const float *__restrict__ dy, long rows, int D, float eps,
-                                                                float *__restrict__ dx, float *__restrict__ part) {
+                                                                float *__restrict__ dx, float *__restrict__ part,
+                                                                const float *__restrict__ addend) {
   __shared__ float s_part[4][2][NV * 64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const long row0 = ((long)blockIdx.x * 4 + wid) * BWD_RW;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float *__r
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int j = lane + 64 * i;
-      if (j < D) dr[j] = r * (g[i] * av[i]) + c2 * xc[i] - c1;
+      if (j < D) dr[j] = r * (g[i] * av[i]) + c2 * xc[i] - c1 + (addend ? addend[row * D + j] : 0.f);
     }
   }
 #pragma unroll
@@ -223,9 +226,21 @@ extern "C" size_t spacap_layernorm_bwd_workspace_bytes(long rows, int D) {
   return (size_t)((rows + per - 1) / per) * 2 * D * sizeof(float);
 }
 
+// dx = (LayerNorm backward of dy) + addend: the pre-norm residual connection x + f(norm(x)) sends the gradient of its
+// output to x twice (directly and through the norm); with `addend` = the direct part the sum needs no extra pass.
+extern "C" int spacap_layernorm_bwd_add_f32(const float *x, const float *a, const float *stats, const float *dy,
+                                            const float *addend, long rows, int D, float eps, float *dx, float *da, float *db,
+                                            void *workspace, spacap_stream_t stream);
+
 extern "C" int spacap_layernorm_bwd_f32(const float *x, const float *a, const float *stats, const float *dy, long rows,
                                         int D, float eps, float *dx, float *da, float *db, void *workspace,
                                         spacap_stream_t stream) {
+  return spacap_layernorm_bwd_add_f32(x, a, stats, dy, nullptr, rows, D, eps, dx, da, db, workspace, stream);
+}
+
+extern "C" int spacap_layernorm_bwd_add_f32(const float *x, const float *a, const float *stats, const float *dy,
+                                            const float *addend, long rows, int D, float eps, float *dx, float *da, float *db,
+                                            void *workspace, spacap_stream_t stream) {
   SPACAP_REQUIRE(rows >= 0 && D >= 2 && D <= 2048, "spacap_layernorm_bwd_f32: bad sizes rows=%ld D=%d", rows, D);
   SPACAP_REQUIRE(da && db, "spacap_layernorm_bwd_f32: null pointer");
   hipStream_t s = spacap::as_stream(stream);
@@ -239,16 +254,16 @@ extern "C" int spacap_layernorm_bwd_f32(const float *x, const float *a, const fl
   if (D <= 512) {
     const unsigned grid = (unsigned)((rows + 4 * BWD_RW - 1) / (4 * BWD_RW));
     if (D <= 128)
-      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<2>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part);
+      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<2>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part, addend);
     else if (D <= 256)
-      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<4>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part);
+      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<4>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part, addend);
     else
-      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<8>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part);
+      hipLaunchKernelGGL((layernorm_bwd_reg_kernel<8>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part, addend);
     hipLaunchKernelGGL(layernorm_bwd_reduce4_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, part, (int)grid, D, da, db);
   } else {
     const unsigned grid = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), sizeof(float) * 8 * D, s, x, a, stats, dy, rows, D,
-                       eps, dx, part);
+                       eps, dx, part, addend);
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, (int)grid, D, da, db);
   }
   SPACAP_CHECK_LAUNCH("spacap_layernorm_bwd_f32");

@@ -215,7 +215,13 @@ class SublayerConnection(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, x, sublayer):
-        y = sublayer(self.norm(x))
+        nr = getattr(ops(), "layer_norm_residual", None)
+        if nr is not None and x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+            # norm and residual operand from one node: its backward adds the two gradient paths into x itself
+            normed, x = nr(x, self.norm.a_2, self.norm.b_2, self.norm.eps)
+            y = sublayer(normed)
+        else:
+            y = sublayer(self.norm(x))
         f = getattr(ops(), "dropout_add", None)
         if f is not None and y.is_cuda:
             return f(x, y, self.dropout.p, self.dropout.training)

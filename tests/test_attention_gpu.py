@@ -324,6 +324,38 @@ def test_relation_tail_matches_the_three_module_composition(shape):
     assert relation_tail(hg, torch.nn.Linear(128, 64).to(DEV), torch.nn.Linear(64, 9).to(DEV)) is None
 
 
+@pytest.mark.parametrize("shape", [(8, 256, 128), (8, 32, 128), (3, 7, 300)])
+def test_layernorm_residual_node_adds_both_gradient_paths(att, shape):
+    """attention.FusedLayerNormResidual: (norm(x), x) from one node whose backward kernel adds the residual path's
+    gradient to the LayerNorm gradient (spacap_layernorm_bwd_add_f32); against float64 autograd of
+    x + W norm(x) with the reference's LayerNorm formula (unbiased std, eps on the std)."""
+    g = torch.Generator().manual_seed(sum(shape))
+    D = shape[-1]
+    x = torch.randn(*shape, generator=g)
+    a, b = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g)
+    W = torch.randn(D, D, generator=g) * 0.1
+    w = torch.randn(*shape, generator=g)
+
+    def ref(x_, a_, b_, W_):
+        mean, std = x_.mean(-1, keepdim=True), x_.std(-1, keepdim=True)
+        return x_ + (a_ * (x_ - mean) / (std + 1e-6) + b_) @ W_.t()
+    xr, ar, br, Wr = (t.double().requires_grad_(True) for t in (x, a, b, W))
+    (ref(xr, ar, br, Wr) * w.double()).sum().backward()
+    xg, ag, bg, Wg = (t.to(DEV).requires_grad_(True) for t in (x, a, b, W))
+    normed, res = att.layer_norm_residual(xg, ag, bg, 1e-6)
+    out = res + normed @ Wg.t()
+    assert float((out.double().cpu() - ref(xr, ar, br, Wr).detach()).abs().max()) < 1e-4
+    (out * w.to(DEV)).sum().backward()
+    for got, want in ((xg.grad, xr.grad), (ag.grad, ar.grad), (bg.grad, br.grad), (Wg.grad, Wr.grad)):
+        err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 1e-4, err
+    # only the residual output used / only the normed output used
+    x2 = x.to(DEV).requires_grad_(True)
+    n2, r2 = att.layer_norm_residual(x2, ag.detach(), bg.detach(), 1e-6)
+    (r2 * w.to(DEV)).sum().backward()
+    assert torch.allclose(x2.grad, w.to(DEV))
+
+
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
     """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
     gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
