@@ -1160,20 +1160,31 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
     for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const long ntiles = (R + TW - 1) / TW;
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  // register pipeline: the next tile's rows are in flight while this tile's MFMAs run (a workgroup per CU has nobody
+  // else to hide the load latency behind)
+  f32x4 pa[TW / 8], pb[TW / 8];
+  auto fetch = [&](long t) {
     const long row0 = t * TW;
 #pragma unroll
     for (int i = 0; i < TW / 8; ++i) {
       const int row = r0 + 8 * i;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + row < R) {
-        a = ld4(g + (size_t)(row0 + row) * CK + ck0 + c4 * 4);
-        b = ld4(x + (size_t)(row0 + row) * CP + cp0 + c4 * 4);
+      pa[i] = pb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < ntiles && row0 + row < R) {
+        pa[i] = ld4(g + (size_t)(row0 + row) * CK + ck0 + c4 * 4);
+        pb[i] = ld4(x + (size_t)(row0 + row) * CP + cp0 + c4 * 4);
       }
-      st4(&s_g[row * LDG + c4 * 4], a);
-      st4(&s_x[row * LDG + c4 * 4], b);
+    }
+  };
+  fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < TW / 8; ++i) {
+      const int row = r0 + 8 * i;
+      st4(&s_g[row * LDG + c4 * 4], pa[i]);
+      st4(&s_x[row * LDG + c4 * 4], pb[i]);
     }
     __syncthreads();
+    fetch(t + gridDim.x);
 #pragma unroll
     for (int ks = 0; ks < TW / 4; ++ks) {
       float af[2];
