@@ -127,6 +127,11 @@ int spacap_three_interpolate_f32(const float *points, const int32_t *idx, const 
 int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
                                       const float *weight, int B, int C, int n, int m,
                                       float *grad_points, spacap_stream_t stream);
+/* The same gradient with POINT-MAJOR operands: grad_pm f32 [B,n,C] -> grad_points_pm f32 [B,m,C] (same summation
+ * order and values as spacap_three_interpolate_grad_f32 on the transposed tensors; contiguous C-float rows instead
+ * of one element per 4 KB row). */
+int spacap_three_interpolate_grad_pm_f32(const float *grad_pm, const int32_t *idx, const float *weight, int B, int C,
+                                         int n, int m, float *grad_points_pm, spacap_stream_t stream);
 
 /* ---- attention (replaces models/transformer_captioner.py:27-37) ------------------------------ */
 

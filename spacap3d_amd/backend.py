@@ -21,7 +21,7 @@ class HipBackend:
         self._ext = ext
         for n in ("gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
                   "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
-                  "group_points_grad", "group_max", "group_max_grad"):
+                  "group_points_grad", "group_max", "group_max_grad", "three_interpolate_grad_pm"):
             setattr(self, n, getattr(ext, n))
         self.attention = _att.attention
         self.self_attention_packed = _att.self_attention_packed

@@ -131,6 +131,19 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     return out
 
 
+def three_interpolate_grad_pm(grad_pm, idx, weight, m):
+    """Point-major form of ``three_interpolate_grad``: grad_pm (B,n,C) -> (B,m,C), same values."""
+    _chk_contig(grad_pm, "grad_pm"); _chk_contig(idx, "idx"); _chk_contig(weight, "weight")
+    _chk_float(grad_pm, "grad_pm"); _chk_float(weight, "weight")
+    _chk_gpu(grad_pm, "grad_pm"); _chk_gpu(idx, "idx", grad_pm); _chk_gpu(weight, "weight", grad_pm)
+    B, n, C = grad_pm.shape
+    with torch.cuda.device(grad_pm.device):
+        out = torch.empty(B, int(m), C, dtype=torch.float32, device=grad_pm.device)
+        check(lib.spacap_three_interpolate_grad_pm_f32(grad_pm.data_ptr(), idx.data_ptr(), weight.data_ptr(), B, C, n, int(m),
+                                                       out.data_ptr(), _stream(grad_pm)), "three_interpolate_grad_pm")
+    return out
+
+
 # ---- ball_query.cpp --------------------------------------------------------------------------
 BALL_QUERY_GRID_MIN_N = 8192   # below this the exhaustive kernel is as fast as building the grid
 

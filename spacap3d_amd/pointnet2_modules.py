@@ -147,7 +147,10 @@ class PointnetFPModule(nn.Module):
         """``nn``: optionally the precomputed ``neighbours(unknown, known)`` (coordinates only)."""
         if known is not None:
             idx, weight = nn if nn is not None else self.neighbours(unknown, known)
-            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
+            if self.training and torch.is_grad_enabled():
+                interpolated = pointnet2_utils.three_interpolate_train(known_feats, idx, weight)
+            else:
+                interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated

@@ -81,6 +81,35 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class ThreeInterpolatePM(Function):
+    """``three_interpolate`` whose backward gathers on point-major gradients (ext.three_interpolate_grad_pm).
+    ``features``: (B,C,m) channel-major, or -- ``point_major=True`` -- the (B,m,C) tensor an SA module produced, in
+    which case the gradient goes back in that layout too and no transposed copies are made for it."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight, point_major):
+        cm = features.transpose(1, 2).contiguous() if point_major else features.contiguous()
+        ctx.m, ctx.point_major = cm.size(2), point_major
+        ctx.save_for_backward(idx, weight)
+        return ops().three_interpolate(cm, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        g = ops().three_interpolate_grad_pm(grad_out.transpose(1, 2).contiguous(), idx, weight, ctx.m)   # (B,m,C)
+        return (g if ctx.point_major else g.transpose(1, 2)), None, None, None
+
+
+def three_interpolate_train(features, idx, weight):
+    """Training-path interpolation: point-major gradient gather when the backend has it (same values)."""
+    if getattr(ops(), "three_interpolate_grad_pm", None) is None or not features.is_cuda:
+        return three_interpolate(features.contiguous(), idx, weight)
+    pm = getattr(features, "_point_major", None)
+    if pm is not None:
+        return ThreeInterpolatePM.apply(pm, idx, weight, True)
+    return ThreeInterpolatePM.apply(features, idx, weight, False)
+
+
 class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):

@@ -84,6 +84,38 @@ def test_ball_query_bit_exact(hip_ext, oracle_ext, N, m, radius, nsample):
     assert int(want[:, -1].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("C,n,m", [(256, 1024, 512), (256, 512, 256), (5, 70, 9), (64, 300, 1), (130, 33, 200)])
+def test_three_interpolate_point_major_gradient_is_the_same_gather(hip_ext, oracle_ext, C, n, m):
+    """spacap_three_interpolate_grad_pm_f32 on the transposed gradient gives the transposed result of
+    spacap_three_interpolate_grad_f32 / the oracle, bit for bit (same lists, same (n, k) order); and
+    pointnet2_utils.three_interpolate_train routes both layouts of the features correctly."""
+    from spacap3d_amd import pointnet2_utils as pu
+    g = torch.Generator().manual_seed(C + n)
+    B = 2
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32)
+    idx[:, : n // 2, 0] = 0                       # one very popular known point (beyond the list capacity when n is large)
+    w = torch.rand(B, n, 3, generator=g)
+    go = torch.randn(B, C, n, generator=g)
+    want = oracle_ext.three_interpolate_grad(go, idx, w, m)
+    got_cm = hip_ext.three_interpolate_grad(go.to(DEV), idx.to(DEV), w.to(DEV), m)
+    got_pm = hip_ext.three_interpolate_grad_pm(go.transpose(1, 2).contiguous().to(DEV), idx.to(DEV), w.to(DEV), m)
+    assert torch.equal(got_cm.cpu(), want)
+    assert torch.equal(got_pm.transpose(1, 2).cpu(), want)
+    feats = torch.randn(B, C, m, generator=g)
+    for layout in ("channel", "point"):
+        f = feats.to(DEV).requires_grad_(True)
+        if layout == "point":
+            pm = f.transpose(1, 2).contiguous()
+            view = pm.transpose(1, 2)
+            view._point_major = pm
+            out = pu.three_interpolate_train(view, idx.to(DEV), w.to(DEV))
+        else:
+            out = pu.three_interpolate_train(f, idx.to(DEV), w.to(DEV))
+        assert torch.equal(out.detach().cpu(), oracle_ext.three_interpolate(feats, idx, w))
+        (out * go.to(DEV)).sum().backward()
+        assert torch.equal(f.grad.cpu(), want)
+
+
 @pytest.mark.parametrize("N,m,radius,nsample", BQ_CASES + [(40001, 300, 0.2, 64), (9000, 200, 0.05, 32), (20000, 64, 3.0, 64)])
 def test_ball_query_cell_grid_is_bit_exact(hip_ext, oracle_ext, monkeypatch, N, m, radius, nsample):
     """spacap_ball_query_grid_f32 (cell grid + hit bitmap) must give the exhaustive kernel's / the oracle's rows
