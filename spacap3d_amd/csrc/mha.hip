@@ -50,15 +50,28 @@ struct MhaArgs {
   long g_sl;                        // row stride (floats) of dq / dk / dv: h * d_k when dense
 };
 
-__device__ __forceinline__ bool keep_elem(const MhaArgs &A, int b, int hh, int q, int key) {
+// Dropout keep decision of element (b, head, q, key): a counter hash (murmur3 fmix32 over the element index mixed
+// with both words of the seed), the same function in forward and backward.  The seed = host seed + device-resident
+// step counter is formed once per kernel (drop_seed): a 64-bit splitmix finaliser per element cost ~10 us of VALU time
+// in each of the three kernels of an encoder layer.
+struct DropSeed {
+  unsigned lo, hi;
+};
+__device__ __forceinline__ DropSeed drop_seed(const MhaArgs &A) {
+  const unsigned long long s = A.seed + (A.seed_dev ? *A.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+  return DropSeed{(unsigned)s, (unsigned)(s >> 32)};
+}
+__device__ __forceinline__ bool keep_elem(const MhaArgs &A, DropSeed sd, int b, int hh, int q, int key) {
   if (A.drop_thresh == 0u) return true;
-  const unsigned long long sd = A.seed + (A.seed_dev ? *A.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
-  unsigned long long x = ((((unsigned long long)b * A.h + hh) * A.Lq + q) * (unsigned long long)A.Lk + key) ^ sd;
-  x += 0x9E3779B97F4A7C15ull;  // splitmix64 finaliser
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (unsigned)(x >> 32) >= A.drop_thresh;
+  const unsigned long long idx = (((unsigned long long)b * A.h + hh) * A.Lq + q) * (unsigned long long)A.Lk + key;
+  unsigned h = (unsigned)idx ^ sd.lo;
+  h += ((unsigned)(idx >> 32) ^ sd.hi) * 0x9E3779B1u;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h >= A.drop_thresh;
 }
 
 // logit of (q, key) from the raw dot product: scale, optional bias, key mask (-1e9), padding (-inf)
@@ -81,6 +94,7 @@ __device__ __forceinline__ float logit(const MhaArgs &A, float dot, int b, int h
 // ------------------------------------------------------------------------------------------------
 template <int NT, int DK>
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int q0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float pv = acc[t][r] / l;
-      if (!keep_elem(A, b, hh, q, 16 * t + 4 * lg + r)) pv = 0.f; else pv *= A.keep_scale;
+      if (!keep_elem(A, sd, b, hh, q, 16 * t + 4 * lg + r)) pv = 0.f; else pv *= A.keep_scale;
       p[r] = pv;
     }
     acc[t] = p;
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs A) {
 // ------------------------------------------------------------------------------------------------
 template <int NT, int DK>
 __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   const int lane = threadIdx.x;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int q0 = blockIdx.x * 16;
@@ -237,7 +252,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
         const float pr = (key < A.Lk) ? expf(s - m) * inv_l : 0.f;
         float g = dp[t][r];
         if (dprow && key < A.Lk) g += dprow[key];
-        g = keep_elem(A, b, hh, q, key) ? g * A.keep_scale : 0.f;  // dP (pre-dropout)
+        g = keep_elem(A, sd, b, hh, q, key) ? g * A.keep_scale : 0.f;  // dP (pre-dropout)
         delta += g * pr;
         p[t][r] = pr;
         dp[t][r] = (masked || key >= A.Lk) ? NAN : g;  // NaN marks "no gradient to the logit"
@@ -282,6 +297,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
 // ------------------------------------------------------------------------------------------------
 template <int DK>
 __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   const int lane = threadIdx.x;
   const int b = blockIdx.z, hh = blockIdx.y;
   const int key0 = blockIdx.x * 16;
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
       const float pr = valid ? expf(s - stb[qc * 2]) / stb[qc * 2 + 1] : 0.f;
       float g = g4[r];
       if (A.d_p && valid) g += A.d_p[(((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk + kc];
-      const bool keep = keep_elem(A, b, hh, q, key);
+      const bool keep = keep_elem(A, sd, b, hh, q, key);
       g = keep ? g * A.keep_scale : 0.f;
       const float pd = keep ? pr * A.keep_scale : 0.f;
       const float ds = (masked || !valid) ? 0.f : pr * (g - delb[qc]) * A.scale;
@@ -366,6 +382,7 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
 // ------------------------------------------------------------------------------------------------
 template <int NTW, int DK>  // NTW key tiles per wave, 4 waves: Lk <= 64 * NTW
 __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   __shared__ float s_m[4][16], s_l[4][16];
   __shared__ float s_o[4][16][DK + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float pv = acc[tt][r] / l;
-      if (!keep_elem(A, b, hh, q, 16 * (t0 + tt) + 4 * lg + r)) pv = 0.f; else pv *= A.keep_scale;
+      if (!keep_elem(A, sd, b, hh, q, 16 * (t0 + tt) + 4 * lg + r)) pv = 0.f; else pv *= A.keep_scale;
       p[r] = pv;
     }
     acc[tt] = p;
@@ -482,6 +499,7 @@ __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
 
 template <int NTW, int DK>
 __global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   __shared__ float s_d[4][16];
   __shared__ float s_o[4][16][DK + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) 
         const float pr = (key < A.Lk) ? expf(s - m) * inv_l : 0.f;
         float g = dp[tt][r];
         if (dprow && key < A.Lk) g += dprow[key];
-        g = keep_elem(A, b, hh, q, key) ? g * A.keep_scale : 0.f;
+        g = keep_elem(A, sd, b, hh, q, key) ? g * A.keep_scale : 0.f;
         delta += g * pr;
         p[tt][r] = pr;
         dp[tt][r] = (masked || key >= A.Lk) ? NAN : g;
@@ -579,6 +597,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) 
 // dK / dV: 16 keys per workgroup, the query tiles interleaved over the 4 waves
 template <int DK>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A) {
+  const DropSeed sd = drop_seed(A);
   __shared__ float s_k[4][16][DK + 1], s_v[4][16][DK + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
@@ -626,7 +645,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A)
       const float pr = valid ? expf(s - stb[qc * 2]) / stb[qc * 2 + 1] : 0.f;
       float g = g4[r];
       if (A.d_p && valid) g += A.d_p[(((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk + kc];
-      const bool keep = keep_elem(A, b, hh, q, key);
+      const bool keep = keep_elem(A, sd, b, hh, q, key);
       g = keep ? g * A.keep_scale : 0.f;
       const float pd = keep ? pr * A.keep_scale : 0.f;
       const float ds = (masked || !valid) ? 0.f : pr * (g - delb[qc]) * A.scale;
