@@ -59,13 +59,14 @@ __device__ __forceinline__ float huber1(float err, float &grad) {  // delta = 1 
 
 // cross-entropy over C logits with stride 1; writes (softmax - onehot) * scale into g
 __device__ __forceinline__ float ce_grad(const float *s, int C, int label, float scale, float *g) {
+  const float s_label = s[label];   // read first: g may alias s (rows staged in LDS are overwritten in place)
   float m = s[0];
   for (int c = 1; c < C; ++c) m = fmaxf(m, s[c]);
   float l = 0.f;
   for (int c = 0; c < C; ++c) l += expf(s[c] - m);
   const float lse = m + logf(l);
   for (int c = 0; c < C; ++c) g[c] = (expf(s[c] - lse) - (c == label ? 1.f : 0.f)) * scale;
-  return lse - s[label];
+  return lse - s_label;
 }
 
 __device__ float block_sum(float v, float *s_red) {  // 256 threads, fixed order
@@ -77,14 +78,21 @@ __device__ float block_sum(float v, float *s_red) {  // 256 threads, fixed order
   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// STAGED: the scene's K x CH head outputs are copied into LDS with coalesced loads, every thread works on its own row
+// there (rows are CH floats apart: a per-thread walk over a row in global memory touches 64 cache lines per load
+// instruction), the gradient numerators overwrite the row in place and leave with coalesced stores.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void det_proposal_kernel(const DetArgs A) {
   extern __shared__ float smem[];
   float *s_gt = smem;                 // [M][3]
   float *s_c = s_gt + 3 * A.M;        // [K][3] predicted centres
   int *s_i2 = reinterpret_cast<int *>(s_c + 3 * A.K);  // [M] nearest proposal of every gt box
   float *s_w2 = reinterpret_cast<float *>(s_i2 + A.M); // [M] box mask
+  float *s_net = s_w2 + A.M;          // [K][CH] (STAGED only)
   __shared__ float s_red[4];
   const int b = blockIdx.x, tid = threadIdx.x, K = A.K, M = A.M, CH = A.CH;
+  if (STAGED)
+    for (int i = tid; i < K * CH; i += 256) s_net[i] = A.net[(size_t)b * K * CH + i];
   for (int i = tid; i < 3 * M; i += 256) s_gt[i] = A.gt_center[(size_t)b * M * 3 + i];
   for (int i = tid; i < 3 * K; i += 256) s_c[i] = A.center[(size_t)b * K * 3 + i];
   for (int j = tid; j < M; j += 256) s_w2[j] = A.box_mask[(size_t)b * M + j];
@@ -124,8 +132,8 @@ __global__ __launch_bounds__(256) void det_proposal_kernel(const DetArgs A) {
     A.assignment[bk] = i1;
     n_obj += obj;
     n_mask += mask;
-    const float *row = A.net + bk * CH;
-    float *g = A.dnet + bk * CH;
+    const float *row = STAGED ? s_net + (size_t)k * CH : A.net + bk * CH;
+    float *g = STAGED ? s_net + (size_t)k * CH : A.dnet + bk * CH;
     // objectness: weighted 2-class cross-entropy
     num_obj += ce_grad(row, 2, label, (label ? A.w1 : A.w0) * mask, g) * (label ? A.w1 : A.w0) * mask;
     g[2] = g[3] = g[4] = 0.f;  // centre offsets: their gradient arrives through `center`
@@ -162,15 +170,20 @@ __global__ __launch_bounds__(256) void det_proposal_kernel(const DetArgs A) {
     const int sl = (int)A.size_cls_label[bj];
     num_sc += ce_grad(row + o_ss, A.NS, sl, obj, g + o_ss) * obj;
     float sr = 0.f;
+    const float res[3] = {row[o_sr + 3 * sl], row[o_sr + 3 * sl + 1], row[o_sr + 3 * sl + 2]};   // (g may alias row)
     for (int c = 0; c < 3 * A.NS; ++c) g[o_sr + c] = 0.f;
     for (int d = 0; d < 3; ++d) {
       float sg;
-      sr += huber1(row[o_sr + 3 * sl + d] - A.size_res_label[bj * 3 + d] / A.mean_size[3 * sl + d], sg);
+      sr += huber1(res[d] - A.size_res_label[bj * 3 + d] / A.mean_size[3 * sl + d], sg);
       g[o_sr + 3 * sl + d] = sg * obj / 3.0f;
     }
     num_sr += sr / 3.0f * obj;
     // semantic class
     num_sem += ce_grad(row + o_sem, A.NC, (int)A.sem_cls_label[bj], obj, g + o_sem) * obj;
+  }
+  if (STAGED) {
+    __syncthreads();
+    for (int i = tid; i < K * CH; i += 256) A.dnet[(size_t)b * K * CH + i] = s_net[i];
   }
   float *p = A.part + (size_t)b * NPARTL;
   const float v[NPARTL] = {0.f, num_obj, num_c1, num_c2, num_hc, num_hr, num_sc, num_sr, num_sem, n_obj, n_mask, n_box};
@@ -399,7 +412,18 @@ extern "C" int spacap_det_losses_fwd_f32(
   hipStream_t s = spacap::as_stream(stream);
   const size_t lds = sizeof(float) * (3 * (size_t)M + 3 * (size_t)K + 2 * (size_t)M);
   SPACAP_REQUIRE(lds <= 60000, "%s: K=%d too large", what, K);
-  hipLaunchKernelGGL(det_proposal_kernel, dim3(B), dim3(256), lds, s, A);
+  const size_t lds_staged = lds + sizeof(float) * (size_t)K * A.CH;
+  if (lds_staged <= 150 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&det_proposal_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), what);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(det_proposal_kernel<true>, dim3(B), dim3(256), lds_staged, s, A);
+  } else {
+    hipLaunchKernelGGL(det_proposal_kernel<false>, dim3(B), dim3(256), lds, s, A);
+  }
   float *vpart = part + (size_t)B * NPARTL;
   hipLaunchKernelGGL(det_vote_kernel, dim3(B), dim3(256), 0, s, seed_xyz, vote_xyz, seed_inds, vote_label, vote_mask, NSEED, N,
                      dvote_num, vpart);
