@@ -69,7 +69,7 @@ class DetectionLosses(Function):
 
 
 def detection_losses(d, num_heading_bin, num_size_cluster, mean_size_f32, near_thr, far_thr, w):
-    """The 12-tuple ``loss_helper.start_detection_losses`` stores, from the fused op.  ``d`` must hold the proposal
+    """The 12-tuple ``loss_helper.start_detection_losses`` stores (last entry, box_loss: None), from the fused op.  ``d`` must hold the proposal
     head's raw output rows ``_proposal_net`` (B,K,CH) next to the decoded entries."""
     losses, label, mask, oa = DetectionLosses.apply(
         d["_proposal_net"], d["center"], d["vote_xyz"], d["aggregated_vote_xyz"], d["center_label"], d["box_label_mask"],
@@ -77,8 +77,9 @@ def detection_losses(d, num_heading_bin, num_size_cluster, mean_size_f32, near_t
         d["sem_cls_label"], mean_size_f32, d["seed_xyz"], d["seed_inds"], d["vote_label"], d["vote_label_mask"],
         num_heading_bin, num_size_cluster, near_thr, far_thr, w[0], w[1])
     vote, objn, center, hcls, hreg, scls, sreg, sem = losses.unbind(0)
-    box = center + 0.1 * hcls + hreg + 0.1 * scls + sreg
-    return vote, objn, label, mask, oa, center, hcls, hreg, scls, sreg, sem, box
+    # box_loss (= center + 0.1 * hcls + hreg + 0.1 * scls + sreg) is left to the caller: loss_helper folds it into
+    # the one matrix-vector product that also forms det_loss and the total
+    return vote, objn, label, mask, oa, center, hcls, hreg, scls, sreg, sem, None
 
 
 class RelationLoss(Function):

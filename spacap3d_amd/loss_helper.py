@@ -213,6 +213,10 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         start_detection_losses(d, num_heading_bin, num_size_cluster, mean_size_arr)
     (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment, center_loss, heading_cls_loss,
      heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss, box_loss) = d.pop("_detection_losses")
+    # every derived sum in one matrix-vector product at the end (see below)
+    fast = detection and caption and use_relation and vote_loss.is_cuda
+    if box_loss is None and not fast:   # the fused detection-loss op leaves the box sum to this function
+        box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
     if caption:
         d["cap_loss"], d["cap_acc"] = compute_cap_loss(d)
     else:
@@ -234,7 +238,8 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         frel = getattr(ops(), "relation_losses", None) if d["relation_pred"].is_cuda else None
         rel = frel(d) if frel is not None else compute_relation_loss(d)
         d.update(rel)
-        d["relation_loss"] = rel["y_loss"] + rel["z_loss"] + rel["x_loss"]
+        if not fast:
+            d["relation_loss"] = rel["y_loss"] + rel["z_loss"] + rel["x_loss"]
     else:
         for k in ("x_loss", "y_loss", "z_loss", "relation_loss", "x_acc", "y_acc", "z_acc"):
             d[k] = zero
@@ -248,6 +253,13 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     if not detection:
         d["det_loss"] = zero
 
+    if fast:
+        # box_loss, det_loss, relation_loss and the total (lib/loss_helper.py:340-383) as ONE 4 x 12 matrix-vector
+        # product over the stacked terms instead of ~17 scalar kernels forward and as many backward
+        t = torch.stack([d[k] for k in _TERMS])
+        box, det, rel_sum, total_loss = (_const("loss_matrix", dev, _loss_matrix) @ t).unbind(0)
+        d["box_loss"], d["det_loss"], d["relation_loss"], d["loss"] = box, det, rel_sum, total_loss
+        return d
     loss = 0
     if detection:
         d["det_loss"] = d["vote_loss"] + 0.5 * d["objectness_loss"] + d["box_loss"] + 0.1 * d["sem_cls_loss"]
@@ -258,3 +270,16 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         loss = loss + 0.1 * d["relation_loss"]
     d["loss"] = loss
     return d
+
+
+_TERMS = ("vote_loss", "objectness_loss", "center_loss", "heading_cls_loss", "heading_reg_loss", "size_cls_loss",
+          "size_reg_loss", "sem_cls_loss", "cap_loss", "x_loss", "y_loss", "z_loss")
+
+
+def _loss_matrix():
+    """rows: box_loss (lib/loss_helper.py:340), det_loss (:372), relation_loss (:366), loss (:373-383) over _TERMS."""
+    box = torch.tensor([0, 0, 1, 0.1, 1, 0.1, 1, 0, 0, 0, 0, 0], dtype=torch.float64)
+    det = box + torch.tensor([1, 0.5, 0, 0, 0, 0, 0, 0.1, 0, 0, 0, 0], dtype=torch.float64)
+    rel = torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1], dtype=torch.float64)
+    cap = torch.tensor([0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=torch.float64)
+    return torch.stack([box, det, rel, 10 * det + cap + 0.1 * rel]).float()
