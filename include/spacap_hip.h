@@ -400,6 +400,11 @@ int spacap_rel_loss_bwd_f32(const float *dnum, const float *grad_losses, const f
 /* out[i] = sum_s part[s][i] in ascending s: the second stage of the split reductions (weight-gradient slabs, partial
  * bias sums).  part f32 [nslab, n] dense, n a multiple of 4, pointers 16-byte aligned. */
 int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spacap_stream_t stream);
+/* nseg independent slab sums in one launch (same values as nseg calls of spacap_sum_slabs_f32): parts[i] f32
+ * [nslabs[i]][n[i]] -> outs[i] f32 [n[i]].  parts / outs / n / nslabs are HOST arrays (read before the call returns);
+ * the segment table is passed to the kernel by value, so the launch is capturable in a hipGraph. */
+int spacap_sum_slabs_batched_f32(const float *const *parts, float *const *outs, const long *n, const int *nslabs, int nseg,
+                                 spacap_stream_t stream);
 
 /* Feed-forward block, backward of w_2(dropout(relu(.))) w.r.t. the hidden pre-activation in one launch:
  * dx[r,n] = (y[r,n] > 0) ? scale * sum_k g[r,k] W[k,n] : 0 with g f32 [R,128] (gradient of the block output), W f32

@@ -87,6 +87,7 @@ SIGNATURES = {
     "spacap_rel_loss_fwd_f32": (_i, [_p] * 7 + [_i] * 3 + [_p] * 3 + [_p]),
     "spacap_rel_loss_bwd_f32": (_i, [_p] * 3 + [_i] * 2 + [_p, _p]),
     "spacap_sum_slabs_f32": (_i, [_p, _i, _l, _p, _p]),
+    "spacap_sum_slabs_batched_f32": (_i, [_p, _p, _p, _p, _i, _p]),
     "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
     "spacap_linear_dgrad_mask_f32": (_i, [_p, _p, _p, _f, _l, _i, _i, _p, _p]),
     "spacap_rel_tail_fwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p]),
@@ -136,15 +137,60 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
-def sum_slabs(part):
+_DEFERRED = None   # pending (part, out) pairs while a deferred_slab_sums() block is active
+
+
+class deferred_slab_sums:
+    """While active, ``sum_slabs(part, deferrable=True)`` only allocates its result and queues the reduction;
+    ``flush()`` then runs ALL queued reductions in one launch (spacap_sum_slabs_batched_f32).  For a training step's
+    backward pass: the ~70 weight-gradient slab sums are only read by the optimizer, so they can wait until the
+    backward is over (the engine wraps ``loss.backward()`` in this and flushes before it touches the gradients).
+    Call sites mark a sum deferrable only when its result is handed to autograd as a leaf gradient untouched."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self._prev, self.items = _DEFERRED, []
+        _DEFERRED = self.items
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        _DEFERRED = self._prev
+        if exc[0] is None:
+            self.flush()
+        return False
+
+    def flush(self):
+        import torch
+        items, self.items[:] = list(self.items), []
+        by_dev = {}
+        for part, out in items:
+            by_dev.setdefault(part.device, []).append((part, out))
+        for dev, group in by_dev.items():
+            k = len(group)
+            parts = (ctypes.c_void_p * k)(*[p.data_ptr() for p, _ in group])
+            outs = (ctypes.c_void_p * k)(*[o.data_ptr() for _, o in group])
+            ns = (ctypes.c_long * k)(*[o.numel() for _, o in group])
+            nsl = (ctypes.c_int * k)(*[p.shape[0] for p, _ in group])
+            with torch.cuda.device(dev):
+                check(lib.spacap_sum_slabs_batched_f32(parts, outs, ns, nsl, k, torch.cuda.current_stream(dev).cuda_stream),
+                      "spacap_sum_slabs_batched_f32")
+
+
+def sum_slabs(part, deferrable=False):
     """part (nslab, ...) float32 contiguous -> sum over dim 0 in ascending order (csrc/elementwise.hip); falls back to
-    torch.sum when the row size is not a multiple of 4."""
+    torch.sum when the row size is not a multiple of 4.  ``deferrable``: see ``deferred_slab_sums``."""
     import torch
     n = part[0].numel()
     if part.shape[0] == 1:
         return part[0]
     if not part.is_cuda or n % 4 or part.dtype != torch.float32 or not part.is_contiguous():
         return part.sum(0)
+    if deferrable and _DEFERRED is not None and part.data_ptr() % 16 == 0:
+        with torch.cuda.device(part.device):
+            out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        _DEFERRED.append((part, out))
+        return out
     with torch.cuda.device(part.device):
         out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
         check(lib.spacap_sum_slabs_f32(part.data_ptr(), part.shape[0], n, out.data_ptr(),

@@ -213,6 +213,73 @@ __global__ __launch_bounds__(256) void sum_slabs_kernel(const float *__restrict_
 }
 }  // namespace
 
+// Many slab sums in ONE launch: a training step produces ~70 of them (one per Linear / 1x1 convolution weight
+// gradient), each a few microseconds of mostly launch latency.  The segment table travels by value in the kernel
+// arguments (no device-side table to copy, so the launch can be captured in a hipGraph as it is); a workgroup finds
+// its segment by binary search over the first-block prefix and then does exactly what sum_slabs_kernel does (same
+// slab grouping, same order: identical values).
+namespace {
+constexpr int SLAB_SEG_MAX = 96;
+struct SlabSeg {
+  const float *part;
+  float *out;
+  long n4;
+  int nslab, block0;
+};
+struct SlabTable {
+  int nseg, pad;
+  SlabSeg seg[SLAB_SEG_MAX];
+};
+__global__ __launch_bounds__(256) void sum_slabs_batched_kernel(const SlabTable T) {
+  __shared__ f32x4 s[4][64];
+  int lo = 0, hi = T.nseg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.seg[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SlabSeg sg = T.seg[lo];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long i = (long)((int)blockIdx.x - sg.block0) * 64 + c;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < sg.n4) {
+    const int per = (sg.nslab + 3) / 4, s0 = grp * per, s1 = min(sg.nslab, s0 + per);
+#pragma unroll 8
+    for (int k = s0; k < s1; ++k) a += *reinterpret_cast<const f32x4 *>(sg.part + ((size_t)k * sg.n4 + i) * 4);
+  }
+  s[grp][c] = a;
+  __syncthreads();
+  if (grp == 0 && i < sg.n4) *reinterpret_cast<f32x4 *>(sg.out + 4 * i) = (s[0][c] + s[1][c]) + (s[2][c] + s[3][c]);
+}
+}  // namespace
+
+// nseg independent slab sums: parts[i] f32 [nslabs[i]][n[i]] -> outs[i] f32 [n[i]] (each n a multiple of 4, pointers
+// 16-byte aligned).  parts / outs / n / nslabs are HOST arrays, read before the call returns.
+extern "C" int spacap_sum_slabs_batched_f32(const float *const *parts, float *const *outs, const long *n, const int *nslabs,
+                                            int nseg, spacap_stream_t stream) {
+  const char *what = "spacap_sum_slabs_batched_f32";
+  SPACAP_REQUIRE(nseg >= 0 && (nseg == 0 || (parts && outs && n && nslabs)), "%s: bad arguments", what);
+  hipStream_t st = spacap::as_stream(stream);
+  for (int base = 0; base < nseg; base += SLAB_SEG_MAX) {
+    SlabTable T;
+    T.nseg = 0, T.pad = 0;
+    long blocks = 0;
+    for (int i = base; i < nseg && T.nseg < SLAB_SEG_MAX; ++i) {
+      SPACAP_REQUIRE(nslabs[i] >= 1 && n[i] >= 0 && (n[i] & 3) == 0 && parts[i] && outs[i] &&
+                         ((reinterpret_cast<uintptr_t>(parts[i]) | reinterpret_cast<uintptr_t>(outs[i])) & 15) == 0,
+                     "%s: segment %d: bad size or unaligned pointer", what, i);
+      if (n[i] == 0) continue;
+      SlabSeg &sg = T.seg[T.nseg++];
+      sg.part = parts[i], sg.out = outs[i], sg.n4 = n[i] >> 2, sg.nslab = nslabs[i], sg.block0 = (int)blocks;
+      blocks += (sg.n4 + 63) / 64;
+      SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
+    }
+    if (T.nseg == 0) continue;
+    hipLaunchKernelGGL(sum_slabs_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, st, T);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // part f32 [nslab][n] dense (n a multiple of 4, 16-byte aligned) -> out f32 [n]
 extern "C" int spacap_sum_slabs_f32(const float *part, int nslab, long n, float *out, spacap_stream_t stream) {
   SPACAP_REQUIRE(nslab >= 1 && n >= 0 && (n & 3) == 0, "spacap_sum_slabs_f32: bad sizes (nslab=%d, n=%ld)", nslab, n);

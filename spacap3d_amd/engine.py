@@ -131,7 +131,14 @@ class Trainer:
             advance_rng(pc.device)  # new attention-dropout masks every step, also under graph replay
         self.bucket.zero()
         d = self.loss(data_dict)
-        d["loss"].backward()
+        if pc.is_cuda:
+            # the ~70 weight-gradient slab sums of the backward are only read by the optimizer: queue them and run them
+            # as ONE launch when the backward is over (spacap3d_amd/_native.py: deferred_slab_sums)
+            from ._native import deferred_slab_sums
+            with deferred_slab_sums():
+                d["loss"].backward()
+        else:
+            d["loss"].backward()
         if pc.is_cuda:
             streams.join_all(pc.device)  # side-stream branches (relation head, detection losses) re-join here
         streams.enable(False)            # the switch is process-wide: do not leak it to callers outside the step

@@ -75,7 +75,7 @@ class FusedLinear(Function):
             part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
             check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
                                               torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-            s = sum_slabs(part)
+            s = sum_slabs(part, deferrable=True)
         return dx, s[:CK * CP].view(CK, CP), s[CK * CP:]
 
 
@@ -125,7 +125,7 @@ class FFNTail(Function):
                 part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=dev)
                 check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), y2.data_ptr(), R, CK, CP, 1, part.data_ptr(), st),
                       "spacap_linear_wgrad_f32")
-                s = sum_slabs(part)
+                s = sum_slabs(part, deferrable=True)
                 dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         return dh.view_as(y), dw, db, None, None
 
@@ -168,7 +168,7 @@ class PackedLinear(Function):
                 part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
                 check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
                                                   torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-                s = sum_slabs(part)
+                s = sum_slabs(part, deferrable=True)
             dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         a, b, _ = ctx.split
         return (dx, None, None, dw[:a], dw[a:a + b], dw[a + b:], db[:a], db[a:a + b], db[a + b:])
@@ -218,7 +218,7 @@ class Conv1x1(Function):
             part = torch.empty(nslab, CO * CI, dtype=torch.float32, device=g.device)
             check(lib.spacap_conv1x1_wgrad_f32(g.data_ptr(), x.data_ptr(), B, CO, CI, N, part.data_ptr(),
                                                torch.cuda.current_stream(g.device).cuda_stream), "spacap_conv1x1_wgrad_f32")
-            dw = (sum_slabs(part) if nslab > 1 else part[0]).view_as(weight)
+            dw = (sum_slabs(part, deferrable=True) if nslab > 1 else part[0]).view_as(weight)
         db = g.sum(dim=[0] + list(range(2, g.dim()))) if ctx.has_bias else None
         return dx, dw, db
 
@@ -277,12 +277,13 @@ class RelationTail(Function):
             dz2 = torch.empty_like(hid2)
             check(lib.spacap_rel_tail_bwd_f32(g2.data_ptr(), W3.data_ptr(), hid2.data_ptr(), R, dz2.data_ptr(), part.data_ptr(),
                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_rel_tail_bwd_f32")
-            s = sum_slabs(part)
+            s = sum_slabs(part, deferrable=True)
             dW3, db2, db3 = s[:NO * 128].view(NO, 128), s[NO * 128:NO * 128 + 128], s[NO * 128 + 128:NO * 128 + 128 + NO]
             dh1 = (dz2 @ W2).view(ctx.shape) if ctx.needs_input_grad[0] else None
             S = RelationTail.SLABS
             if R % S == 0 and R >= 64 * S:
-                dW2 = sum_slabs(torch.bmm(dz2.view(S, R // S, 128).transpose(1, 2), h1.view(S, R // S, 128)).view(S, -1)).view(128, 128)
+                dW2 = sum_slabs(torch.bmm(dz2.view(S, R // S, 128).transpose(1, 2), h1.view(S, R // S, 128)).view(S, -1),
+                                deferrable=True).view(128, 128)
             else:
                 dW2 = dz2.t() @ h1
         return dh1, dW2, db2, dW3, db3

@@ -105,7 +105,7 @@ class _SAMLP(Function):
             pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
             check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
                                           z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-            dW3 = sum_slabs(pw)
+            dW3 = sum_slabs(pw, deferrable=True)
             dy2 = torch.empty(R, C2, **f32)
             check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
                                           W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
@@ -115,7 +115,7 @@ class _SAMLP(Function):
             pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)
             check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
                                           st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-            dW2 = sum_slabs(pw)
+            dW2 = sum_slabs(pw, deferrable=True)
             fuse_l1 = (not ctx.has_Y) and (not ctx.need_xyz) and C1 == 64 and C2 == 64
             if fuse_l1:
                 # SA1: the first layer's weight gradient comes out of this kernel's epilogue as three sums

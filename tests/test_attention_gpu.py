@@ -356,6 +356,42 @@ def test_layernorm_residual_node_adds_both_gradient_paths(att, shape):
     assert torch.allclose(x2.grad, w.to(DEV))
 
 
+def test_deferred_slab_sums_give_the_same_gradients_in_one_launch():
+    """_native.deferred_slab_sums: inside the block the weight-gradient slab sums are queued, the block's exit runs them
+    as one batched launch; the gradients must equal the immediate path bit for bit (same kernel arithmetic), and a sum
+    that is not marked deferrable must still be computed on the spot."""
+    from spacap3d_amd._native import deferred_slab_sums, sum_slabs
+    from spacap3d_amd.linear import conv1x1, linear
+    g = torch.Generator().manual_seed(21)
+    lins = [torch.nn.Linear(128, 384), torch.nn.Linear(384, 128), torch.nn.Linear(128, 2048), torch.nn.Linear(2048, 128)]
+    conv = torch.nn.Conv1d(256, 256, 1)
+    x0 = torch.randn(8, 256, 128, generator=g)
+    c0 = torch.randn(8, 256, 1024, generator=g)
+    res = []
+    for deferred in (False, True):
+        mods = [type(m)(m.in_features, m.out_features).to(DEV) for m in lins]
+        for a, b in zip(mods, lins):
+            a.load_state_dict(b.state_dict())
+        cv = torch.nn.Conv1d(256, 256, 1).to(DEV)
+        cv.load_state_dict(conv.state_dict())
+        x = x0.to(DEV)
+        for m in mods:
+            x = linear(x, m.weight, m.bias)
+        loss = x.sum() + conv1x1(c0.to(DEV).requires_grad_(True), cv).square().sum()
+        if deferred:
+            with deferred_slab_sums() as q:
+                loss.backward()
+                assert len(q.items) >= 5
+                part = torch.randn(8, 1024, device=DEV)
+                assert torch.equal(sum_slabs(part), sum_slabs(part, deferrable=False))   # immediate inside the block
+            assert len(q.items) == 0
+        else:
+            loss.backward()
+        res.append([p.grad.clone() for m in mods + [cv] for p in m.parameters()])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
     """linear.PackedLinear: q | k | v weights adjacent in one flat buffer are read as ONE (3d, d) matrix; the
     gradient slices must reach the three parameters exactly as three separate nn.Linear would (float64 check), and
