@@ -242,7 +242,10 @@ size_t spacap_layernorm_bwd_workspace_bytes(long rows, int D);
 int spacap_layernorm_bwd_f32(const float *x, const float *a, const float *stats, const float *dy, long rows,
                              int D, float eps, float *dx, float *da, float *db, void *workspace,
                              spacap_stream_t stream);
-/* Same, plus an addend: dx = (LayerNorm backward of dy) + addend (f32, x's shape; may be null).  For the pre-norm
+/* (da and db may both be null: the caller then adds up the workgroup partials left in `workspace`, f32 [blocks][2*D]
+ * with blocks = spacap_layernorm_bwd_workspace_bytes(rows, D) / (8*D), rows of [da | db] -- e.g. batched with other
+ * slab sums.)
+ * Same, plus an addend: dx = (LayerNorm backward of dy) + addend (f32, x's shape; may be null).  For the pre-norm
  * residual x + f(norm(x)) (models/transformer_captioner.py:115-123), whose output gradient reaches x twice. */
 int spacap_layernorm_bwd_add_f32(const float *x, const float *a, const float *stats, const float *dy, const float *addend,
                                  long rows, int D, float eps, float *dx, float *da, float *db, void *workspace,

@@ -235,6 +235,36 @@ def attention(query, key, value, mask=None, dropout_p=0.0, training=False, need_
     return out, (second if need_p else None)
 
 
+def _ln_backward(xc, a, stats, dyc, add, eps):
+    """dx, da, db of the LayerNorm; the (da, db) column sums over the workgroup partials go through ``sum_slabs``
+    (same 4-group order as the library's own reduction kernel) so that a training step can batch them with the
+    weight-gradient sums (deferred_slab_sums)."""
+    from ._native import sum_slabs
+    D = xc.shape[-1]
+    rows = xc.numel() // D
+    with torch.cuda.device(xc.device):
+        dx = torch.empty_like(xc)
+        nbytes = int(lib.spacap_layernorm_bwd_workspace_bytes(rows, D))
+        if D <= 512 and D % 2 == 0 and nbytes >= 8 * D:
+            part = torch.empty(nbytes // (8 * D), 2 * D, dtype=torch.float32, device=xc.device)
+            check(lib.spacap_layernorm_bwd_add_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(),
+                                                   add.data_ptr() if add is not None else None, rows, D, eps,
+                                                   dx.data_ptr(), None, None, part.data_ptr(),
+                                                   torch.cuda.current_stream(xc.device).cuda_stream),
+                  "spacap_layernorm_bwd_add_f32")
+            s = sum_slabs(part, deferrable=True)
+            return dx, s[:D], s[D:]
+        da = torch.empty(D, dtype=torch.float32, device=xc.device)
+        db = torch.empty(D, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=xc.device)
+        check(lib.spacap_layernorm_bwd_add_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(),
+                                               add.data_ptr() if add is not None else None, rows, D, eps,
+                                               dx.data_ptr(), da.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                               torch.cuda.current_stream(xc.device).cuda_stream),
+              "spacap_layernorm_bwd_add_f32")
+    return dx, da, db
+
+
 class FusedLayerNorm(Function):
     """a * (x - mean) / (std_unbiased + eps) + b  (models/transformer_captioner.py:102-113) in one launch
     forward and two backward (spacap_layernorm_*_f32)."""
@@ -259,18 +289,7 @@ class FusedLayerNorm(Function):
     @staticmethod
     def backward(ctx, dy):
         xc, a, stats = ctx.saved_tensors
-        D = xc.shape[-1]
-        rows = xc.numel() // D
-        dyc = dy.contiguous()
-        with torch.cuda.device(xc.device):
-            dx = torch.empty_like(xc)
-            da = torch.empty(D, dtype=torch.float32, device=xc.device)
-            db = torch.empty(D, dtype=torch.float32, device=xc.device)
-            ws = torch.empty(max(int(lib.spacap_layernorm_bwd_workspace_bytes(rows, D)), 16), dtype=torch.uint8,
-                             device=xc.device)
-            check(lib.spacap_layernorm_bwd_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(), rows, D,
-                                               ctx.eps, dx.data_ptr(), da.data_ptr(), db.data_ptr(), ws.data_ptr(),
-                                               torch.cuda.current_stream(xc.device).cuda_stream), "spacap_layernorm_bwd_f32")
+        dx, da, db = _ln_backward(xc, a, stats, dy.contiguous(), None, ctx.eps)
         return dx, da, db, None
 
 
@@ -305,23 +324,9 @@ class FusedLayerNormResidual(Function):
     @staticmethod
     def backward(ctx, dy, dres):
         xc, a, stats = ctx.saved_tensors
-        D = xc.shape[-1]
-        rows = xc.numel() // D
         if dy is None:
             return dres, None, None, None
-        dyc = dy.contiguous()
-        add = dres.contiguous() if dres is not None else None
-        with torch.cuda.device(xc.device):
-            dx = torch.empty_like(xc)
-            da = torch.empty(D, dtype=torch.float32, device=xc.device)
-            db = torch.empty(D, dtype=torch.float32, device=xc.device)
-            ws = torch.empty(max(int(lib.spacap_layernorm_bwd_workspace_bytes(rows, D)), 16), dtype=torch.uint8,
-                             device=xc.device)
-            check(lib.spacap_layernorm_bwd_add_f32(xc.data_ptr(), a.data_ptr(), stats.data_ptr(), dyc.data_ptr(),
-                                                   add.data_ptr() if add is not None else None, rows, D, ctx.eps,
-                                                   dx.data_ptr(), da.data_ptr(), db.data_ptr(), ws.data_ptr(),
-                                                   torch.cuda.current_stream(xc.device).cuda_stream),
-                  "spacap_layernorm_bwd_add_f32")
+        dx, da, db = _ln_backward(xc, a, stats, dy.contiguous(), dres.contiguous() if dres is not None else None, ctx.eps)
         return dx, da, db, None
 
 

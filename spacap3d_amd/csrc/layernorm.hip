@@ -242,11 +242,16 @@ extern "C" int spacap_layernorm_bwd_add_f32(const float *x, const float *a, cons
                                             const float *addend, long rows, int D, float eps, float *dx, float *da, float *db,
                                             void *workspace, spacap_stream_t stream) {
   SPACAP_REQUIRE(rows >= 0 && D >= 2 && D <= 2048, "spacap_layernorm_bwd_f32: bad sizes rows=%ld D=%d", rows, D);
-  SPACAP_REQUIRE(da && db, "spacap_layernorm_bwd_f32: null pointer");
+  // da == db == null: the caller reduces the workgroup partials in `workspace` ([blocks][2*D], blocks =
+  // spacap_layernorm_bwd_workspace_bytes / (8*D)) itself -- e.g. batched with other slab sums (spacap_sum_slabs_*)
+  SPACAP_REQUIRE((da && db) || (!da && !db), "spacap_layernorm_bwd_f32: da / db must both be given or both be null");
+  const bool reduce = da != nullptr;
   hipStream_t s = spacap::as_stream(stream);
   if (rows == 0) {
-    SPACAP_CHECK_HIP(hipMemsetAsync(da, 0, sizeof(float) * D, s), "spacap_layernorm_bwd_f32");
-    SPACAP_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * D, s), "spacap_layernorm_bwd_f32");
+    if (reduce) {
+      SPACAP_CHECK_HIP(hipMemsetAsync(da, 0, sizeof(float) * D, s), "spacap_layernorm_bwd_f32");
+      SPACAP_CHECK_HIP(hipMemsetAsync(db, 0, sizeof(float) * D, s), "spacap_layernorm_bwd_f32");
+    }
     return SPACAP_OK;
   }
   SPACAP_REQUIRE(x && a && stats && dy && dx && workspace, "spacap_layernorm_bwd_f32: null pointer");
@@ -259,12 +264,14 @@ extern "C" int spacap_layernorm_bwd_add_f32(const float *x, const float *a, cons
       hipLaunchKernelGGL((layernorm_bwd_reg_kernel<4>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part, addend);
     else
       hipLaunchKernelGGL((layernorm_bwd_reg_kernel<8>), dim3(grid), dim3(256), 0, s, x, a, stats, dy, rows, D, eps, dx, part, addend);
-    hipLaunchKernelGGL(layernorm_bwd_reduce4_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, part, (int)grid, D, da, db);
+    if (reduce)
+      hipLaunchKernelGGL(layernorm_bwd_reduce4_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, s, part, (int)grid, D, da, db);
   } else {
     const unsigned grid = (unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid), dim3(256), sizeof(float) * 8 * D, s, x, a, stats, dy, rows, D,
                        eps, dx, part, addend);
-    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, (int)grid, D, da, db);
+    if (reduce)
+      hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, s, part, (int)grid, D, da, db);
   }
   SPACAP_CHECK_LAUNCH("spacap_layernorm_bwd_f32");
   return SPACAP_OK;
