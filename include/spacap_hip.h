@@ -320,6 +320,12 @@ int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int N
 int spacap_linear_wgrad_slabs(long R, int CK, int CP);
 int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
                             spacap_stream_t stream);
+/* njobs independent weight gradients in ONE launch (same values as njobs calls of spacap_linear_wgrad_f32).  All
+ * arrays are HOST arrays read before the call returns; the job table is passed to the kernel by value (capturable in a
+ * hipGraph).  For the end of a backward pass: only the optimizer reads these gradients. */
+int spacap_linear_wgrad_batched_f32(const float *const *g, const float *const *x, const long *R, const int *CK,
+                                    const int *CP, const int *with_bias, float *const *part, int njobs,
+                                    spacap_stream_t stream);
 
 /* ---- fused elementwise pieces of the Transformer sublayers (csrc/elementwise.hip) -----------------------------
  * Dropout as torch.nn.Dropout (keep with probability 1-p, kept values scaled by 1/(1-p)); the keep mask is a

@@ -99,6 +99,7 @@ SIGNATURES = {
     "spacap_linear_rows_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
+    "spacap_linear_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
@@ -137,7 +138,7 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
 
 
-_DEFERRED = None   # pending (part, out) pairs while a deferred_slab_sums() block is active
+_DEFERRED = None   # the active deferred_slab_sums() block, if any
 
 
 class deferred_slab_sums:
@@ -149,8 +150,10 @@ class deferred_slab_sums:
 
     def __enter__(self):
         global _DEFERRED
-        self._prev, self.items = _DEFERRED, []
-        _DEFERRED = self.items
+        self._prev = _DEFERRED
+        self.items = []   # (part, out): slab sums to run
+        self.jobs = []    # (g2, x2, with_bias, part): weight gradients (linear_wgrad_partials) that fill queued partials
+        _DEFERRED = self
         return self
 
     def __exit__(self, *exc):
@@ -162,7 +165,22 @@ class deferred_slab_sums:
 
     def flush(self):
         import torch
-        items, self.items[:] = list(self.items), []
+        jobs, self.jobs = self.jobs, []
+        if jobs:   # first the weight gradients themselves (one launch), then the sums over their slabs
+            by_dev = {}
+            for j in jobs:
+                by_dev.setdefault(j[0].device, []).append(j)
+            for dev, group in by_dev.items():
+                k = len(group)
+                arr = lambda ct, vals: (ct * k)(*vals)
+                with torch.cuda.device(dev):
+                    check(lib.spacap_linear_wgrad_batched_f32(
+                        arr(ctypes.c_void_p, [j[0].data_ptr() for j in group]), arr(ctypes.c_void_p, [j[1].data_ptr() for j in group]),
+                        arr(ctypes.c_long, [j[0].shape[0] for j in group]), arr(ctypes.c_int, [j[0].shape[1] for j in group]),
+                        arr(ctypes.c_int, [j[1].shape[1] for j in group]), arr(ctypes.c_int, [int(j[2]) for j in group]),
+                        arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]), k, torch.cuda.current_stream(dev).cuda_stream),
+                        "spacap_linear_wgrad_batched_f32")
+        items, self.items = self.items, []
         by_dev = {}
         for part, out in items:
             by_dev.setdefault(part.device, []).append((part, out))
@@ -186,13 +204,36 @@ def sum_slabs(part, deferrable=False):
         return part[0]
     if not part.is_cuda or n % 4 or part.dtype != torch.float32 or not part.is_contiguous():
         return part.sum(0)
-    if deferrable and _DEFERRED is not None and part.data_ptr() % 16 == 0:
+    if deferrable and _DEFERRED is not None and part.data_ptr() % 16 == 0:   # (a 1-slab result returned above is
+        # filled by its deferred weight-gradient job, if it has one)
         with torch.cuda.device(part.device):
             out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
-        _DEFERRED.append((part, out))
+        _DEFERRED.items.append((part, out))
         return out
     with torch.cuda.device(part.device):
         out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
         check(lib.spacap_sum_slabs_f32(part.data_ptr(), part.shape[0], n, out.data_ptr(),
                                        torch.cuda.current_stream(part.device).cuda_stream), "spacap_sum_slabs_f32")
     return out
+
+
+def linear_wgrad_partials(g2, x2, with_bias, deferrable=False):
+    """Per-slab partials of dW = g2^T x2 (+ db = column sums of g2) for g2 (R, CK), x2 (R, CP) dense float32 on the GPU:
+    (nslab, CK*CP [+ CK]) to be summed over dim 0, or None when the shape has no kernel.  Inside a
+    ``deferred_slab_sums`` block with ``deferrable=True`` the kernel is only queued: all queued weight gradients run as
+    one launch at the flush, before the slab sums -- the caller must then hand the result to ``sum_slabs(...,
+    deferrable=True)`` untouched."""
+    import torch
+    R, CK = g2.shape
+    CP = x2.shape[1]
+    nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
+    if nslab == 0:
+        return None
+    with torch.cuda.device(g2.device):
+        part = torch.empty(nslab, CK * CP + (CK if with_bias else 0), dtype=torch.float32, device=g2.device)
+        if deferrable and _DEFERRED is not None:
+            _DEFERRED.jobs.append((g2, x2, bool(with_bias), part))
+            return part
+        check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1 if with_bias else 0, part.data_ptr(),
+                                          torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
+    return part

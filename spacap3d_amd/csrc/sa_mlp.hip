@@ -1143,14 +1143,15 @@ extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, i
 // gradient falls out of the same staged tile as one more MFMA column against a constant 1), summed in slab order
 // by the caller.
 namespace {
+// (bx, gx): slab index / number of slabs; by, bz: 128-wide blocks of CK and CP
 template <bool WITH_BIAS>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CK,
-                                                           int CP, long R, float *__restrict__ part) {
+__device__ __forceinline__ void linear_wgrad_body(const float *__restrict__ g, const float *__restrict__ x, int CK, int CP,
+                                                  long R, float *__restrict__ part, int bx, int by, int bz, int gx) {
   constexpr int CB = 128, LDG = CB + 16;
   __shared__ __attribute__((aligned(16))) float s_g[TW * LDG];
   __shared__ __attribute__((aligned(16))) float s_x[TW * LDG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int ck0 = blockIdx.y * CB, cp0 = blockIdx.z * CB;
+  const int ck0 = by * CB, cp0 = bz * CB;
   const int c4 = tid & 31, r0 = tid >> 5;  // 32 float4 per 128-wide row, 8 rows per pass
   f32x4 acc[2][8], accb[2];
 #pragma unroll
@@ -1175,8 +1176,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
       }
     }
   };
-  fetch(blockIdx.x);
-  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  fetch(bx);
+  for (long t = bx; t < ntiles; t += gx) {
 #pragma unroll
     for (int i = 0; i < TW / 8; ++i) {
       const int row = r0 + 8 * i;
@@ -1184,7 +1185,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
       st4(&s_x[row * LDG + c4 * 4], pb[i]);
     }
     __syncthreads();
-    fetch(t + gridDim.x);
+    fetch(t + gx);
 #pragma unroll
     for (int ks = 0; ks < TW / 4; ++ks) {
       float af[2];
@@ -1204,7 +1205,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
     __syncthreads();
   }
   // partial layout per slab: [CK][CP] weights, then [CK] bias
-  float *o = part + (size_t)blockIdx.x * ((size_t)CK * CP + (WITH_BIAS ? CK : 0));
+  float *o = part + (size_t)bx * ((size_t)CK * CP + (WITH_BIAS ? CK : 0));
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1212,12 +1213,45 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restri
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         o[(size_t)(ck0 + (w * 2 + m) * 16 + 4 * lg + u) * CP + cp0 + n * 16 + l15] = acc[m][n][u];
-  if (WITH_BIAS && blockIdx.z == 0 && l15 == 0) {
+  if (WITH_BIAS && bz == 0 && l15 == 0) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int u = 0; u < 4; ++u) o[(size_t)CK * CP + ck0 + (w * 2 + m) * 16 + 4 * lg + u] = accb[m][u];
   }
+}
+template <bool WITH_BIAS>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CK,
+                                                           int CP, long R, float *__restrict__ part) {
+  linear_wgrad_body<WITH_BIAS>(g, x, CK, CP, R, part, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Many weight gradients in ONE launch: the backward of a training step produces ~50 of them, most far too small to
+// fill the chip (the decoder's: 8 slabs x 1 - 16 blocks) and each a launch of its own; nothing but the optimizer
+// reads them, so they can all run together when the backward is over.  Job table by value in the kernel arguments
+// (hipGraph-capturable as it is); a workgroup finds its job by binary search over the first-block prefix.
+constexpr int WG_JOB_MAX = 72;
+struct WgradJob {
+  const float *g, *x;
+  float *part;
+  long R;
+  int CK, CP, gx, gy, with_bias, block0;
+};
+struct WgradTable {
+  int njobs, pad;
+  WgradJob job[WG_JOB_MAX];
+};
+__global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const WgradTable T) {
+  int lo = 0, hi = T.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.job[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradJob J = T.job[lo];
+  const int local = (int)blockIdx.x - J.block0;
+  const int bx = local % J.gx, by = (local / J.gx) % J.gy, bz = local / (J.gx * J.gy);
+  if (J.with_bias) linear_wgrad_body<true>(J.g, J.x, J.CK, J.CP, J.R, J.part, bx, by, bz, J.gx);
+  else linear_wgrad_body<false>(J.g, J.x, J.CK, J.CP, J.R, J.part, bx, by, bz, J.gx);
 }
 }  // namespace
 
@@ -1242,6 +1276,36 @@ extern "C" int spacap_linear_wgrad_f32(const float *g, const float *x, long R, i
   const dim3 grid(nslab, CK / 128, CP / 128);
   if (with_bias) hipLaunchKernelGGL((linear_wgrad_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
   else hipLaunchKernelGGL((linear_wgrad_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// njobs independent weight gradients in one launch (same values as njobs calls of spacap_linear_wgrad_f32 with the
+// same arguments).  All arrays are HOST arrays, read before the call returns; part[i] must hold
+// spacap_linear_wgrad_slabs(R[i], CK[i], CP[i]) partial results.
+extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const float *const *x, const long *R, const int *CK,
+                                               const int *CP, const int *with_bias, float *const *part, int njobs,
+                                               spacap_stream_t stream) {
+  const char *what = "spacap_linear_wgrad_batched_f32";
+  SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (g && x && R && CK && CP && with_bias && part)), "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  int i = 0;
+  while (i < njobs) {
+    WgradTable T;
+    T.njobs = 0, T.pad = 0;
+    long blocks = 0;
+    for (; i < njobs && T.njobs < WG_JOB_MAX; ++i) {
+      const int nslab = spacap_linear_wgrad_slabs(R[i], CK[i], CP[i]);
+      SPACAP_REQUIRE(nslab > 0 && g[i] && x[i] && part[i], "%s: job %d: (R=%ld, CK=%d, CP=%d) unsupported or null pointer", what,
+                     i, R[i], CK[i], CP[i]);
+      WgradJob &J = T.job[T.njobs++];
+      J.g = g[i], J.x = x[i], J.part = part[i], J.R = R[i], J.CK = CK[i], J.CP = CP[i];
+      J.gx = nslab, J.gy = CK[i] / 128, J.with_bias = with_bias[i], J.block0 = (int)blocks;
+      blocks += (long)nslab * (CK[i] / 128) * (CP[i] / 128);
+      SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
+    }
+    hipLaunchKernelGGL(linear_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+  }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._native import check, lib, sum_slabs
+from ._native import check, lib, linear_wgrad_partials, sum_slabs
 
 
 def rows_product(a2, W, bias, trans_w):
@@ -67,15 +67,10 @@ class FusedLinear(Function):
         x2 = x.reshape(-1, CP)
         R = g2.shape[0]
         dx = _data_gradient(g2, weight).view_as(x) if ctx.needs_input_grad[0] else None
-        nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP)) if g2.is_cuda else 0
-        if nslab == 0:
+        part = linear_wgrad_partials(g2.contiguous(), x2.contiguous(), True, deferrable=True) if g2.is_cuda else None
+        if part is None:
             return dx, g2.t() @ x2, g2.sum(0)
-        g2, x2 = g2.contiguous(), x2.contiguous()
-        with torch.cuda.device(g2.device):
-            part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
-            check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
-                                              torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-            s = sum_slabs(part, deferrable=True)
+        s = sum_slabs(part, deferrable=True)
         return dx, s[:CK * CP].view(CK, CP), s[CK * CP:]
 
 
@@ -118,13 +113,10 @@ class FFNTail(Function):
             dh = torch.empty_like(y2)
             check(lib.spacap_linear_dgrad_mask_f32(g2.data_ptr(), weight.contiguous().data_ptr(), y2.data_ptr(), scale, R, CK,
                                                    CP, dh.data_ptr(), st), "spacap_linear_dgrad_mask_f32")
-            nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
-            if nslab == 0:
+            part = linear_wgrad_partials(g2, y2.contiguous(), True, deferrable=True)
+            if part is None:
                 dw, db = g2.t() @ y2, g2.sum(0)
             else:
-                part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=dev)
-                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), y2.data_ptr(), R, CK, CP, 1, part.data_ptr(), st),
-                      "spacap_linear_wgrad_f32")
                 s = sum_slabs(part, deferrable=True)
                 dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         return dh.view_as(y), dw, db, None, None
@@ -160,15 +152,11 @@ class PackedLinear(Function):
         x2 = x.reshape(-1, CP).contiguous()
         R = g2.shape[0]
         dx = _data_gradient(g2, weight).view_as(x) if ctx.needs_input_grad[0] else None
-        nslab = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
-        if nslab == 0:
+        part = linear_wgrad_partials(g2, x2, True, deferrable=True)
+        if part is None:
             dw, db = g2.t() @ x2, g2.sum(0)
         else:
-            with torch.cuda.device(g2.device):
-                part = torch.empty(nslab, CK * CP + CK, dtype=torch.float32, device=g2.device)
-                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1, part.data_ptr(),
-                                                  torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-                s = sum_slabs(part, deferrable=True)
+            s = sum_slabs(part, deferrable=True)
             dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         a, b, _ = ctx.split
         return (dx, None, None, dw[:a], dw[a:a + b], dw[a + b:], db[:a], db[a:a + b], db[a + b:])

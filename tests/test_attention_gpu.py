@@ -381,10 +381,10 @@ def test_deferred_slab_sums_give_the_same_gradients_in_one_launch():
         if deferred:
             with deferred_slab_sums() as q:
                 loss.backward()
-                assert len(q.items) >= 5
+                assert len(q.items) >= 5 and len(q.jobs) == 4
                 part = torch.randn(8, 1024, device=DEV)
                 assert torch.equal(sum_slabs(part), sum_slabs(part, deferrable=False))   # immediate inside the block
-            assert len(q.items) == 0
+            assert len(q.items) == 0 and len(q.jobs) == 0
         else:
             loss.backward()
         res.append([p.grad.clone() for m in mods + [cv] for p in m.parameters()])
