@@ -320,11 +320,13 @@ int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int N
 int spacap_linear_wgrad_slabs(long R, int CK, int CP);
 int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
                             spacap_stream_t stream);
-/* njobs independent weight gradients in ONE launch (same values as njobs calls of spacap_linear_wgrad_f32).  All
+/* njobs independent weight gradients in ONE launch; part[i] receives nslabs[i] partial results (with nslabs[i] =
+ * spacap_linear_wgrad_slabs(...) the values of spacap_linear_wgrad_f32; other counts regroup the rows).  All
  * arrays are HOST arrays read before the call returns; the job table is passed to the kernel by value (capturable in a
  * hipGraph).  For the end of a backward pass: only the optimizer reads these gradients. */
+int spacap_linear_wgrad_slabs_batched(long R, int CK, int CP);   /* recommended slabs per job inside a batch */
 int spacap_linear_wgrad_batched_f32(const float *const *g, const float *const *x, const long *R, const int *CK,
-                                    const int *CP, const int *with_bias, float *const *part, int njobs,
+                                    const int *CP, const int *with_bias, const int *nslabs, float *const *part, int njobs,
                                     spacap_stream_t stream);
 
 /* ---- fused elementwise pieces of the Transformer sublayers (csrc/elementwise.hip) -----------------------------

@@ -99,7 +99,8 @@ SIGNATURES = {
     "spacap_linear_rows_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
-    "spacap_linear_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "spacap_linear_wgrad_slabs_batched": (_i, [_l, _i, _i]),
+    "spacap_linear_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
@@ -178,6 +179,7 @@ class deferred_slab_sums:
                         arr(ctypes.c_void_p, [j[0].data_ptr() for j in group]), arr(ctypes.c_void_p, [j[1].data_ptr() for j in group]),
                         arr(ctypes.c_long, [j[0].shape[0] for j in group]), arr(ctypes.c_int, [j[0].shape[1] for j in group]),
                         arr(ctypes.c_int, [j[1].shape[1] for j in group]), arr(ctypes.c_int, [int(j[2]) for j in group]),
+                        arr(ctypes.c_int, [j[3].shape[0] for j in group]),
                         arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]), k, torch.cuda.current_stream(dev).cuda_stream),
                         "spacap_linear_wgrad_batched_f32")
         items, self.items = self.items, []
@@ -230,10 +232,13 @@ def linear_wgrad_partials(g2, x2, with_bias, deferrable=False):
     if nslab == 0:
         return None
     with torch.cuda.device(g2.device):
-        part = torch.empty(nslab, CK * CP + (CK if with_bias else 0), dtype=torch.float32, device=g2.device)
         if deferrable and _DEFERRED is not None:
+            # the batch fills the chip: fewer, longer slabs (less to write and to add up)
+            nb = int(lib.spacap_linear_wgrad_slabs_batched(R, CK, CP))
+            part = torch.empty(nb, CK * CP + (CK if with_bias else 0), dtype=torch.float32, device=g2.device)
             _DEFERRED.jobs.append((g2, x2, bool(with_bias), part))
             return part
+        part = torch.empty(nslab, CK * CP + (CK if with_bias else 0), dtype=torch.float32, device=g2.device)
         check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1 if with_bias else 0, part.data_ptr(),
                                           torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
     return part

@@ -1281,13 +1281,25 @@ extern "C" int spacap_linear_wgrad_f32(const float *g, const float *x, long R, i
 }
 
 // njobs independent weight gradients in one launch (same values as njobs calls of spacap_linear_wgrad_f32 with the
-// same arguments).  All arrays are HOST arrays, read before the call returns; part[i] must hold
-// spacap_linear_wgrad_slabs(R[i], CK[i], CP[i]) partial results.
+// same arguments when nslabs[i] = spacap_linear_wgrad_slabs(...); any other slab count only changes how the rows are
+// grouped).  All arrays are HOST arrays, read before the call returns; part[i] holds nslabs[i] partial results.
+// slabs per job when many jobs share one launch: the batch fills the chip, so a workgroup can take 8 row tiles
+// (fewer partial results to write and to add up; one slab = the result itself for the decoder's 256 rows)
+extern "C" int spacap_linear_wgrad_slabs_batched(long R, int CK, int CP) {
+  const int single = spacap_linear_wgrad_slabs(R, CK, CP);
+  if (single == 0) return 0;
+  const long tiles = (R + TW - 1) / TW;
+  long n = tiles / 8;
+  if (n < 1) n = 1;
+  return (int)(n < single ? n : single);
+}
+
 extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const float *const *x, const long *R, const int *CK,
-                                               const int *CP, const int *with_bias, float *const *part, int njobs,
-                                               spacap_stream_t stream) {
+                                               const int *CP, const int *with_bias, const int *nslabs, float *const *part,
+                                               int njobs, spacap_stream_t stream) {
   const char *what = "spacap_linear_wgrad_batched_f32";
-  SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (g && x && R && CK && CP && with_bias && part)), "%s: bad arguments", what);
+  SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (g && x && R && CK && CP && with_bias && nslabs && part)), "%s: bad arguments",
+                 what);
   hipStream_t s = spacap::as_stream(stream);
   int i = 0;
   while (i < njobs) {
@@ -1295,9 +1307,9 @@ extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const floa
     T.njobs = 0, T.pad = 0;
     long blocks = 0;
     for (; i < njobs && T.njobs < WG_JOB_MAX; ++i) {
-      const int nslab = spacap_linear_wgrad_slabs(R[i], CK[i], CP[i]);
-      SPACAP_REQUIRE(nslab > 0 && g[i] && x[i] && part[i], "%s: job %d: (R=%ld, CK=%d, CP=%d) unsupported or null pointer", what,
-                     i, R[i], CK[i], CP[i]);
+      const int nslab = nslabs[i];
+      SPACAP_REQUIRE(spacap_linear_wgrad_slabs(R[i], CK[i], CP[i]) > 0 && nslab >= 1 && g[i] && x[i] && part[i],
+                     "%s: job %d: (R=%ld, CK=%d, CP=%d, slabs=%d) unsupported or null pointer", what, i, R[i], CK[i], CP[i], nslab);
       WgradJob &J = T.job[T.njobs++];
       J.g = g[i], J.x = x[i], J.part = part[i], J.R = R[i], J.CK = CK[i], J.CP = CP[i];
       J.gx = nslab, J.gy = CK[i] / 128, J.with_bias = with_bias[i], J.block0 = (int)blocks;

@@ -358,8 +358,8 @@ def test_layernorm_residual_node_adds_both_gradient_paths(att, shape):
 
 def test_deferred_slab_sums_give_the_same_gradients_in_one_launch():
     """_native.deferred_slab_sums: inside the block the weight-gradient slab sums are queued, the block's exit runs them
-    as one batched launch; the gradients must equal the immediate path bit for bit (same kernel arithmetic), and a sum
-    that is not marked deferrable must still be computed on the spot."""
+    as one batched launch; the gradients must equal the immediate path (bit for bit where the slabs are the same), and a
+    sum that is not marked deferrable must still be computed on the spot."""
     from spacap3d_amd._native import deferred_slab_sums, sum_slabs
     from spacap3d_amd.linear import conv1x1, linear
     g = torch.Generator().manual_seed(21)
@@ -388,8 +388,10 @@ def test_deferred_slab_sums_give_the_same_gradients_in_one_launch():
         else:
             loss.backward()
         res.append([p.grad.clone() for m in mods + [cv] for p in m.parameters()])
+    # (inside a batch the Linear weight gradients use fewer, longer row slabs: same sums, another grouping)
     for a, b in zip(*res):
-        assert torch.equal(a, b)
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-9
+    assert torch.equal(res[0][-2], res[1][-2])   # the 1x1 convolution's slabs are the same either way
 
 
 def test_packed_qkv_projection_routes_gradients_to_the_three_linears():
