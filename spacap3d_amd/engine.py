@@ -153,7 +153,7 @@ class Trainer:
         self.optimizer.step()
 
     # -- hipGraph mode ------------------------------------------------------------------------------------------
-    # One training step is ~1 900 kernel launches, most of them microseconds long (Transformer, loss); eager
+    # One training step is ~800 kernel launches (1 900 before the fused operators), most of them microseconds long; eager
     # PyTorch needs ~13 us of host time per launch, which caps the step at ~25 ms whatever the GPU does.  The
     # step (zero-grad, forward, loss, backward, Adam) is therefore captured once into a hipGraph over static
     # input buffers and replayed; per step the host then only copies the batch (and the prefetched sampling
