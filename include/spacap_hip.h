@@ -311,6 +311,11 @@ int spacap_sa_l1_bwd_f32(float *dy1, const float *z1, const float *coef, const f
 size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E);
 int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
                                void *workspace, spacap_stream_t stream);
+/* The two halves of spacap_sa_rows_scatter_f32: the inverted index depends on idx only (= on the input coordinates), so
+ * it can be built ahead of the step; the gather then reads it from the same workspace. */
+int spacap_sa_rows_index_f32(const int32_t *idx, int B, int Np, long E, void *workspace, spacap_stream_t stream);
+int spacap_sa_rows_gather_f32(const float *dz, int B, int Np, long E, int C, const void *workspace, float *out,
+                              spacap_stream_t stream);
 
 /* ---- Linear layers of the Transformer: weight + bias gradient in one launch ------------------------------------
  * dW[ck,cp] = sum_r g[r,ck] x[r,cp], db[ck] = sum_r g[r,ck]  (backward of torch.nn.Linear as used by

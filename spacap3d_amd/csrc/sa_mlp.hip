@@ -1114,12 +1114,13 @@ extern "C" size_t spacap_sa_rows_scatter_workspace_bytes(int B, int Np, long E) 
   return rows_layout(B, Np, E, L) ? L.bytes : 0;
 }
 
-// out[b, p, :] = sum of dz[r, :] over the rows r = (b, e) with idx[b, e] = p, ascending r (E = rows per scene)
-extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
-                                          void *workspace, spacap_stream_t stream) {
-  const char *what = "spacap_sa_rows_scatter_f32";
+// The inverted index of a grouping (which rows reference each source point, ascending): a function of idx alone, i.e.
+// of the input coordinates -- a trainer can build it ahead of the step (detector.geometry_pyramid) and the backward
+// then only gathers.  `workspace` (spacap_sa_rows_scatter_workspace_bytes) holds the index afterwards.
+extern "C" int spacap_sa_rows_index_f32(const int32_t *idx, int B, int Np, long E, void *workspace, spacap_stream_t stream) {
+  const char *what = "spacap_sa_rows_index_f32";
   RowsLayout L;
-  SPACAP_REQUIRE(dz && idx && out && workspace && C % 4 == 0 && rows_layout(B, Np, E, L), "%s: bad arguments", what);
+  SPACAP_REQUIRE(idx && workspace && rows_layout(B, Np, E, L), "%s: bad arguments", what);
   hipStream_t s = spacap::as_stream(stream);
   char *ws = reinterpret_cast<char *>(workspace);
   unsigned *keys_in = reinterpret_cast<unsigned *>(ws + L.keys_in), *keys_out = reinterpret_cast<unsigned *>(ws + L.keys_out);
@@ -1130,9 +1131,30 @@ extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, i
   SPACAP_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, keys_in, keys_out, vals_in, vals_out,
                                                       (int)L.total, 0, L.bits, s), what);
   hipLaunchKernelGGL(rows_offsets_kernel, dim3(nblocks((long)L.K + 1, 256)), dim3(256), 0, s, keys_out, (long)L.total, (long)L.K, off);
-  hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(nblocks((long)L.K * (C / 4), 256)), dim3(256), 0, s, dz, off, vals_out, (long)L.K, C, out);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
+}
+
+// out[b, p, :] = sum of dz[r, :] over the rows r = (b, e) with idx[b, e] = p, ascending r, from the index
+// spacap_sa_rows_index_f32 left in `workspace` (same B, Np, E)
+extern "C" int spacap_sa_rows_gather_f32(const float *dz, int B, int Np, long E, int C, const void *workspace, float *out,
+                                         spacap_stream_t stream) {
+  const char *what = "spacap_sa_rows_gather_f32";
+  RowsLayout L;
+  SPACAP_REQUIRE(dz && out && workspace && C % 4 == 0 && rows_layout(B, Np, E, L), "%s: bad arguments", what);
+  const char *ws = reinterpret_cast<const char *>(workspace);
+  hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(nblocks((long)L.K * (C / 4), 256)), dim3(256), 0, spacap::as_stream(stream), dz,
+                     reinterpret_cast<const int *>(ws + L.off), reinterpret_cast<const int *>(ws + L.vals_out), (long)L.K, C, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// out[b, p, :] = sum of dz[r, :] over the rows r = (b, e) with idx[b, e] = p, ascending r (E = rows per scene)
+extern "C" int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int Np, long E, int C, float *out,
+                                          void *workspace, spacap_stream_t stream) {
+  SPACAP_REQUIRE(dz && out && C % 4 == 0, "spacap_sa_rows_scatter_f32: bad arguments");
+  const int rc = spacap_sa_rows_index_f32(idx, B, Np, E, workspace, stream);
+  return rc ? rc : spacap_sa_rows_gather_f32(dz, B, Np, E, C, workspace, out, stream);
 }
 
 // ===========================================================================================================

@@ -44,7 +44,7 @@ SA_NSAMPLES = (64, 32, 16, 16)        # backbone_module.py:31,40,49,58
 
 
 def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPLES):
-    """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 tensors:
+    """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 (+3 on the GPU) tensors:
     the four sampling index sets (``sampling_pyramid``), the four ball-query groupings of the SA modules
     (pointnet2_modules.py:241-247) and (idx, weight) of the two feature-propagation modules' three-nearest-neighbour
     interpolation (:399-405; fp1: SA3 points from SA4's, fp2: SA2 points from SA3's, backbone_module.py:115-119).
@@ -62,7 +62,13 @@ def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPL
         cur = new_xyz
     fp1 = PointnetFPModule.neighbours(xyzs[3], xyzs[4])
     fp2 = PointnetFPModule.neighbours(xyzs[2], xyzs[3])
-    return tuple(inds_all) + tuple(idx_all) + (fp1[0], fp1[1], fp2[0], fp2[1])
+    out = tuple(inds_all) + tuple(idx_all) + (fp1[0], fp1[1], fp2[0], fp2[1])
+    if xyz.is_cuda:
+        # + the inverted indices of the SA2..SA4 groupings (feature-gradient gathers of the fused SA op; SA1's
+        # features are an input and get no gradient)
+        from .sa_mlp import rows_index
+        out = out + tuple(rows_index(idx_all[l], xyzs[l].shape[1]) for l in (1, 2, 3))
+    return out
 
 
 class Pointnet2Backbone(nn.Module):
@@ -91,16 +97,17 @@ class Pointnet2Backbone(nn.Module):
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
         # optional precomputed sampling pyramid (see sampling_pyramid); None -> each SA module samples itself
-        # (4 tensors: sampling_pyramid; 12: geometry_pyramid, which adds the groupings and interpolation weights)
+        # (4 tensors: sampling_pyramid; 12 / 15: geometry_pyramid, which adds the groupings, the interpolation weights and, on
+        # the GPU, the inverted indices of the SA2..SA4 groupings)
         pyr = tuple(data_dict.get("fps_pyramid") or ())
-        pyr = pyr + (None,) * (12 - len(pyr))
+        pyr = pyr + (None,) * (15 - len(pyr))
         xyz, features, fps_inds = self.sa1(xyz, features, pyr[0], pyr[4])
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1], pyr[5])
+        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1], pyr[5], pyr[12])
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2], pyr[6])
+        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2], pyr[6], pyr[13])
         data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
-        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3], pyr[7])
+        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3], pyr[7], pyr[14])
         data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
                             data_dict["sa4_features"], nn=(pyr[8], pyr[9]) if pyr[8] is not None else None)

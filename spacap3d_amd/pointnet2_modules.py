@@ -94,9 +94,10 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = SharedMLP(mlp_spec, bn=bn)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None,
-                idx: torch.Tensor = None):
+                idx: torch.Tensor = None, rows_idx: torch.Tensor = None):
         """``inds`` (B,npoint) / ``idx`` (B,npoint,nsample): optionally precomputed sampling and grouping indices
-        (they depend on the coordinates only: detector.geometry_pyramid computes them ahead of the step)."""
+        (they depend on the coordinates only: detector.geometry_pyramid computes them ahead of the step);
+        ``rows_idx``: optionally the inverted index of ``idx`` (sa_mlp.rows_index) for the fused op's backward."""
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
@@ -117,7 +118,7 @@ class PointnetSAModuleVotes(nn.Module):
         if fused is not None:
             # training step: grouping + SharedMLP + pooling as one point-major op of the backend (sa_mlp.py)
             out = fused(xyz, new_xyz, features, idx, self.mlp_module, self.radius if self.normalize_xyz else 1.0,
-                        self.use_xyz)
+                        self.use_xyz, rows_idx)
             if out is not None:
                 return new_xyz, out, inds
         if features is not None:

@@ -23,7 +23,7 @@ class _SAMLP(Function):
     output: (B,N,C3) pooled features."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat, Y, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv):
+    def forward(ctx, xyz, new_xyz, idx, feat, Y, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv, rows_index=None):
         dev = xyz.device
         B, Np, _ = xyz.shape
         N, S = idx.shape[1], idx.shape[2]
@@ -70,6 +70,7 @@ class _SAMLP(Function):
                                              st), "spacap_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg)
         ctx.rdiv = float(rdiv)
+        ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
         ctx.has_Y = Y is not None
         ctx.need_xyz = xyz.requires_grad or new_xyz.requires_grad
         return out
@@ -132,7 +133,7 @@ class _SAMLP(Function):
                 cf = coef[0].double()
                 dW1 = (cf[:, 0:1] * S13[:, 0] + cf[:, 1:2] * P[C1 * 8:].view(1, 4) - cf[:, 2:3] * S13[:, 1]).float()
                 dW1 = dW1[:, :W1.shape[1]].contiguous()
-                return (None, None, None, None, None, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
+                return (None, None, None, None, None, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
             dy1 = torch.empty(R, C1, **f32)
             check(lib.spacap_sa_dgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
                                           z1.data_ptr(), st1.data_ptr(), R, C2, C1, dy1.data_ptr(), part.data_ptr(), st),
@@ -149,10 +150,17 @@ class _SAMLP(Function):
             dW1 = sum_slabs(pw1)[:, :W1.shape[1]].contiguous()
             dY = None
             if ctx.has_Y and ctx.needs_input_grad[4]:
-                ws = torch.empty(int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S)), dtype=torch.uint8, device=dev)
                 dY = torch.empty(B, Np, C1, **f32)
-                check(lib.spacap_sa_rows_scatter_f32(dy1.data_ptr(), idx.data_ptr(), B, Np, N * S, C1, dY.data_ptr(),
-                                                     ws.data_ptr(), st), "spacap_sa_rows_scatter_f32")
+                nbytes = int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S))
+                ri = ctx.rows_index
+                if ri is not None and ri.numel() == nbytes and ri.device == dev:
+                    # the inverted index came with the geometry pyramid: only the gather is left
+                    check(lib.spacap_sa_rows_gather_f32(dy1.data_ptr(), B, Np, N * S, C1, ri.data_ptr(), dY.data_ptr(), st),
+                          "spacap_sa_rows_gather_f32")
+                else:
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    check(lib.spacap_sa_rows_scatter_f32(dy1.data_ptr(), idx.data_ptr(), B, Np, N * S, C1, dY.data_ptr(),
+                                                         ws.data_ptr(), st), "spacap_sa_rows_scatter_f32")
             dxyz = dnew = None
             if drel is not None:
                 d3 = drel.view(B, N * S, 3)
@@ -161,7 +169,7 @@ class _SAMLP(Function):
                     dxyz.scatter_add_(1, idx.view(B, N * S, 1).expand(-1, -1, 3).long(), d3)
                 if ctx.needs_input_grad[1]:
                     dnew = -drel.view(B, N, S, 3).sum(2)
-        return (dxyz, dnew, None, None, dY, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
+        return (dxyz, dnew, None, None, dY, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
 
 
 def supported(mlp_module, nsample):
@@ -204,7 +212,19 @@ class _FeatureProduct(Function):
         return dpm, dW
 
 
-def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
+def rows_index(idx, Np):
+    """Inverted index of a grouping idx (B,N,S) over Np source points (which grouped rows reference each point, in
+    ascending row order) as an opaque uint8 tensor: what the feature-gradient gather of the fused SA op needs.  It
+    depends on idx only, so a trainer can build it ahead of the step (detector.geometry_pyramid)."""
+    B, N, S = idx.shape
+    with torch.cuda.device(idx.device):
+        ws = torch.empty(int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S)), dtype=torch.uint8, device=idx.device)
+        check(lib.spacap_sa_rows_index_f32(idx.data_ptr(), B, Np, N * S, ws.data_ptr(),
+                                           torch.cuda.current_stream(idx.device).cuda_stream), "spacap_sa_rows_index_f32")
+    return ws
+
+
+def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True, rows_idx=None):
     """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N) [a view of the point-major (B,N,C3) result, also attached as ``._point_major``].  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
     updated.  Returns None when this MLP has no fused kernels (the caller then uses the per-operator path)."""
     if not use_xyz or not xyz.is_cuda or not supported(mlp_module, idx.shape[2]):
@@ -228,7 +248,7 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
     bns = [l.bn.bn for l in (l1, l2, l3)]
     out = _SAMLP.apply(xyz, new_xyz, idx, feat, Y, W1a, l2.conv.weight.view(l2.conv.out_channels, -1),
                        l3.conv.weight.view(l3.conv.out_channels, -1), bns[0].weight, bns[0].bias, bns[1].weight,
-                       bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv)
+                       bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv, rows_idx)
     # (B,C3,N) as a transposed VIEW of the point-major result: the next SA module and the proposal head read the
     # point-major tensor itself (``_point_major``), so no transposed copy is made unless a consumer asks for one
     res = out.transpose(1, 2)

@@ -137,6 +137,32 @@ def test_fused_and_per_operator_paths_agree_including_running_stats():
         assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-4 * float(gb.abs().max()))
 
 
+def test_prebuilt_inverted_index_gives_the_same_feature_gradient():
+    """sa_mlp.rows_index(idx, Np) handed to the module (as the geometry pyramid does) must give bit-identical
+    outputs and gradients to the module sorting its grouping itself in the backward."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    from spacap3d_amd.sa_mlp import rows_index
+    torch.manual_seed(5)
+    sa = PointnetSAModuleVotes(npoint=256, radius=0.6, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    xyz = S.scene_batch(3, 1000, use_height=False, seed=2).to(DEV)
+    feats = F.relu(torch.randn(3, 128, 1000, device=DEV))
+    inds = pu.furthest_point_sample(xyz, 256)
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+    idx = pu.ball_query(0.6, 32, xyz, new_xyz)
+    fa, fb = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    _, oa, _ = sa(xyz, fa, inds, idx, rows_index(idx, 1000))
+    _, ob, _ = sb(xyz, fb, inds, idx)
+    w = torch.randn_like(oa)
+    (oa * w).sum().backward()
+    (ob * w).sum().backward()
+    assert torch.equal(oa, ob) and torch.equal(fa.grad, fb.grad)
+    for la, lb in zip(sa.mlp_module.children(), sb.mlp_module.children()):
+        assert torch.equal(la.conv.weight.grad, lb.conv.weight.grad)
+
+
 def test_unsupported_mlp_uses_the_per_operator_path():
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
     from spacap3d_amd import sa_mlp
