@@ -448,6 +448,11 @@ int spacap_rel_tail_bwd_f32(const float *dpred, const float *W3, const float *hi
 int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N);
 int spacap_conv1x1_wgrad_f32(const float *g, const float *x, int B, int CO, int CI, int N, float *part,
                              spacap_stream_t stream);
+/* Several of them in ONE launch (end of a backward pass); HOST arrays, job table by value, nslabs[i] =
+ * spacap_conv1x1_wgrad_slabs_batched(...) (or any multiple of B[i] that divides the point tiles). */
+int spacap_conv1x1_wgrad_slabs_batched(int B, int CO, int CI, int N);
+int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const float *const *x, const int *B, const int *CO, const int *CI,
+                                     const int *N, const int *nslabs, float *const *part, int njobs, spacap_stream_t stream);
 
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with

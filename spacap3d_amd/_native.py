@@ -97,6 +97,8 @@ SIGNATURES = {
     "spacap_rel_tail_bwd_f32": (_i, [_p, _p, _p, _l, _p, _p, _p]),
     "spacap_conv1x1_wgrad_slabs": (_i, [_i, _i, _i, _i]),
     "spacap_conv1x1_wgrad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_conv1x1_wgrad_slabs_batched": (_i, [_i, _i, _i, _i]),
+    "spacap_conv1x1_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "spacap_linear_rows_supported": (_i, [_l, _i, _i]),
     "spacap_linear_rows_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
@@ -156,6 +158,7 @@ class deferred_slab_sums:
         self._prev = _DEFERRED
         self.items = []   # (part, out): slab sums to run
         self.jobs = []    # (g2, x2, with_bias, part): weight gradients (linear_wgrad_partials) that fill queued partials
+        self.conv_jobs = []   # (g, x, (B, CO, CI, N), part): 1x1-convolution weight gradients (conv1x1_wgrad_partials)
         _DEFERRED = self
         return self
 
@@ -184,6 +187,21 @@ class deferred_slab_sums:
                         arr(ctypes.c_int, [j[3].shape[0] for j in group]),
                         arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]), k, torch.cuda.current_stream(dev).cuda_stream),
                         "spacap_linear_wgrad_batched_f32")
+        cjobs, self.conv_jobs = self.conv_jobs, []
+        if cjobs:
+            by_dev = {}
+            for j in cjobs:
+                by_dev.setdefault(j[0].device, []).append(j)
+            for dev, group in by_dev.items():
+                k = len(group)
+                arr = lambda ct, vals: (ct * k)(*vals)
+                with torch.cuda.device(dev):
+                    check(lib.spacap_conv1x1_wgrad_batched_f32(
+                        arr(ctypes.c_void_p, [j[0].data_ptr() for j in group]), arr(ctypes.c_void_p, [j[1].data_ptr() for j in group]),
+                        arr(ctypes.c_int, [j[2][0] for j in group]), arr(ctypes.c_int, [j[2][1] for j in group]),
+                        arr(ctypes.c_int, [j[2][2] for j in group]), arr(ctypes.c_int, [j[2][3] for j in group]),
+                        arr(ctypes.c_int, [j[3].shape[0] for j in group]), arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]),
+                        k, torch.cuda.current_stream(dev).cuda_stream), "spacap_conv1x1_wgrad_batched_f32")
         items, self.items = self.items, []
         by_dev = {}
         for part, out in items:
@@ -243,4 +261,21 @@ def linear_wgrad_partials(g2, x2, with_bias, deferrable=False):
         part = torch.empty(nslab, CK * CP + (CK if with_bias else 0), dtype=torch.float32, device=g2.device)
         check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, CK, CP, 1 if with_bias else 0, part.data_ptr(),
                                           torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
+    return part
+
+
+def conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=False):
+    """Per-slab partials (nslab, CO*CI) of the weight gradient of a 1x1 convolution on channel-major g (B,CO,N...) and
+    x (B,CI,N...); queued inside a ``deferred_slab_sums`` block with ``deferrable=True`` (see linear_wgrad_partials)."""
+    import torch
+    with torch.cuda.device(g.device):
+        if deferrable and _DEFERRED is not None:
+            nb = int(lib.spacap_conv1x1_wgrad_slabs_batched(B, CO, CI, N))
+            part = torch.empty(nb, CO * CI, dtype=torch.float32, device=g.device)
+            _DEFERRED.conv_jobs.append((g, x, (B, CO, CI, N), part))
+            return part
+        nslab = int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N))
+        part = torch.empty(nslab, CO * CI, dtype=torch.float32, device=g.device)
+        check(lib.spacap_conv1x1_wgrad_f32(g.data_ptr(), x.data_ptr(), B, CO, CI, N, part.data_ptr(),
+                                           torch.cuda.current_stream(g.device).cuda_stream), "spacap_conv1x1_wgrad_f32")
     return part

@@ -1353,14 +1353,14 @@ extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const floa
 // (contiguous along n), each (scene, point range) slab accumulates a 128 x 128 block by MFMA and writes a partial
 // result; the caller adds the slabs in order (spacap_sum_slabs_f32).
 namespace {
-__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CO,
-                                                            int CI, int N, int nsplit, float *__restrict__ part) {
+__device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, const float *__restrict__ x, int CO, int CI,
+                                                   int N, int nsplit, float *__restrict__ part, int bx, int by, int bz) {
   constexpr int CB = 128, KT = 32, LDK = KT + 4;
   __shared__ __attribute__((aligned(16))) float s_g[CB * LDK];
   __shared__ __attribute__((aligned(16))) float s_x[CB * LDK];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x / nsplit, sl = blockIdx.x % nsplit;
-  const int co0 = blockIdx.y * CB, ci0 = blockIdx.z * CB;
+  const int b = bx / nsplit, sl = bx % nsplit;
+  const int co0 = by * CB, ci0 = bz * CB;
   const int tiles = N / KT, t_begin = (int)((long)tiles * sl / nsplit), t_end = (int)((long)tiles * (sl + 1) / nsplit);
   const float *gb = g + ((size_t)b * CO + co0) * N, *xb = x + ((size_t)b * CI + ci0) * N;
   const int k4 = tid & 7, c0 = tid >> 3;   // 8 float4 per 32-point row, 32 channels per pass
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
     }
     __syncthreads();
   }
-  float *o = part + (size_t)blockIdx.x * ((size_t)CO * CI);
+  float *o = part + (size_t)bx * ((size_t)CO * CI);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1400,6 +1400,33 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restr
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         o[(size_t)(co0 + (w * 2 + m) * 16 + 4 * lg + u) * CI + ci0 + n * 16 + l15] = acc[m][n][u];
+}
+
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CO,
+                                                            int CI, int N, int nsplit, float *__restrict__ part) {
+  conv1x1_wgrad_body(g, x, CO, CI, N, nsplit, part, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several 1x1-convolution weight gradients in one launch (end of a backward pass: see linear_wgrad_batched_kernel)
+constexpr int CV_JOB_MAX = 64;
+struct ConvJob {
+  const float *g, *x;
+  float *part;
+  int CO, CI, N, nsplit, gx, gy, block0, pad;
+};
+struct ConvTable {
+  int njobs, pad;
+  ConvJob job[CV_JOB_MAX];
+};
+__global__ __launch_bounds__(256) void conv1x1_wgrad_batched_kernel(const ConvTable T) {
+  int lo = 0, hi = T.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.job[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ConvJob J = T.job[lo];
+  const int local = (int)blockIdx.x - J.block0;
+  conv1x1_wgrad_body(J.g, J.x, J.CO, J.CI, J.N, J.nsplit, J.part, local % J.gx, (local / J.gx) % J.gy, local / (J.gx * J.gy));
 }
 
 inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
@@ -1415,6 +1442,45 @@ inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
 extern "C" int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N) {
   if (B < 1 || N < 32 || N % 32 || CO < 128 || CI < 128 || CO % 128 || CI % 128) return 0;
   return B * conv1x1_nsplit(B, CO, CI, N);
+}
+
+// slabs per job inside a batch (the batch fills the chip: ~8 point tiles per workgroup)
+extern "C" int spacap_conv1x1_wgrad_slabs_batched(int B, int CO, int CI, int N) {
+  if (spacap_conv1x1_wgrad_slabs(B, CO, CI, N) == 0) return 0;
+  int nsplit = N / 256;
+  if (nsplit < 1) nsplit = 1;
+  const int single = conv1x1_nsplit(B, CO, CI, N);
+  return B * (nsplit < single ? nsplit : single);
+}
+
+// njobs independent 1x1-convolution weight gradients in one launch; all arrays are HOST arrays (read before the call
+// returns); part[i] receives nslabs[i] = B[i] x (point ranges) partial results (add in order).
+extern "C" int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const float *const *x, const int *B, const int *CO,
+                                                const int *CI, const int *N, const int *nslabs, float *const *part, int njobs,
+                                                spacap_stream_t stream) {
+  const char *what = "spacap_conv1x1_wgrad_batched_f32";
+  SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (g && x && B && CO && CI && N && nslabs && part)), "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  int i = 0;
+  while (i < njobs) {
+    ConvTable T;
+    T.njobs = 0, T.pad = 0;
+    long blocks = 0;
+    for (; i < njobs && T.njobs < CV_JOB_MAX; ++i) {
+      SPACAP_REQUIRE(spacap_conv1x1_wgrad_slabs(B[i], CO[i], CI[i], N[i]) > 0 && nslabs[i] >= B[i] && nslabs[i] % B[i] == 0 &&
+                         g[i] && x[i] && part[i],
+                     "%s: job %d: (B=%d, CO=%d, CI=%d, N=%d, slabs=%d) unsupported or null pointer", what, i, B[i], CO[i], CI[i],
+                     N[i], nslabs[i]);
+      ConvJob &J = T.job[T.njobs++];
+      J.g = g[i], J.x = x[i], J.part = part[i], J.CO = CO[i], J.CI = CI[i], J.N = N[i];
+      J.nsplit = nslabs[i] / B[i], J.gx = nslabs[i], J.gy = CO[i] / 128, J.block0 = (int)blocks, J.pad = 0;
+      blocks += (long)nslabs[i] * (CO[i] / 128) * (CI[i] / 128);
+      SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
+    }
+    hipLaunchKernelGGL(conv1x1_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
 }
 
 // g f32 [B,CO,N], x f32 [B,CI,N] dense; part f32 [spacap_conv1x1_wgrad_slabs(B,CO,CI,N)][CO*CI]

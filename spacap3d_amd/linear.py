@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._native import check, lib, linear_wgrad_partials, sum_slabs
+from ._native import check, conv1x1_wgrad_partials, lib, linear_wgrad_partials, sum_slabs
 
 
 def rows_product(a2, W, bias, trans_w):
@@ -201,12 +201,8 @@ class Conv1x1(Function):
             dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
                                                      [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
                                                      [True, False, False])[0]
-        nslab = int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N))
-        with torch.cuda.device(g.device):
-            part = torch.empty(nslab, CO * CI, dtype=torch.float32, device=g.device)
-            check(lib.spacap_conv1x1_wgrad_f32(g.data_ptr(), x.data_ptr(), B, CO, CI, N, part.data_ptr(),
-                                               torch.cuda.current_stream(g.device).cuda_stream), "spacap_conv1x1_wgrad_f32")
-            dw = (sum_slabs(part, deferrable=True) if nslab > 1 else part[0]).view_as(weight)
+        part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True)
+        dw = sum_slabs(part, deferrable=True).view_as(weight)
         db = g.sum(dim=[0] + list(range(2, g.dim()))) if ctx.has_bias else None
         return dx, dw, db
 
