@@ -214,7 +214,7 @@ def main():
                                    f"{per_gpu} scenes/GPU; full training step (SpaCapNet fwd + loss + bwd + "
                                    f"grad all-reduce + Adam)",
                        "global_batch": per_gpu * world, "parallelism": f"dp{world}",
-                       "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None,
+                       "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
                        "side_stream_branches": bool(trainer.multi_stream),
                        "params": sum(p.numel() for p in model.parameters()),
                        "allreduce_bytes": trainer.bucket.nbytes},
