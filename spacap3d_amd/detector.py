@@ -153,7 +153,14 @@ class VotingModule(nn.Module):
         net = net.transpose(2, 1).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, num_vote, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[:, :, :, 3:]
-        vote_features = vote_features.contiguous().view(B, num_vote, self.out_dim).transpose(2, 1).contiguous()
+        pm = vote_features.contiguous().view(B, num_vote, self.out_dim)   # (B, num_vote, C): point-major
+        if self.training and pm.is_cuda:
+            # (B, C, num_vote) as a transposed VIEW carrying the point-major tensor (the fused SA op of the proposal
+            # module reads that one): no transposed copy here nor of its gradient
+            vote_features = pm.transpose(2, 1)
+            vote_features._point_major = pm
+        else:
+            vote_features = pm.transpose(2, 1).contiguous()
         return vote_xyz, vote_features
 
 

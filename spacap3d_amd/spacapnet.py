@@ -43,7 +43,13 @@ class SpaCapNet(nn.Module):
         data_dict["seed_xyz"] = xyz
         data_dict["seed_features"] = features
         xyz, features = self.vgen(xyz, features)
-        features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))  # SpaCapNet.py:66-67 (no eps)
+        pm = getattr(features, "_point_major", None)
+        if pm is not None:   # same L2 normalisation over the channels, on the point-major tensor
+            pm = pm.div(torch.norm(pm, p=2, dim=2).unsqueeze(2))
+            features = pm.transpose(1, 2)
+            features._point_major = pm
+        else:
+            features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))  # SpaCapNet.py:66-67 (no eps)
         data_dict["vote_xyz"] = xyz
         data_dict["vote_features"] = features
         data_dict = self.proposal(xyz, features, data_dict)
