@@ -135,7 +135,11 @@ class Trainer:
             # the ~70 weight-gradient slab sums of the backward are only read by the optimizer: queue them and run them
             # as ONE launch when the backward is over (spacap3d_amd/_native.py: deferred_slab_sums)
             from ._native import deferred_slab_sums
-            with deferred_slab_sums():
+            # (only when autograd will ASSIGN the gradients: accumulating into an existing .grad reads them at once)
+            if all(p.grad is None for p in self.bucket.params):
+                with deferred_slab_sums():
+                    d["loss"].backward()
+            else:
                 d["loss"].backward()
         else:
             d["loss"].backward()
