@@ -169,7 +169,21 @@ class deferred_slab_sums:
             self.flush()
         return False
 
+    def has_job_for(self, part):
+        """True when ``part`` is a queued, NOT YET COMPUTED weight-gradient partial."""
+        ptr = part.data_ptr()
+        return any(j[3].data_ptr() == ptr for j in self.jobs) or any(j[3].data_ptr() == ptr for j in self.conv_jobs)
+
+    def outputs(self):
+        """The result tensors of the queued slab sums (still unfilled until ``flush``)."""
+        return [o for _, o in self.items]
+
     def flush(self):
+        self.run_jobs()
+        self.run_sums()
+
+    def run_jobs(self):
+        """Run the queued weight-gradient kernels now (fills their ``part`` buffers)."""
         import torch
         jobs, self.jobs = self.jobs, []
         if jobs:   # first the weight gradients themselves (one launch), then the sums over their slabs
@@ -202,6 +216,9 @@ class deferred_slab_sums:
                         arr(ctypes.c_int, [j[2][2] for j in group]), arr(ctypes.c_int, [j[2][3] for j in group]),
                         arr(ctypes.c_int, [j[3].shape[0] for j in group]), arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]),
                         k, torch.cuda.current_stream(dev).cuda_stream), "spacap_conv1x1_wgrad_batched_f32")
+
+    def run_sums(self):
+        import torch
         items, self.items = self.items, []
         by_dev = {}
         for part, out in items:
@@ -223,11 +240,16 @@ def sum_slabs(part, deferrable=False):
     import torch
     n = part[0].numel()
     if part.shape[0] == 1:
-        return part[0]
+        return part[0]   # (inside a deferred block a queued job fills it at the flush: still the leaf gradient)
+    can_defer = deferrable and _DEFERRED is not None and part.is_cuda and part.data_ptr() % 16 == 0 and n % 4 == 0 \
+        and part.dtype == torch.float32 and part.is_contiguous()
+    if not can_defer and _DEFERRED is not None and part.is_cuda and _DEFERRED.has_job_for(part):
+        # `part` was only QUEUED by linear_wgrad_partials / conv1x1_wgrad_partials and this call reduces it at once
+        # (odd row size, unaligned pointer, caller did not mark the sum deferrable): compute it first
+        _DEFERRED.run_jobs()
     if not part.is_cuda or n % 4 or part.dtype != torch.float32 or not part.is_contiguous():
         return part.sum(0)
-    if deferrable and _DEFERRED is not None and part.data_ptr() % 16 == 0:   # (a 1-slab result returned above is
-        # filled by its deferred weight-gradient job, if it has one)
+    if can_defer:
         with torch.cuda.device(part.device):
             out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
         _DEFERRED.items.append((part, out))

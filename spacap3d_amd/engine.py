@@ -28,7 +28,10 @@ class Trainer:
         self._static = None
         self._static_loss = None
         self._eager_steps = 0
+        self._eager_checks = 2     # first steps: verify the deferred-gradient contract (see _core)
         self._graph_grads = None
+        self._capture_stream = None
+        self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
         # independent branches of the step (relation head, detection losses) on side streams (spacap3d_amd/streams.py);
@@ -84,8 +87,13 @@ class Trainer:
     def _setup(self, data_dict):
         """First step: discover which parameters the loss reaches, then lay their gradients out in one flat
         bucket and build Adam over exactly those (scripts/train.py:262: Adam lr 1e-3, weight_decay 1e-5)."""
+        # (this discovery pass is not a training step: BatchNorm running statistics / batch counters it moves are restored)
+        bufs = [(b, b.detach().clone()) for b in self.model.buffers()]
         d = self.loss(data_dict)
         used = used_parameters(self.model, d["loss"])
+        with torch.no_grad():
+            for b, saved in bufs:
+                b.copy_(saved)
         # gradients are assigned by autograd (no per-parameter accumulate kernels) and packed into the flat
         # bucket only when there is something to all-reduce
         used = self._group_qkv(used)
@@ -137,8 +145,16 @@ class Trainer:
             from ._native import deferred_slab_sums
             # (only when autograd will ASSIGN the gradients: accumulating into an existing .grad reads them at once)
             if all(p.grad is None for p in self.bucket.params):
-                with deferred_slab_sums():
+                with deferred_slab_sums() as dq:
                     d["loss"].backward()
+                    if self._eager_checks > 0:
+                        # A queued sum is unfilled until the flush: it must have reached a parameter's .grad untouched
+                        # (a parameter consumed by two autograd nodes, or an AccumulateGrad that clones, would have read it)
+                        self._eager_checks -= 1
+                        leaf = {p.grad.untyped_storage().data_ptr() for p in self.model.parameters() if p.grad is not None}
+                        lost = [tuple(o.shape) for o in dq.outputs() if o.untyped_storage().data_ptr() not in leaf]
+                        if lost:
+                            raise RuntimeError(f"deferred weight-gradient sums did not land in a leaf .grad: {lost}")
             else:
                 d["loss"].backward()
         else:
@@ -166,7 +182,9 @@ class Trainer:
     # captured); single-rank runs capture them too.
     def enable_graph(self, example, warmup=3):
         """Capture the step for batches shaped like ``example`` (which must carry a prefetched pyramid if
-        prefetching is used).  Falls back to eager mode (and records why) if capture fails."""
+        prefetching is used).  Falls back to eager mode (and records why) if capture fails.
+        NOTE: the ``warmup`` iterations are real optimizer steps on ``example`` (see _capture); pass ``warmup=0`` after
+        at least one eager step() if the trajectory must not contain them."""
         import torch.distributed as dist
         dev = example["point_clouds"].device
         if dev.type != "cuda":
@@ -189,21 +207,7 @@ class Trainer:
             for mod in self.model.modules():
                 if hasattr(mod, "attn") and hasattr(mod, "keep_value"):
                     mod.attn, mod.value = None, None
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                for _ in range(warmup):
-                    self._core(static, self._graph_with_opt)
-                    if not self._graph_with_opt:
-                        self._optimizer_step(None)
-            torch.cuda.current_stream(dev).wait_stream(s)
-            torch.cuda.synchronize(dev)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=s):
-                loss = self._core(static, self._graph_with_opt)
-            self.graph, self._static, self._static_loss = g, static, loss
-            # the tensors autograd assigned as gradients during capture: every replay rewrites them in place
-            self._graph_grads = [p.grad for p in self.bucket.params]
+            self._capture(static, warmup)
             return True
         except Exception as e:  # noqa: BLE001 -- any capture failure means "stay eager"
             self.graph, self._static, self._static_loss = None, None, None
@@ -212,14 +216,79 @@ class Trainer:
             torch.cuda.synchronize(dev)
             return False
 
+    def _capture(self, static, warmup):
+        """``warmup`` REAL training steps on the static batch (they update the parameters, the BatchNorm statistics
+        and the optimizer state exactly like step() would: callers that count steps must count them), then the
+        capture of one more step, which is not executed until the first replay."""
+        dev = static["point_clouds"].device
+        if self._capture_stream is None:
+            self._capture_stream = torch.cuda.Stream(device=dev)
+        s = self._capture_stream
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._core(static, self._graph_with_opt)
+                if not self._graph_with_opt:
+                    self._optimizer_step(None)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            loss = self._core(static, self._graph_with_opt)
+        self.graph, self._static, self._static_loss = g, static, loss
+        # the tensors autograd assigned as gradients during capture: every replay rewrites them in place
+        self._graph_grads = [p.grad for p in self.bucket.params]
+        self._recapture = False
+
+    def set_hyper(self, lr=None, bn_momentum=None):
+        """Change the learning rate and / or the BatchNorm momentum (what the reference's Solver does every epoch with
+        StepLR / BNMomentumScheduler, lib/solver.py:228-235).  These scalars are kernel ARGUMENTS, i.e. frozen into a
+        captured hipGraph: when a graph is active it is re-captured (same static buffers, no warm-up steps) at the
+        next step."""
+        if lr is not None:
+            self.lr = float(lr)
+            if isinstance(self.optimizer, torch.optim.Optimizer):
+                for grp in self.optimizer.param_groups:
+                    grp["lr"] = self.lr
+            elif self.optimizer is not None:
+                self.optimizer.lr = self.lr
+        if bn_momentum is not None:
+            for m in self.model.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.momentum = float(bn_momentum)
+        if self.graph is not None:
+            self._recapture = True
+
     def _graph_step(self, data_dict, next_data):
+        if self._recapture:
+            static, self.graph = self._static, None
+            for mod in self.model.modules():
+                if hasattr(mod, "attn") and hasattr(mod, "keep_value"):
+                    mod.attn, mod.value = None, None
+            self._capture(static, warmup=0)
         pre = data_dict.pop("_fps_prefetch", None)
-        if pre is not None:
-            pyr, ev = pre
-            torch.cuda.current_stream(pyr[0].device).wait_event(ev)
-            for dst, src in zip(self._static["fps_pyramid"], pyr):
+        static_pyr = self._static.get("fps_pyramid")
+        if static_pyr is not None:
+            # The captured graph READS the pyramid (sampling / grouping / interpolation indices) from static buffers
+            # and never computes it.  A batch that arrives without a prefetched pyramid (first batch after
+            # enable_graph, epoch boundary, caller without next_data) gets one computed here, in line, on the
+            # current stream -- never the previous batch's indices.
+            if pre is not None:
+                pyr, ev = pre
+                torch.cuda.current_stream(pyr[0].device).wait_event(ev)
+            else:
+                with torch.no_grad():
+                    fn = geometry_pyramid if len(static_pyr) > 4 else sampling_pyramid
+                    pyr = fn(data_dict["point_clouds"][..., :3].contiguous())
+            if len(pyr) != len(static_pyr):
+                raise RuntimeError(f"prefetched pyramid has {len(pyr)} tensors, the captured graph expects "
+                                   f"{len(static_pyr)} (prefetch_geometry changed after enable_graph?)")
+            for dst, src in zip(static_pyr, pyr):
                 dst.copy_(src, non_blocking=True)
                 src.record_stream(torch.cuda.current_stream(src.device))
+        elif pre is not None:
+            # graph captured WITHOUT a pyramid: it samples / groups inside the replay; the prefetched one is not needed
+            torch.cuda.current_stream(pre[0][0].device).wait_event(pre[1])
         for k, dst in self._static.items():
             if k != "fps_pyramid" and k in data_dict and data_dict[k] is not dst:
                 dst.copy_(data_dict[k], non_blocking=True)

@@ -176,6 +176,8 @@ def supported(mlp_module, nsample):
     layers = list(mlp_module.children())
     if len(layers) != 3 or not all(getattr(l, "has_bn", False) for l in layers):
         return False
+    if any(l.bn.bn.momentum is None for l in layers):
+        return False   # cumulative-average running statistics need the batch count on the host: per-operator path
     c = [l.conv.out_channels for l in layers]
     return bool(lib.spacap_sa_mlp_supported(*c)) and 1 <= nsample <= 255
 

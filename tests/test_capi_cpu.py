@@ -50,6 +50,20 @@ def test_argument_validation_needs_no_device():
     assert b"d_k=24" in lib.spacap_last_error()
 
 
+def test_fps_workspace_covers_the_dispatched_bucket_template():
+    """The bucketed FPS kernel indexes its planes with NPAD = NB*4096 where NB is the template instance that gets
+    launched (3,4,5,6,8,10,12,16 with the index map in LDS; 16,20 beyond 65 535 points), not ceil(N/4096)."""
+    from spacap3d_amd._native import lib
+    inst = (3, 4, 5, 6, 8, 10, 12, 16)
+    for N in (8193, 24576, 24577, 28672, 33000, 36864, 40000, 40960, 40961, 45056, 50000, 61440, 65535, 65536, 70000,
+              77824, 81920):
+        nb = (N + 4095) // 4096
+        NB = next(v for v in inst if nb <= v) if N <= 65535 else (16 if nb <= 16 else 20)
+        planes = 3 if N <= 65535 else 4
+        for B in (1, 8):
+            assert lib.spacap_fps_workspace_bytes(B, N) >= B * planes * NB * 4096 * 4, N
+
+
 def test_host_shim_fails_loudly_on_cpu_tensors():
     from spacap3d_amd import attention, ext
     xyz = torch.rand(1, 64, 3)

@@ -61,6 +61,60 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
             assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (name, i, a, other)
 
 
+def test_graph_step_never_reuses_the_previous_batch_geometry():
+    """A graph captured WITH a prefetched pyramid reads sampling / grouping indices from static buffers.  Feeding it a
+    NEW batch that carries no prefetch (epoch boundary, caller without next_data) must compute that batch's pyramid in
+    line -- not replay the previous batch's indices on the new point cloud."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+
+    def run(graph):
+        model = _make()
+        tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6)
+        a = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+        b = synthetic_batch(2, 4096, DEV, seed=4, vocab=200)
+        tr.step(a, next_data=a)
+        if graph:
+            assert tr.enable_graph(a, warmup=2), tr.graph_error
+        else:
+            tr.step(a), tr.step(a)
+        la = float(tr.step(dict(a)))              # no prefetch attached
+        lb = float(tr.step(dict(b)))              # different scenes, no prefetch attached
+        lb2 = float(tr.step(dict(b), next_data=b))
+        lb3 = float(tr.step(b))                   # consumes the prefetch
+        return la, lb, lb2, lb3
+
+    e, g = run(False), run(True)
+    assert abs(e[0] - e[1]) > 1e-3 * abs(e[0]), "the two batches must differ for this test to mean anything"
+    for x, y in zip(e, g):
+        assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (e, g)
+
+
+def test_hyperparameter_change_reaches_a_captured_graph():
+    """lr and the BatchNorm momentum are kernel arguments, frozen into the hipGraph: Trainer.set_hyper re-captures."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    model = _make()
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-3)
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    tr.step(data, next_data=data)
+    assert tr.enable_graph(data, warmup=1), tr.graph_error
+    tr.step(data, next_data=data)
+    w = model.backbone_net.sa2.mlp_module.layer1.conv.weight
+    bn = model.backbone_net.sa2.mlp_module.layer1.bn.bn
+    before, rm = w.detach().clone(), bn.running_mean.clone()
+    tr.step(data, next_data=data)
+    assert not torch.equal(w, before) and not torch.equal(bn.running_mean, rm)
+    tr.set_hyper(lr=0.0, bn_momentum=0.0)
+    before, rm = w.detach().clone(), bn.running_mean.clone()
+    l1 = float(tr.step(data, next_data=data))
+    l2 = float(tr.step(data, next_data=data))
+    assert torch.equal(w, before), "lr = 0 must freeze the parameters (weight decay scales with lr too)"
+    assert torch.equal(bn.running_mean, rm), "momentum = 0 must freeze the running statistics"
+    assert l1 == l1 and abs(l1 - l2) <= 1e-3 * abs(l1)
+    tr.set_hyper(lr=1e-3)
+    tr.step(data, next_data=data)
+    assert not torch.equal(w, before)
+
+
 def test_geometry_pyramid_equals_what_the_modules_compute_themselves():
     """detector.geometry_pyramid (sampling indices, ball-query groupings, interpolation neighbours: everything the
     trainer prefetches on the side stream) fed through the backbone must give bit-identical features to the backbone

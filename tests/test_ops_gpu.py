@@ -35,6 +35,27 @@ def test_fps_bit_exact(hip_ext, oracle_ext, N, m):
     assert torch.equal(got, want), f"first mismatch at {(got != want).nonzero()[0].tolist()}"
 
 
+@pytest.mark.parametrize("N", [26000, 28672, 33000, 36864, 41000, 45056, 50000, 61440, 66000, 70000, 77824])
+def test_fps_stays_inside_its_workspace(oracle_ext, N):
+    """The bucketed kernel lays its planes out with NPAD = NB*4096 for the DISPATCHED template NB (3,4,5,6,8,10,12,16,20),
+    which exceeds ceil(N/4096) for these N: spacap_fps_workspace_bytes must size for it.  The workspace handed to the C
+    ABI is the exact-size prefix of a larger buffer whose tail is a guard pattern."""
+    from spacap3d_amd._native import check, lib
+    B, m = 2, 24
+    xyz = _scene(N, seed=N, B=B)
+    want = oracle_ext.furthest_point_sampling(xyz, m)
+    nbytes = int(lib.spacap_fps_workspace_bytes(B, N))
+    guard = 4 << 20
+    buf = torch.full((nbytes + guard,), 0xA5, dtype=torch.uint8, device=DEV)
+    x = xyz.to(DEV)
+    out = torch.empty(B, m, dtype=torch.int32, device=DEV)
+    check(lib.spacap_fps_f32(x.data_ptr(), B, N, m, buf.data_ptr(), out.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream), "fps")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
+    assert bool((buf[nbytes:] == 0xA5).all()), "FPS wrote past spacap_fps_workspace_bytes()"
+
+
 @pytest.mark.parametrize("N,m", [(512, 128), (700, 64), (1024, 256), (2048, 256), (5000, 300), (40000, 400)])
 def test_fps_ties_on_a_grid(hip_ext, oracle_ext, N, m):
     """Integer-lattice points: almost every round has many exactly equal maxima, so the result is decided
