@@ -41,6 +41,10 @@ CFG = {  # BASELINE.json configs[1..]
     "cfg2": dict(n_points=40000, proposals=256, batch=8, feats=dict(), transformer=dict()),
     "cfg3": dict(n_points=40000, proposals=256, batch=8, feats=dict(use_color=True, use_normal=True), transformer=dict()),
     "cfg4": dict(n_points=40000, proposals=256, batch=8, feats=dict(use_multiview=True, use_normal=True), transformer=dict()),
+    # stress config: 80 000 points, 512 proposals, 16 scenes / GPU; "d_model=512" cannot run in the reference (no input
+    # projection, relation head hard-codes d_k = 16: SURVEY.md section 5) -- built here with the documented deviation:
+    # Linear(128, 512) token projection (transformer_captioner.TransformerDecoderModel.token_proj) and h = 32
+    "cfg5": dict(n_points=80000, proposals=512, batch=16, feats=dict(), transformer=dict(d_model=512, h=32)),
 }
 
 
@@ -86,7 +90,8 @@ def cpu_baseline(cfg, sample_batch):
     torch.set_num_threads(cores)
     with backend.use_backend(be):
         torch.manual_seed(0)
-        model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"])
+        model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"],
+                              **cfg["transformer"])
         model.train()
         tr = Trainer(model, S.mean_size_arr().numpy())
         small = synthetic_batch(1, 2048, "cpu", seed=1, **cfg["feats"])
@@ -132,7 +137,8 @@ def main():
     be.furthest_point_sampling = fps_timer
 
     torch.manual_seed(0)
-    model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"]).to(dev)
+    model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"],
+                          **cfg["transformer"]).to(dev)
     model.train()
     if args.ablate == "relation":
         model.caption.check_relation = False

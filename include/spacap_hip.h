@@ -227,6 +227,7 @@ int spacap_relation_l1_fwd_f32(const float *P, const float *U, const float *b1, 
  * db_part f32 [spacap_relation_l1_blocks(B,K,C), C] are partial sums (per query chunk / per workgroup) that the
  * caller adds up in order. */
 int spacap_relation_l1_isplit(void);
+int spacap_relation_l1_supported(int H, int K, int C); /* 1 when relation_l1_fwd/bwd have a kernel for this shape */
 int spacap_relation_l1_blocks(int B, int K, int C);
 int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, const float *P, const float *U, int B, int H,
                                int K, int C, float *dP, float *dU, float *db_part, spacap_stream_t stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "spacap_relation_feature_fwd_f32": (_i, [_p, _p, _l, _l, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_feature_bwd_f32": (_i, [_p, _p, _p, _l, _l, _l, _i, _i, _i, _i, _p, _p, _p]),
     "spacap_relation_l1_isplit": (_i, []),
+    "spacap_relation_l1_supported": (_i, [_i, _i, _i]),
     "spacap_relation_l1_blocks": (_i, [_i, _i, _i]),
     "spacap_relation_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),

@@ -412,5 +412,8 @@ def relation_layer1(P, V, weight, bias):
         raise RuntimeError("CPU not supported")
     B, H, K, D = V.shape
     C = weight.shape[0]
+    if not lib.spacap_relation_l1_supported(H, K, C):
+        # widths without a fused kernel (cfg5: d_model 512): the feature is formed (one launch) and multiplied by BLAS
+        return torch.relu(torch.nn.functional.linear(RelationFeature.apply(P, V), weight, bias))
     U = torch.einsum("bhjd,ohd->bjho", V, weight.view(C, H, D))  # (B,K,H,C): tiny, autograd gives dV and dW1
     return RelationLayer1.apply(P, U, bias)

@@ -217,6 +217,7 @@ bool l1_shape_ok(int H, int K, int C) {
 
 constexpr int L1_ISPLIT = 4;  // query chunks per key tile in the backward (partial dU / db per chunk)
 extern "C" int spacap_relation_l1_isplit(void) { return L1_ISPLIT; }
+extern "C" int spacap_relation_l1_supported(int H, int K, int C) { return l1_shape_ok(H, K, C) ? 1 : 0; }
 extern "C" int spacap_relation_l1_blocks(int B, int K, int C) {
   return L1_ISPLIT * B * ((K + 256 / (C / 4) - 1) / (256 / (C / 4)));
 }

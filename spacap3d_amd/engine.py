@@ -31,6 +31,7 @@ class Trainer:
         self._eager_checks = 2     # first steps: verify the deferred-gradient contract (see _core)
         self._graph_grads = None
         self._capture_stream = None
+        self.last_losses = {}
         self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
@@ -164,6 +165,9 @@ class Trainer:
         streams.enable(False)            # the switch is process-wide: do not leak it to callers outside the step
         if with_optimizer:
             self._optimizer_step(None)
+        # the loss terms of this step as device scalars (no host sync; under graph replay: the static result tensors)
+        self.last_losses = {k: d[k].detach() for k in ("loss", "vote_loss", "objectness_loss", "box_loss", "sem_cls_loss",
+                                                       "cap_loss", "relation_loss") if k in d and torch.is_tensor(d[k])}
         return d["loss"].detach()
 
     def _optimizer_step(self, sources):

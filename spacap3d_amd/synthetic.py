@@ -134,6 +134,26 @@ def labels(batch: int, n_points: int, vocab: int = 3001, seed: int = 0, n_gt: in
     return d
 
 
+def anchor_boxes_on_proposals(lab: dict, aggregated_vote_xyz: torch.Tensor, n_gt: int = 32, seed: int = 3) -> dict:
+    """Move the first ``n_gt`` ground-truth box centres onto (0.05 m jitter) randomly chosen proposal positions
+    ``aggregated_vote_xyz`` (B, P, 3) of a probe forward, and the reference object onto the first of them.  With the
+    unrelated random centres of ``labels`` almost no proposal is a positive (objectness_label, lib/loss_helper.py:
+    NEAR_THRESHOLD 0.3), so the box / class / relation losses are means over 0-3 items that switch on and off from step
+    to step; anchored boxes give every step ~n_gt positives per scene (what the fixtures and trajectory tests use)."""
+    agg = aggregated_vote_xyz.detach().cpu()
+    B, P, _ = agg.shape
+    n_gt = min(n_gt, P)
+    g = torch.Generator().manual_seed(seed)
+    pick = torch.stack([torch.randperm(P, generator=g)[:n_gt] for _ in range(B)])
+    ctr = torch.gather(agg, 1, pick.unsqueeze(-1).expand(-1, -1, 3)) + 0.05 * torch.randn(B, n_gt, 3, generator=g)
+    out = dict(lab)
+    c = lab["center_label"].detach().cpu().clone()
+    c[:, :n_gt] = ctr
+    out["center_label"] = c.to(lab["center_label"].device)
+    out["ref_center_label"] = ctr[:, 0].clone().to(lab["ref_center_label"].device)
+    return out
+
+
 def make_vocabulary(vocab: int = 3001) -> dict:
     words = ["pad_", "unk", "sos", "eos"] + [f"w{i}" for i in range(vocab - 4)]
     return {"word2idx": {w: i for i, w in enumerate(words)}, "idx2word": {str(i): w for i, w in enumerate(words)}}
@@ -147,6 +167,6 @@ def attention_inputs(B: int, h: int, Lq: int, Lk: int, d_k: int, seed: int = 0, 
     return q, k, v
 
 
-__all__ = ["room_xyz", "uniform_xyz", "scene_batch", "num_extra_channels", "labels", "mean_size_arr", "make_vocabulary",
+__all__ = ["anchor_boxes_on_proposals", "room_xyz", "uniform_xyz", "scene_batch", "num_extra_channels", "labels", "mean_size_arr", "make_vocabulary",
            "attention_inputs", "MAX_NUM_OBJ", "MAX_DES_LEN", "NUM_CLASS", "NUM_SIZE_CLUSTER", "NUM_HEADING_BIN"]
 _ = math

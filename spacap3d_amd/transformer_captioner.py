@@ -20,6 +20,7 @@ from .backend import ops
 from .loss_helper import nn_distance
 
 MAX_DES_LEN = 30  # lib/config.py:55
+PROPOSAL_FEATURE_DIM = 128  # models/proposal_module.py:39 (vote aggregation mlp [..., 128])
 
 
 def subsequent_mask(size, device=None):
@@ -382,6 +383,11 @@ class TransformerDecoderModel(nn.Module):
                                      dropout=transformer_dropout, bn_momentum=bn_momentum,
                                      src_pos_type=src_pos_type, use_transformer_encoder=use_transformer_encoder,
                                      early_guide=early_guide)
+        # DEVIATION (BASELINE configs[4] "d_model=512"): the reference has no input projection, so
+        # its encoder only runs with d_model == 128 (the proposal feature width, :163-164).  For other widths the 128-d
+        # proposal tokens go through one Linear(128, d_model) first; with d_model == 128 (every reference configuration)
+        # the module does not exist and the state-dict layout is the reference's.
+        self.token_proj = nn.Linear(PROPOSAL_FEATURE_DIM, d_model) if d_model != PROPOSAL_FEATURE_DIM else None
         if check_relation:
             self.relation_proposal = nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(),
                                                    nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, 9))
@@ -445,6 +451,8 @@ class TransformerDecoderModel(nn.Module):
 
     def forward_train(self, ep):
         src = ep["aggregated_vote_features"]
+        if self.token_proj is not None:
+            src = _linear(src, self.token_proj)
         src_pos = self._src_pos(ep)
         _, _, target_ious, idx = nn_distance(ep["aggregated_vote_xyz"], ep["ref_center_label"].unsqueeze(1))
         ep["match_idx"] = idx.squeeze(1)
@@ -491,6 +499,8 @@ class TransformerDecoderModel(nn.Module):
         processes the newest token (16x fewer token-layer evaluations).  ``use_cache=False`` recomputes the prefix
         as the reference does (kept for parity tests)."""
         obj_features = ep["aggregated_vote_features"]
+        if self.token_proj is not None:
+            obj_features = self.token_proj(obj_features)
         B, K, _ = obj_features.shape
         src_pos = self._src_pos(ep)
         if not self.use_transformer_encoder:
