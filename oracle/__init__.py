@@ -31,7 +31,7 @@ BUILD_DIR = os.path.join(_HERE, "_build")
 
 def build(force: bool = False) -> None:
     """Compile the C restatement (gcc, seconds)."""
-    libs = [os.path.join(BUILD_DIR, n) for n in ("liboracle.so", "liboracle_omp.so")]
+    libs = [os.path.join(BUILD_DIR, n) for n in ("liboracle.so", "liboracle_omp.so", "liboracle_fma.so")]
     src = os.path.join(_HERE, "pointnet2_oracle.c")
     fresh = all(os.path.exists(p) and os.path.getmtime(p) >= os.path.getmtime(src) for p in libs)
     if fresh and not force:
@@ -39,5 +39,7 @@ def build(force: bool = False) -> None:
     subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)
 
 
-def lib_path(openmp: bool = False) -> str:
+def lib_path(openmp: bool = False, fma: bool = False) -> str:
+    if fma:   # nvcc-default contraction of the distance sums (OpenMP build); never the parity target
+        return os.path.join(BUILD_DIR, "liboracle_fma.so")
     return os.path.join(BUILD_DIR, "liboracle_omp.so" if openmp else "liboracle.so")

@@ -29,10 +29,11 @@ def _check(t, name, dtype):
 class OracleExt:
     """Drop-in for the object the reference binds as ``pointnet2_utils._ext``."""
 
-    def __init__(self, openmp: bool = False):
+    def __init__(self, openmp: bool = False, fma: bool = False):
         build()
-        self.openmp = openmp
-        self._lib = ctypes.CDLL(lib_path(openmp))
+        self.openmp = openmp or fma
+        self.fma = fma
+        self._lib = ctypes.CDLL(lib_path(openmp, fma))
         L = self._lib
         L.oracle_opt_n_threads.restype = _c_int
         L.oracle_opt_n_threads.argtypes = [_c_int]

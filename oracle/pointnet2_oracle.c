@@ -39,6 +39,19 @@
 
 #define ORACLE_TOTAL_THREADS 512 /* include/cuda_utils.h:13 */
 
+/* Sum of three squares `a*a + b*b + c*c` as the .cu sources write it.
+ * Canonical build: un-contracted, left to right (three products, two adds, five roundings).
+ * -DORACLE_FMA build (liboracle_fma.so): what nvcc emits for that expression with its DEFAULT
+ * --fmad=true (the reference's setup.py passes only -O3): mul, fma, fma -- three roundings.  That variant exists only to
+ * QUANTIFY how often the reference *binary* could decide differently from its *source* semantics on
+ * borderline comparisons (tests/test_oracle.py::test_fma_contraction_caveat_is_quantified); it is never
+ * the parity target. */
+#ifdef ORACLE_FMA
+#define SQSUM3(a, b, c) fmaf((c), (c), fmaf((b), (b), (a) * (a)))
+#else
+#define SQSUM3(a, b, c) (((a) * (a) + (b) * (b)) + (c) * (c))
+#endif
+
 /* include/cuda_utils.h:15-19: pow_2 = (int)(log(work)/log(2)); clamp(1<<pow_2, 1, 512).
  * The double-precision quotient is restated literally because its truncation
  * decides the FPS block size and with it the arg-max tie-break. */
@@ -90,10 +103,10 @@ static void fps_one_scene(int n, int m, const float *dataset, float *temp,
       const float x2 = dataset[k * 3 + 0];
       const float y2 = dataset[k * 3 + 1];
       const float z2 = dataset[k * 3 + 2];
-      const float mag = (x2 * x2) + (y2 * y2) + (z2 * z2); /* :100 */
+      const float mag = SQSUM3(x2, y2, z2); /* :100  (x2*x2) + (y2*y2) + (z2*z2) */
       if ((double)mag <= 1e-3) continue;                   /* :101 */
-      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) +
-                      (z2 - z1) * (z2 - z1); /* :103-104 */
+      const float dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+      const float d = SQSUM3(dx, dy, dz); /* :103-104  (x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1) */
       const float d2 = fminf(d, temp[k]);    /* :106 */
       temp[k] = d2;
       if (d2 > dists[t]) { /* :108-109 */
@@ -192,8 +205,8 @@ void oracle_ball_query(int b, int n, int m, float radius, int nsample,
         const float x = pts[k * 3 + 0];
         const float y = pts[k * 3 + 1];
         const float z = pts[k * 3 + 2];
-        const float d2 = (new_x - x) * (new_x - x) + (new_y - y) * (new_y - y) +
-                         (new_z - z) * (new_z - z);
+        const float ex = new_x - x, ey = new_y - y, ez = new_z - z;
+        const float d2 = SQSUM3(ex, ey, ez); /* ball_query_gpu.cu:31-32 */
         if (d2 < radius2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) row[l] = k;
@@ -257,8 +270,8 @@ void oracle_three_nn(int b, int n, int m, const float *unknown,
       int besti1 = 0, besti2 = 0, besti3 = 0;
       for (int k = 0; k < m; ++k) {
         const float x = kn[k * 3 + 0], y = kn[k * 3 + 1], z = kn[k * 3 + 2];
-        const float d =
-            (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+        const float ex = ux - x, ey = uy - y, ez = uz - z;
+        const float d = SQSUM3(ex, ey, ez); /* interpolate_gpu.cu:31-32 */
         if ((double)d < best1) {
           best3 = best2; besti3 = besti2;
           best2 = best1; besti2 = besti1;

@@ -204,7 +204,17 @@ class _FeatureProduct(Function):
         dW = torch.zeros_like(W1)
         nslab = int(lib.spacap_linear_wgrad_slabs(R, C1, Cf)) if x2.is_contiguous() else 0
         if nslab == 0:
-            dW[:, 3:] = g2.t() @ x2
+            # Channel counts without a slab kernel (cfg3: 7, cfg4: 132 input channels).  The reduction runs over every
+            # source point of the batch (320 000 at cfg2 sizes) and the incoming gradient sums to ~0 per channel
+            # (BatchNorm), so one long fp32 accumulation loses digits to cancellation (4e-3 of the result against
+            # float64 at C = 132) and the BLAS heuristics do not split K: 64 row slabs as one batched GEMM + an ordered
+            # sum instead (as relation-head weight gradients, transformer_captioner._TallLinear).
+            S = 64
+            if R % S == 0 and R >= 64 * S:
+                pw = torch.bmm(g2.view(S, R // S, C1).transpose(1, 2), x2.reshape(S, R // S, Cf))
+                dW[:, 3:] = sum_slabs(pw.view(S, C1 * Cf) if (C1 * Cf) % 4 == 0 else pw).view(C1, Cf)
+            else:
+                dW[:, 3:] = g2.t() @ x2
         else:
             with torch.cuda.device(g2.device):
                 part = torch.empty(nslab, C1 * Cf, dtype=torch.float32, device=g2.device)

@@ -5,9 +5,9 @@ Two legs over the same assertions:
   * ``oracle`` (CPU, runs everywhere): host logic + CPU oracle ops  -> checks the port of the glue;
   * ``hip``    (-m gpu): host logic + HIP kernels through the C ABI  -> checks the product path.
 Integer outputs (FPS / ball-query derived indices, assignments, greedy captions) must be identical.  Float
-outputs: 2e-4 on the CPU leg (same torch CPU kernels as the fixture generator); 2e-3 of the tensor's scale on the
-GPU leg, where every conv / matmul of the ~30-layer network runs on rocBLAS / MIOpen with a different
-fp32 summation order and train-mode BatchNorm renormalises the differences (measured: 2e-4 of scale).
+outputs: 2e-4 on the CPU leg (same torch CPU kernels as the fixture generator); 3e-4 of the tensor's scale (+ 4e-4
+relative) on the GPU leg, where every GEMM of the ~30-layer network runs with a different fp32 summation order and
+train-mode BatchNorm renormalises the differences (measured on MI355X: <= 1e-4 of scale, tools/lab/golden_err.py).
 """
 import os
 import sys
@@ -25,7 +25,7 @@ from spacap3d_amd.loss_helper import get_scene_cap_loss  # noqa: E402
 from spacap3d_amd.spacapnet import SpaCapNet  # noqa: E402
 
 G = os.path.join(HERE, "golden")
-TOL = {"cpu": (2e-4, 2e-5), "cuda:0": (2e-3, 1e-3)}
+TOL = {"cpu": (2e-4, 2e-5), "cuda:0": (4e-4, 3e-4)}
 _leg = {"device": "cpu"}
 
 
@@ -117,14 +117,15 @@ def test_train_step_matches_reference(kind):
             if device == "cpu" or (k.startswith("grad_caption.") and "relation" not in k):
                 _close(g, fx[k], k, rtol=2e-3, atol=2e-4)
             else:
-                # Detector gradients are ill-conditioned on this fixture: perturbing the weights by 3e-6
-                # (relative) on the CPU leg alone moves them by 4-12 % of their scale (ReLU / max-pool
-                # selections flip on ~1e-5 forward noise, each flip is a discrete change of one of ~100
-                # summands).  A different BLAS summation order is such a perturbation, so on the GPU leg
-                # they are only sanity-checked; every operator's backward is pinned tightly in
-                # tests/test_ops_gpu.py and tests/test_attention_gpu.py instead.
-                err = np.abs(g - fx[k]).max() / (np.abs(fx[k]).max() + 1e-12)
-                assert err < 0.3, (k, err)
+                # Detector / relation-head gradients on the GPU leg.  What makes this fixture ill-conditioned is ONE
+                # discrete step: the vote-aggregation FPS runs on network outputs (vote_xyz), and a 3e-6 relative
+                # weight perturbation on the CPU leg alone already changes which votes become proposals (aggregated
+                # features move by 100 % of their scale).  With the sampled indices identical -- asserted above --
+                # the gradients agree to fp32 summation-order noise amplified by the BatchNorm backward's
+                # cancellations; measured on MI355X (tools/lab/golden_err.py): linf <= 1.2e-2, l2 <= 2.8e-3.
+                linf = np.abs(g - fx[k]).max() / (np.abs(fx[k]).max() + 1e-12)
+                l2 = np.linalg.norm(g - fx[k]) / (np.linalg.norm(fx[k]) + 1e-12)
+                assert linf < 3e-2 and l2 < 6e-3, (k, linf, l2)
     absent = sorted(n for n, p in model.named_parameters() if p.grad is None)
     assert absent == list(fx["grad_absent"])
 
