@@ -12,13 +12,24 @@ head on, attention dropout 0.1 as in the reference) -- fp32, inputs resident in 
 are sharded by rank (weak scaling); rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      the dominant hand-written kernel (SA1 furthest-point sampling, N -> 2048): algorithmic bytes
-                B*(m-1)*N*20 (SURVEY.md section 8d streamed-traffic model) / its average duration measured with
-                events on the stream it is launched on (the prefetch side stream, i.e. while it shares the chip with
-                the dense kernels of the step) inside the timed steps, against 8 TB/s HBM; `isolated_ms` is the same
-                launch alone on an idle chip.
+  roofline      the dominant kernel of the step's critical path: the largest shared-MLP GEMM (SA2 layer 3, 262 144 rows,
+                128 -> 256 channels, `sa_mid_fwd_kernel<128,..>`; that kernel family is the largest block of main-stream
+                time).  achieved = algorithmic flops 2*cin*cout*R / its average launch duration, measured live with HIP
+                events around back-to-back launches through the C ABI on the launch stream right after the timed steps
+                (inside the step the kernel sits in a replayed hipGraph, where events cannot bracket it; the in-step
+                duration is in the committed rocprofv3 trace under profiles/, `profiled_us`).  peak = 157.3 TFLOP/s
+                (fp32 MFMA).  traffic = HBM bytes per launch from the tracked rocprofv3 --pmc passes
+                (profiles/rNN_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_parse.py) next to the algorithmic
+                4*R*(cin+cout).
+  roofline_more the same object for an HBM-bound layer (SA1 layer 2, 64 -> 64 on 1 048 576 rows) and for the SA1
+                furthest-point sampling, which is neither: an on-chip latency chain (bound "latency", us per round;
+                `in_step_us` = its duration on the prefetch side stream inside the timed steps, from events).
+  step          algorithmic flops of the whole training step and the resulting fraction of the fp32-MFMA peak.
+  drop_in       scenes/s when the caller invokes the model unchanged (no Trainer-level pipelining: furthest-point
+                sampling, ball queries and interpolation weights computed inside the step).
   cpu_baseline  the same training step on the host CPU (this repo's host code on device "cpu" driving the CPU
-                oracle ops, oracle/) on a bounded sample; rank 0, N = 1 only.
+                oracle ops, oracle/): single-thread canonical and OpenMP variants, warm-up + >= 3 timed steps each on a
+                bounded batch; per-operator CPU rates for FPS / ball query.  rank 0, N = 1 only.
   ops           FPS and ball_query Mpts/s at the SA1 shape (the second half of BASELINE.json's metric).
 """
 import argparse
@@ -31,6 +42,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 from spacap3d_amd import backend, synthetic as S  # noqa: E402
 from spacap3d_amd.distributed import init_from_env  # noqa: E402
@@ -82,28 +94,76 @@ def time_op(fn, iters=5, warm=1):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(cfg, sample_batch):
-    """One training step of the same model on the host CPU with the oracle ops (OpenMP build)."""
-    from oracle.attention_ref import OracleBackend
-    be = OracleBackend(openmp=True)
-    cores = be._ext.num_threads()
-    torch.set_num_threads(cores)
+def _cpu_steps(cfg, be, threads, batch, steps):
+    """warm-up step at size + `steps` timed steps of the training step on the CPU with backend `be`."""
+    torch.set_num_threads(threads)
     with backend.use_backend(be):
         torch.manual_seed(0)
         model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"],
                               **cfg["transformer"])
         model.train()
         tr = Trainer(model, S.mean_size_arr().numpy())
-        small = synthetic_batch(1, 2048, "cpu", seed=1, **cfg["feats"])
-        tr.step(small)  # builds the optimizer / thread pools on a tiny input (untimed)
-        data = synthetic_batch(sample_batch, cfg["n_points"], "cpu", seed=0, **cfg["feats"])
-        t0 = time.perf_counter()
-        tr.step(data)
-        dt = time.perf_counter() - t0
-    return {"value": sample_batch / dt, "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": f"1 full training step on {sample_batch} synthetic scene(s) of {cfg['n_points']} points "
-                      f"({dt:.1f} s): this repo's host code on device cpu + the C oracle ops (OpenMP) + torch CPU"}
+        data = synthetic_batch(batch, cfg["n_points"], "cpu", seed=0, **cfg["feats"])
+        tr.step(data)   # warm-up AT SIZE (optimizer set-up, thread pools, allocator), untimed
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            tr.step(data)
+            ts.append(time.perf_counter() - t0)
+    return ts
 
+
+def _cpu_ops(ext, B, N, m=2048, radius=0.2, nsample=64):
+    xyz = S.scene_batch(B, N, use_height=False, seed=1000)
+    t0 = time.perf_counter()
+    inds = ext.furthest_point_sampling(xyz, m)
+    t_fps = time.perf_counter() - t0
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    t0 = time.perf_counter()
+    ext.ball_query(new_xyz, xyz, radius, nsample)
+    t_bq = time.perf_counter() - t0
+    return {"scenes": B, "fps_Mpts_s": B * N / t_fps * 1e-6, "fps_s": t_fps, "ball_query_Mpts_s": B * N / t_bq * 1e-6,
+            "ball_query_s": t_bq}
+
+
+def cpu_baseline(cfg, omp_batch, steps):
+    """the same training step on the host CPU, this repo's host code on device "cpu" with the C oracle
+    ops + torch CPU (kind "port"), (i) single thread, canonical oracle; (ii) OpenMP oracle + all torch threads."""
+    from oracle.attention_ref import OracleBackend
+    omp = OracleBackend(openmp=True)
+    cores = omp._ext.num_threads()
+    t_omp = _cpu_steps(cfg, omp, cores, omp_batch, steps)
+    t_one = _cpu_steps(cfg, OracleBackend(openmp=False), 1, 1, steps)
+    ops_one = _cpu_ops(OracleBackend(openmp=False)._ext, 2, cfg["n_points"])
+    ops_omp = _cpu_ops(omp._ext, 8, cfg["n_points"])
+    torch.set_num_threads(cores)
+    mean = lambda v: sum(v) / len(v)
+    return {"value": omp_batch / mean(t_omp), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"OpenMP variant: 1 warm-up + {steps} timed full training steps on B = {omp_batch} synthetic scenes of "
+                      f"{cfg['n_points']} points ({', '.join(f'{t:.1f}' for t in t_omp)} s): this repo's host code on device cpu + "
+                      f"the C oracle ops (OpenMP over scene / centre) + torch CPU with {cores} threads",
+            "single_thread": {"value": 1 / mean(t_one), "unit": "scenes/s", "cores": 1,
+                              "sample": f"canonical single-thread oracle + torch with 1 thread: 1 warm-up + {steps} timed steps on "
+                                        f"B = 1 ({', '.join(f'{t:.1f}' for t in t_one)} s)"},
+            "ops": {"single_thread": ops_one, "openmp": ops_omp,
+                    "what": "oracle FPS N -> 2048 and ball query 2048 x N (r 0.2, 64 samples), one call each"}}
+
+
+def step_flops(cfg, B):
+    """Algorithmic flops of one training step (SURVEY.md section 8d formulas): dense layers 2*cin*cout*rows forward, x3 for
+    forward + data gradient + weight gradient (first layers of SA1 / the embedding have no data gradient: < 1 %)."""
+    N, P = cfg["n_points"], cfg["proposals"]
+    C = S.num_extra_channels(**cfg["feats"])
+    d = cfg["transformer"].get("d_model", 128)
+    dff, V, Lw = 2048, 3001, 32
+    mlp = lambda rows, chans: sum(2.0 * a * b * rows for a, b in zip(chans[:-1], chans[1:]))
+    f = mlp(2048 * 64, [C + 3, 64, 64, 128]) + mlp(1024 * 32, [131, 128, 128, 256]) + mlp(512 * 16, [259, 128, 128, 256])
+    f += mlp(256 * 16, [259, 128, 128, 256]) + mlp(512, [512, 256, 256]) + mlp(1024, [512, 256, 256])
+    f += mlp(1024, [256, 256, 256, 259]) + mlp(P * 16, [259, 128, 128, 128]) + mlp(P, [128, 128, 128, 97])
+    enc_layer = lambda L: 2.0 * L * d * d * 4 + 4.0 * L * L * d + 2.0 * L * d * dff * 2
+    f += 6 * enc_layer(P) + 6 * enc_layer(Lw) + 2.0 * (Lw - 1) * d * V + (2.0 * P * 128 * d if d != 128 else 0.0)
+    f += 2.0 * P * P * (d * d * 2 + d * 9)                      # relation head
+    return 3.0 * f * B
 
 def main():
     ap = argparse.ArgumentParser()
@@ -118,7 +178,9 @@ def main():
     ap.add_argument("--streams", action="store_true", help="run the detection losses as a side-stream branch (slower since they are fused)")
     ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
                                                  "relation head, 'caption' the whole captioner")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="scenes in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=2, help="scenes per step in the OpenMP CPU-baseline sample")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up at size)")
+    ap.add_argument("--no-drop-in", action="store_true", help="skip the extra unpipelined (drop-in caller) measurement")
     args = ap.parse_args()
 
     rank, local_rank, world = init_from_env()
@@ -180,36 +242,66 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss)
+    n_params, allreduce_bytes = sum(p.numel() for p in model.parameters()), trainer.bucket.nbytes
+
+    # -- drop-in caller: the model invoked unchanged, everything (sampling, grouping, neighbour search) inside the step --
+    drop_in = None
+    if world == 1 and nxt is not None and not args.no_drop_in and not args.ablate:
+        data.pop("_fps_prefetch", None)
+        ok = True
+        if graphed:
+            trainer.graph = None
+            ok = trainer.enable_graph(data, warmup=1)   # captured WITHOUT a pyramid: the graph samples in line
+        for _ in range(5):
+            trainer.step(data)
+        torch.cuda.synchronize()
+        k2 = max(5, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(k2):
+            trainer.step(data)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t0) / k2
+        drop_in = {"value": per_gpu / dt2, "unit": "scenes/s", "ms_per_step": dt2 * 1e3, "steps": k2, "hip_graph": bool(ok and graphed),
+                   "what": "same training step without Trainer-level pipelining: furthest-point sampling, ball queries and "
+                           "interpolation weights computed inside the step (what a caller of SpaCapNet.forward gets)"}
 
     if rank == 0:
+        import glob
+        import kernel_cases as KC
         ms_per_step = dt / args.steps * 1e3
         B, N, m = per_gpu, cfg["n_points"], 2048
-        fps_bytes = B * (m - 1) * N * 20  # 12 B xyz + 4 B temp read + 4 B temp write per point-update
-        fps_ms = fps_timer.mean_ms()
-        if not fps_ms:   # --no-prefetch with a hipGraph: the launch sits inside the graph, no live events; time it alone
-            xyz0 = data["point_clouds"][..., :3].contiguous()
-            fps_ms = time_op(lambda: fps_timer.fn(xyz0, m))
-        roof = {"bound": "hbm", "kernel": "fps_bucket_kernel<10> (SA1 furthest point sampling, 40000 -> 2048, runs on the prefetch side stream)",
-                "achieved": fps_bytes / (fps_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": fps_bytes / (fps_ms * 1e-3) / 1e9 / 8000.0,
-                # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_fps_*.csv: FETCH_SIZE 4037 KB,
-                # doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE 3904 KB); cannot be collected
-                # from inside this process.  It is 0.1 % of the algorithmic bytes: the kernel is on-chip resident.
-                "traffic": (2 * 4037 + 3904) * 1024 if (B, N) == (8, 40000) else None,
-                "launch_ms": fps_ms, "launches_timed": len(fps_timer.events),
-                "algorithmic_bytes_per_launch": fps_bytes}
-        roof_fill = roof
+        del trainer
+        torch.cuda.empty_cache()
+        # rocprofv3 --pmc evidence collected by tools/pmc_run.sh at the cfg2 shapes and committed under profiles/
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+        pmc = json.load(open(pmc_files[-1])) if (pmc_files and (B, N) == (8, 40000)) else {}
+        R2, R1 = B * 1024 * 32, B * 2048 * 64
+        c_mfma = KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3")
+        roof = KC.roofline_entry(c_mfma, KC.time_case(c_mfma), pmc)
+        roof["launches_timed"] = 20
+        roof["how"] = ("20 back-to-back launches through the C ABI between two HIP events on the launch stream, right after the "
+                       "timed steps; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+        del c_mfma
+        c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
+        roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)
+        del c_hbm
+        c_fps = KC.fps(B, N, m, dev)
+        t_fps_us = KC.time_case(c_fps, iters=5, warm=1)
+        roof_fps = KC.roofline_entry(c_fps, t_fps_us, pmc)
+        roof_fps["in_step_us"] = fps_timer.mean_ms() * 1e3 if fps_timer.events else None
+        roof_fps["in_step_launches_timed"] = len(fps_timer.events)
+        roof_fps["compulsory_bytes"] = c_fps["compulsory_bytes"]
+        del c_fps
         # isolated SA1-shaped op rates (second half of the BASELINE metric)
         xyz = data["point_clouds"][..., :3].contiguous()
         t_fps = time_op(lambda: fps_timer.fn(xyz, m))
         inds = fps_timer.fn(xyz, m)
         new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
         t_bq = time_op(lambda: be.ball_query(new_xyz, xyz, 0.2, 64))
-        roof_fill["isolated_ms"] = t_fps
-        roof_fill["isolated_frac"] = fps_bytes / (t_fps * 1e-3) / 1e9 / 8000.0
         ops = {"fps_Mpts_s": B * N / t_fps * 1e-3, "fps_ms": t_fps, "fps_Gupdates_s": B * N * (m - 1) / t_fps * 1e-6,
                "ball_query_Mpts_s": B * N / t_bq * 1e-3, "ball_query_ms": t_bq,
                "ball_query_Gpairs_s": B * m * N / t_bq * 1e-6}
+        fl = step_flops(cfg, per_gpu)
         line = {
             "metric": "scenes/sec (40k pts, 256 proposals) fwd+bwd", "value": per_gpu * world / (dt / args.steps),
             "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,18 +310,23 @@ def main():
             "config": {"workload": f"{args.config}: synthetic ScanRefer-shaped scans, {N} pts x (xyz+"
                                    f"{S.num_extra_channels(**cfg['feats'])} ch), {cfg['proposals']} proposals, "
                                    f"{per_gpu} scenes/GPU; full training step (SpaCapNet fwd + loss + bwd + "
-                                   f"grad all-reduce + Adam)",
+                                   f"grad all-reduce + Adam)"
+                                   + (f"; transformer {cfg['transformer']} with the 128->512 token projection" if cfg["transformer"] else ""),
                        "global_batch": per_gpu * world, "parallelism": f"dp{world}",
                        "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
-                       "side_stream_branches": bool(trainer.multi_stream),
-                       "params": sum(p.numel() for p in model.parameters()),
-                       "allreduce_bytes": trainer.bucket.nbytes},
-            "roofline": roof, "ops": ops, "final_loss": loss_val,
+                       "side_stream_branches": bool(args.streams),
+                       "params": n_params, "allreduce_bytes": allreduce_bytes},
+            "roofline": roof, "roofline_more": [roof_hbm, roof_fps],
+            "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
+                     "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
+            "ops": ops, "final_loss": loss_val,
         }
+        if drop_in is not None:
+            line["drop_in"] = drop_in
         if args.ablate:
             line["metric"] += f" [ABLATION {args.ablate}: not the headline metric]"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

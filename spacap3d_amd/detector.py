@@ -198,7 +198,12 @@ class ProposalModule(nn.Module):
             nn.Conv1d(128, 2 + 3 + num_heading_bin * 2 + num_size_cluster * 4 + num_class, 1))
 
     def forward(self, xyz, features, data_dict):
-        xyz, features, fps_inds = self.vote_aggregation(xyz, features)
+        # ``proposal_inds`` (B, num_proposal) int32, optional: precomputed vote-sampling indices, handed to the SA module's
+        # ``inds`` argument (the reference interface, pointnet2_modules.py:214,236-239).  The default -- furthest-point
+        # sampling of the predicted vote positions -- is a discrete, chaotic function of network outputs (a 3e-6 relative
+        # weight perturbation changes which votes become proposals); parity / trajectory tests pin it to compare the
+        # continuous part of the step.
+        xyz, features, fps_inds = self.vote_aggregation(xyz, features, data_dict.get("proposal_inds"))
         data_dict["aggregated_vote_xyz"] = xyz
         pm = getattr(features, "_point_major", None)   # the fused SA op's own (B,K,128) result
         data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()

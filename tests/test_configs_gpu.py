@@ -148,7 +148,12 @@ def test_cfg5_training_step_matches_the_cpu_checker():
         with backend.use_backend(be):
             model = _cfg5_model(dev)
             assert model.caption.token_proj is not None and model.caption.token_proj.weight.shape == (512, 128)
-            d = model({k: v.to(dev) for k, v in data.items()})
+            inp = {k: v.to(dev) for k, v in data.items()}
+            if name == "hip":
+                # 512 of 1 024 predicted vote positions by FPS: chaotic in the weights (detector.ProposalModule.forward);
+                # the HIP run samples the CPU run's votes so that everything downstream is comparable
+                inp["proposal_inds"] = res["cpu"][0]["aggregated_vote_inds"].to(dev)
+            d = model(inp)
             d = get_scene_cap_loss(d, use_relation=True, mean_size_arr=S.mean_size_arr().numpy())
             d["loss"].backward()
             res[name] = (d, model)
@@ -161,7 +166,7 @@ def test_cfg5_training_step_matches_the_cpu_checker():
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
-    for k in ("fp2_features", "aggregated_vote_features", "lang_cap", "relation_pred", "center"):
+    for k in ("fp2_features", "vote_xyz", "vote_features", "aggregated_vote_features", "lang_cap", "relation_pred", "center"):
         assert rel(h[k], c[k]) < 2e-3, (k, rel(h[k], c[k]))
     for k in ("loss", "vote_loss", "objectness_loss", "box_loss", "cap_loss", "relation_loss"):
         assert abs(float(h[k]) - float(c[k])) <= 2e-3 * max(1.0, abs(float(c[k]))), (k, float(h[k]), float(c[k]))

@@ -113,3 +113,32 @@ def test_flat_bucket_pack_mode_matches_view_mode():
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bb.params, bb.views))
     bb.zero()
     assert all(p.grad is None for p in bb.params)
+
+
+def _launch_workers(device, nproc=2, extra=(), timeout=900):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "tests", "dist_worker.py"), "--device", device,
+           *extra]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:] + out.stdout[-1000:]
+    assert out.stdout.count("DIST_OK") == nproc, out.stdout[-2000:]
+
+
+def test_real_training_step_on_two_gloo_ranks():
+    """The real Trainer step (CPU checker backend) on 2 ranks launched as the driver launches bench.py: reduced bucket =
+    mean of the local buckets, bit-identical on both ranks; parameters stay bit-identical after the optimizer steps."""
+    _launch_workers("cpu")
+
+
+@pytest.mark.gpu
+def test_real_training_step_on_two_rccl_ranks():
+    """Same checks over RCCL with one GPU per rank (eager step, then the hipGraph + outside-graph all-reduce path);
+    skipped on boxes with a single GPU."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    _launch_workers("cuda")
+    _launch_workers("cuda", extra=("--graph", "--steps", "3"))

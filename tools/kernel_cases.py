@@ -1,0 +1,189 @@
+"""The hot kernels of the training step as stand-alone launches at their cfg2 shapes (8 scenes x 40 000 points,
+256 proposals), through the C ABI on synthetic device buffers -- measurement tooling shared by
+
+  * bench.py             live HIP-event timing of the roofline kernels right after the timed steps,
+  * tools/pmc_kernels.py the same launches under `rocprofv3 --pmc ...` (FETCH_SIZE / WRITE_SIZE / MFMA counters).
+
+Every case states its ALGORITHMIC work per launch: flops and bytes.
+  shared-MLP layer  flops 2*cin*cout*R, bytes 4*R*(cin+cout)
+  FPS               bytes B*(m-1)*N*20 (streamed model), rounds m-1 (latency chain)
+  MHA per layer     flops 4*B*h*Lq*Lk*d_k, bytes 4*B*L*4*h*d_k (+ 4*B*h*Lq*Lk when P is emitted)
+  relation head     per layer flops 2*B*K*K*cin*cout, bytes 4*B*K*K*(cin+cout)
+"""
+import torch
+
+from spacap3d_amd._native import check, lib
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
+PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
+
+
+def _st(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _rand(*shape, dev):
+    return torch.randn(*shape, dtype=torch.float32, device=dev)
+
+
+def _stats(C, dev):
+    st = torch.empty(C, 4, dtype=torch.float32, device=dev)
+    st[:, 0] = 0.05 * torch.randn(C, device=dev)
+    st[:, 1] = 1.0 + 0.1 * torch.rand(C, device=dev)
+    st[:, 2] = st[:, 1] * (1.0 + 0.1 * torch.rand(C, device=dev))
+    st[:, 3] = 0.1 * torch.randn(C, device=dev)
+    return st
+
+
+def _part(C, dev):
+    return torch.empty(int(lib.spacap_sa_nparts()) * 2 * C, dtype=torch.float64, device=dev)
+
+
+def sa_mid_fwd(R, cin, cout, dev, label):
+    zin, st, W = _rand(R, cin, dev=dev), _stats(cin, dev), _rand(cout, cin, dev=dev) * 0.1
+    zout, part = torch.empty(R, cout, dtype=torch.float32, device=dev), _part(max(cin, cout), dev)
+
+    def run():
+        check(lib.spacap_sa_mid_fwd_f32(zin.data_ptr(), st.data_ptr(), W.data_ptr(), R, cin, cout, zout.data_ptr(),
+                                        part.data_ptr(), _st(dev)), "sa_mid_fwd")
+    return dict(name=f"sa_mid_fwd {cin}->{cout} R={R} ({label})", kernel="sa_mid_fwd_kernel", run=run,
+                flops=2.0 * cin * cout * R, bytes=4.0 * R * (cin + cout), keep=(zin, st, W, zout, part),
+                what=f"{label}: z_out = relu(bn(z_in)) W^T + batch statistics of z_out, {R} rows, {cin} -> {cout} channels")
+
+
+def sa_dgrad(R, ck, cp, pooled, S, dev, label):
+    G = R // S
+    dy = _rand(G if pooled else R, ck, dev=dev)
+    arg = torch.randint(0, S, (G, ck), dtype=torch.uint8, device=dev) if pooled else None
+    zk, zp = _rand(R, ck, dev=dev), _rand(R, cp, dev=dev)
+    coef, stp, W = _stats(ck, dev), _stats(cp, dev), _rand(ck, cp, dev=dev) * 0.1
+    dyp, part = torch.empty(R, cp, dtype=torch.float32, device=dev), _part(max(ck, cp), dev)
+
+    def run():
+        check(lib.spacap_sa_dgrad_f32(dy.data_ptr(), arg.data_ptr() if pooled else None, S if pooled else 0, zk.data_ptr(),
+                                      coef.data_ptr(), W.data_ptr(), zp.data_ptr(), stp.data_ptr(), R, ck, cp, dyp.data_ptr(),
+                                      part.data_ptr(), _st(dev)), "sa_dgrad")
+    # reads: z_k (dense dz is rebuilt from it), z_prev (ReLU mask), dy (dense) or the pooled gradient; writes dy_prev
+    byts = 4.0 * R * (ck + 2 * cp) + (4.0 * G * ck + G * ck if pooled else 4.0 * R * ck)
+    return dict(name=f"sa_dgrad {ck}->{cp} R={R} {'pooled' if pooled else 'dense'} ({label})", kernel="sa_dgrad_kernel", run=run,
+                flops=2.0 * ck * cp * R, bytes=byts, keep=(dy, arg, zk, zp, coef, stp, W, dyp, part),
+                what=f"{label}: dy_prev = (dz W) * relu'(bn(z_prev)) + BN sums, {R} rows")
+
+
+def sa_wgrad(R, ck, cp, pooled, S, dev, label):
+    G = R // S
+    dy = _rand(G if pooled else R, ck, dev=dev)
+    arg = torch.randint(0, S, (G, ck), dtype=torch.uint8, device=dev) if pooled else None
+    zk, zp = _rand(R, ck, dev=dev), _rand(R, cp, dev=dev)
+    coef, stp = _stats(ck, dev), _stats(cp, dev)
+    pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, ck, cp, 1 if pooled else 0)), ck, cp, dtype=torch.float32, device=dev)
+
+    def run():
+        check(lib.spacap_sa_wgrad_f32(dy.data_ptr(), arg.data_ptr() if pooled else None, S if pooled else 0, zk.data_ptr(),
+                                      coef.data_ptr(), zp.data_ptr(), stp.data_ptr(), R, ck, cp, pw.data_ptr(), _st(dev)), "sa_wgrad")
+    byts = 4.0 * R * (ck + cp) + (4.0 * G * ck + G * ck if pooled else 4.0 * R * ck) + 4.0 * pw.numel()
+    return dict(name=f"sa_wgrad {ck}x{cp} R={R} {'pooled' if pooled else 'dense'} ({label})", kernel="sa_wgrad_kernel", run=run,
+                flops=2.0 * ck * cp * R, bytes=byts, keep=(dy, arg, zk, zp, coef, stp, pw),
+                what=f"{label}: dW = dz^T relu(bn(z_prev)) per row slab, {R} rows")
+
+
+def rel_tail_fwd(R, dev):
+    h1, W2, b2 = _rand(R, 128, dev=dev).relu_(), _rand(128, 128, dev=dev) * 0.1, _rand(128, dev=dev) * 0.1
+    W3, b3 = _rand(9, 128, dev=dev) * 0.1, _rand(9, dev=dev) * 0.1
+    hid2, pred = torch.empty(R, 128, dtype=torch.float32, device=dev), torch.empty(R, 9, dtype=torch.float32, device=dev)
+
+    def run():
+        check(lib.spacap_rel_tail_fwd_f32(h1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), R,
+                                          hid2.data_ptr(), pred.data_ptr(), _st(dev)), "rel_tail_fwd")
+    return dict(name=f"rel_tail_fwd R={R} (relation head layers 2+3)", kernel="sa_mid_fwd_kernel<128, 2, true>", run=run,
+                flops=2.0 * R * (128 * 128 + 128 * 9), bytes=4.0 * R * (128 + 128 + 9), keep=(h1, W2, b2, W3, b3, hid2, pred),
+                what="relation head: hid2 = relu(W2 hid1 + b2) stored, pred = W3 hid2 + b3, 524 288 pair rows")
+
+
+def mha_fwd(B, h, L, dk, dev, need_p):
+    hd = h * dk
+    qkv = _rand(B, L, 3 * hd, dev=dev)
+    mask = (torch.rand(B, 1, L, device=dev) > 0.3).to(torch.uint8)
+    mask[..., 0] = 1
+    out = torch.empty(B, L, h, dk, dtype=torch.float32, device=dev)
+    p = torch.empty(B, h, L, L, dtype=torch.float32, device=dev) if need_p else None
+    stats = torch.empty(B, h, L, 2, dtype=torch.float32, device=dev)
+    sb, sh, sl = L * 3 * hd, dk, 3 * hd
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * hd, qkv.data_ptr() + 8 * hd
+
+    def run():
+        check(lib.spacap_mha_fwd_f32(q, k, v, sb, sh, sl, sb, sh, sl, sb, sh, sl, mask.data_ptr(), L, 0, None, 0, 0, 0, B, h, L, L,
+                                     dk, 1.0 / dk ** 0.5, 0.1, 1234, None, out.data_ptr(), p.data_ptr() if need_p else None,
+                                     stats.data_ptr(), _st(dev)), "mha_fwd")
+    return dict(name=f"mha_fwd B={B} h={h} L={L} d_k={dk}{' +P' if need_p else ''}", kernel="mha_fwd", run=run,
+                flops=4.0 * B * h * L * L * dk, bytes=4.0 * B * L * 4 * hd + (4.0 * B * h * L * L if need_p else 0.0),
+                keep=(qkv, mask, out, p, stats), what="encoder self-attention layer (QK^T, mask, softmax, dropout, PV) in one launch")
+
+
+def fps(B, N, m, dev):
+    from spacap3d_amd import synthetic as S
+    xyz = S.scene_batch(B, N, use_height=False, seed=1000).to(dev)
+    ws = torch.empty(max(int(lib.spacap_fps_workspace_bytes(B, N)), 16), dtype=torch.uint8, device=dev)
+    idx = torch.empty(B, m, dtype=torch.int32, device=dev)
+
+    def run():
+        check(lib.spacap_fps_f32(xyz.data_ptr(), B, N, m, ws.data_ptr(), idx.data_ptr(), _st(dev)), "fps")
+    return dict(name=f"fps B={B} {N}->{m} (SA1 sampling)", kernel="fps_bucket_kernel", run=run, flops=10.0 * B * (m - 1) * N,
+                bytes=20.0 * B * (m - 1) * N, compulsory_bytes=float(B * (12 * N + 4 * m)), rounds=m - 1, keep=(xyz, ws, idx),
+                what="furthest point sampling, one workgroup per scene, m-1 sequentially dependent rounds")
+
+
+def cases(dev, B=8):
+    """name -> case dict, cfg2 shapes with B scenes."""
+    R1, R2, R3, R4, RA = B * 2048 * 64, B * 1024 * 32, B * 512 * 16, B * 256 * 16, B * 256 * 16
+    return [
+        lambda: sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3"),
+        lambda: sa_mid_fwd(R2, 128, 128, dev, "SA2 layer 2"),
+        lambda: sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2"),
+        lambda: sa_mid_fwd(R1, 64, 128, dev, "SA1 layer 3"),
+        lambda: sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
+        lambda: sa_dgrad(R2, 128, 128, False, 32, dev, "SA2 layer 2"),
+        lambda: sa_dgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
+        lambda: sa_wgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
+        lambda: sa_wgrad(R2, 128, 128, False, 32, dev, "SA2 layer 2"),
+        lambda: sa_wgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
+        lambda: rel_tail_fwd(B * 256 * 256, dev),
+        lambda: mha_fwd(B, 8, 256, 16, dev, True),
+        lambda: fps(B, 40000, 2048, dev),
+    ]
+
+
+def time_case(case, iters=20, warm=3):
+    """Average duration (us) of `iters` back-to-back launches between two HIP events on the launch stream."""
+    for _ in range(warm):
+        case["run"]()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        case["run"]()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def roofline_entry(case, us, pmc=None):
+    """The bench line's roofline object for one case: MFMA-bound when its arithmetic intensity exceeds the machine
+    balance (157.3 TF/s / 8 TB/s = 19.7 flop/B), else HBM-bound; FPS is a latency chain (on-chip resident)."""
+    if "rounds" in case:
+        ent = dict(bound="latency", kernel=case["name"], achieved=us / case["rounds"], peak=None, unit="us/round", frac=None,
+                   streamed_model_GBs=case["bytes"] / us * 1e-3, streamed_model_frac_of_hbm=case["bytes"] / us * 1e-3 / PEAK_HBM_GBS)
+    elif case["flops"] / case["bytes"] > PEAK_MFMA_F32_TFLOPS * 1e3 / PEAK_HBM_GBS:
+        a = case["flops"] / us * 1e-6
+        ent = dict(bound="mfma", kernel=case["name"], achieved=a, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s", frac=a / PEAK_MFMA_F32_TFLOPS)
+    else:
+        a = case["bytes"] / us * 1e-3
+        ent = dict(bound="hbm", kernel=case["name"], achieved=a, peak=PEAK_HBM_GBS, unit="GB/s", frac=a / PEAK_HBM_GBS)
+    ent.update(launch_us=us, algorithmic_flops=case["flops"], algorithmic_bytes=case["bytes"], what=case["what"])
+    rec = (pmc or {}).get(case["name"])
+    ent["traffic"] = rec.get("hbm_bytes") if rec else None
+    if rec:
+        for k in ("fetch_bytes_corrected", "write_bytes", "mfma_busy_frac", "mfma_flops_counted", "profiled_us", "source"):
+            if k in rec:
+                ent[k] = rec[k]
+    return ent
