@@ -14,11 +14,12 @@ from .loss_helper import get_scene_cap_loss, start_detection_losses
 
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = False):
+                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = False,
+                 adam_eps: float = 1e-8):
         self.model = model
         self.mean_size_arr = mean_size_arr
         self.use_relation = use_relation
-        self.lr, self.weight_decay = lr, weight_decay
+        self.lr, self.weight_decay, self.adam_eps = lr, weight_decay, adam_eps
         self.bucket = None
         self.optimizer = None
         self.side_stream = None
@@ -99,7 +100,7 @@ class Trainer:
         # bucket only when there is something to all-reduce
         used = self._group_qkv(used)
         self.bucket = FlatGradBucket(used, views=False)
-        kw = dict(lr=self.lr, weight_decay=self.weight_decay)
+        kw = dict(lr=self.lr, weight_decay=self.weight_decay, eps=self.adam_eps)
         if used[0].is_cuda:
             from .optim import FlatAdam   # one launch over a flat parameter buffer (spacap3d_amd/optim.py)
             self.optimizer = FlatAdam(self.bucket, **kw)

@@ -84,46 +84,81 @@ def test_cfg5_attention_h32_L512():
     assert float(d.abs().max()) < 1e-3
 
 
-@pytest.mark.parametrize("C", [7, 132])
-def test_cfg3_cfg4_sa1_full_size_first_layer(C):
-    """SA1 at the cfg3 / cfg4 size (40 000 points, C extra channels, 2 048 x 64 groups) through the fused op vs a float64
-    restatement of group -> [rel/r ; feats] -> conv1x1 -> BN(train) -> ReLU -> ... -> max (2 scenes: the float64
-    grouped tensor of 8 scenes would not fit the test's memory budget)."""
+def _fused_node(t):
+    """The autograd node of the fused shared-MLP op behind a module output (its saved tensors hold the kernel's own
+    pre-activations z1..z3, statistics and arg-max map)."""
+    node, seen = t.grad_fn, 0
+    while node is not None and "_SAMLP" not in type(node).__name__:
+        node, seen = node.next_functions[0][0], seen + 1
+        assert seen < 8
+    return node
+
+
+def _sa1_vs_float64(C, seed):
+    """SA1 at the cfg3 / cfg4 size (40 000 points, C extra channels, 2 048 x 64 groups, 2 scenes) through the fused op vs
+    float64 restatements of group -> [rel/r ; feats] -> conv1x1 -> BN(train) -> ReLU -> ... -> max:
+      free    the restatement makes its own ReLU / max-pool selections;
+      frozen  the restatement uses the selections the kernels made (ReLU masks recomputed from the kernel's stored
+              pre-activations exactly as its backward does, arg-max map as stored): a smooth function of the weights,
+              so the comparison is well conditioned.
+    Returns (forward error, [free l2 errors of dW1..3], [frozen l2 errors of dW1..3])."""
+    from spacap3d_amd import pointnet2_utils as pu
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
-    torch.manual_seed(C)
-    pc = S.scene_batch(2, 40000, use_color=(C == 7), use_normal=True, use_multiview=(C == 132), seed=C).to(DEV)
+    torch.manual_seed(seed)
+    pc = S.scene_batch(2, 40000, use_color=(C == 7), use_normal=True, use_multiview=(C == 132), seed=seed).to(DEV)
     assert pc.shape[-1] == 3 + C
     xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
     sa = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[C, 64, 64, 128], use_xyz=True,
                                normalize_xyz=True).to(DEV).train()
     new_xyz, out, inds = sa(xyz, feats)
     assert getattr(out, "_point_major", None) is not None, "the fused shared-MLP path did not run"
+    node = _fused_node(out)
+    saved = node.saved_tensors
+    zs, sts, arg = saved[7:10], saved[10:13], saved[14]
     wsum = torch.randn(out.shape, device=DEV)
     (out * wsum).sum().backward()
-    # float64 restatement
+    got = [l.conv.weight.grad.view(l.conv.out_channels, -1).double() for l in sa.mlp_module.children()]
     with torch.no_grad():
-        from spacap3d_amd import pointnet2_utils as pu
         idx = pu.ball_query(0.2, 64, xyz, new_xyz).long()                        # (B, P, S)
         B, P, Sn = idx.shape
         flat = idx.view(B, -1)
+        # the kernels' selections: relu'(bn(z_k)) with the fp32 expression of the kernels, arg-max of the pooled layer
+        masks = [(((z - st[:, 0]) * st[:, 2] + st[:, 3]) > 0).view(B, P, Sn, -1) for z, st in zip(zs, sts)]
+        argl = arg.view(B, P, 1, -1).long()
     x64, f64 = xyz.double(), feats.double()
     g_xyz = torch.gather(x64, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, P, Sn, 3)
     rel = (g_xyz - new_xyz.double().unsqueeze(2)) / 0.2
     g_f = torch.gather(f64, 2, flat.unsqueeze(1).expand(-1, C, -1)).view(B, C, P, Sn).permute(0, 2, 3, 1)
-    h = torch.cat([rel, g_f], -1)                                                 # (B, P, S, 3 + C)
-    ws = [l.conv.weight.detach().double().view(l.conv.out_channels, -1).requires_grad_(True) for l in sa.mlp_module.children()]
-    for w, l in zip(ws, sa.mlp_module.children()):
-        z = h @ w.t()
-        mu, var = z.mean((0, 1, 2)), z.var((0, 1, 2), unbiased=False)
-        h = torch.relu((z - mu) / torch.sqrt(var + l.bn.bn.eps) * l.bn.bn.weight.double() + l.bn.bn.bias.double())
-    ref = h.max(2).values.permute(0, 2, 1)                                        # (B, 128, P)
-    (ref * wsum.double()).sum().backward()
-    err = float((out.double() - ref).abs().max() / ref.abs().max())
-    assert err < 2e-5, err
-    for w, l in zip(ws, sa.mlp_module.children()):
-        g = l.conv.weight.grad.view_as(w).double()
-        e = float((g - w.grad).norm() / w.grad.norm())
-        assert e < 2e-4, (tuple(w.shape), e)
+    h0 = torch.cat([rel, g_f], -1)                                                # (B, P, S, 3 + C)
+    out_errs, grads = [], []
+    for frozen in (False, True):
+        ws = [l.conv.weight.detach().double().view(l.conv.out_channels, -1).requires_grad_(True) for l in sa.mlp_module.children()]
+        h = h0
+        for k, (w, l) in enumerate(zip(ws, sa.mlp_module.children())):
+            z = h @ w.t()
+            mu, var = z.mean((0, 1, 2)), z.var((0, 1, 2), unbiased=False)
+            y = (z - mu) / torch.sqrt(var + l.bn.bn.eps) * l.bn.bn.weight.double() + l.bn.bn.bias.double()
+            h = y * masks[k].double() if frozen else torch.relu(y)
+        ref = (torch.gather(h, 2, argl).squeeze(2) if frozen else h.max(2).values).permute(0, 2, 1)   # (B, 128, P)
+        (ref * wsum.double()).sum().backward()
+        out_errs.append(float((out.double() - ref).abs().max() / ref.abs().max()))
+        grads.append([float((g - w.grad).norm() / w.grad.norm()) for g, w in zip(got, ws)])
+        del ws, h, ref
+    return max(out_errs), grads[0], grads[1]
+
+
+@pytest.mark.parametrize("C", [7, 132])
+def test_cfg3_cfg4_sa1_full_size_first_layer(C):
+    """Three seeds.  The forward agrees with float64 to 2e-5 of scale.  With the kernels' own ReLU / max-pool selections
+    frozen into the float64 restatement the weight gradients must agree tightly (the well-conditioned comparison).
+    With free selections a candidate pair within fp32 noise of a tie may resolve differently than in float64: one
+    flipped arg-max re-routes one of 4 096 summands of a gradient row (~1e-3 of the matrix), and the per-operator torch
+    path shows the same spread (tools/lab/sa1_c132_err.py) -- those errors are only bounded at the flip level."""
+    res = [_sa1_vs_float64(C, seed) for seed in (C, C + 1000, C + 2000)]
+    assert max(r[0] for r in res) < 2e-5, res
+    for layer in range(3):
+        assert max(r[2][layer] for r in res) < 5e-5, ("frozen selections", layer, [r[2] for r in res])
+        assert max(r[1][layer] for r in res) < 2e-2, ("free selections", layer, [r[1] for r in res])
 
 
 def _cfg5_model(device, layers=2):

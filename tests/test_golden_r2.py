@@ -68,11 +68,15 @@ SA_CASES = {   # as in make_fixtures_r2.py
     "sa3": (1024, 128, 0.8, 16, [256, 128, 128, 256], True),
     "agg": (1024, 64, 0.3, 16, [256, 128, 128, 128], True),
 }
-# (output, gradients): linf / l2 bounds per leg.  CPU leg = same torch CPU kernels as the generator.  GPU leg: fp32
-# GEMMs with another summation order under train-mode BatchNorm; gradients additionally see max-pool / ReLU selections.
-# The gradient w.r.t. the input features is a scatter of single rows: one max-pool / ReLU selection that flips on
-# 1e-6 of forward noise moves one element by ~1 % of the tensor's max (measured on MI355X: linf 1.1e-2, l2 7.6e-4).
-SA_TOL = {"cpu": ((2e-5, 2e-6), (2e-4, 2e-5), (2e-4, 2e-5)), "cuda:0": ((2e-4, 2e-5), (2e-3, 3e-4), (2e-2, 1.5e-3))}
+# (output, parameter gradients, input-feature gradient): linf / l2 bounds per leg.  CPU leg = same torch CPU kernels as
+# the generator.  GPU leg, outputs: fp32 GEMMs with another summation order under train-mode BatchNorm.  GPU leg,
+# gradients: a max-pool arg-max (or ReLU sign) whose two candidates are within fp32 noise selects differently than in
+# the generator's run; ONE such flip among the ~G*C selections re-routes one of the ~G summands of a weight-gradient
+# row (1/64 of that row at G = 4096, ~1e-3 of the matrix) -- measured on MI355X with tools/lab/sa1_c132_err.py: cases
+# without a flip agree to 1e-6 (l2), cases with flips to 3e-5 .. 4e-3, for the fused kernels and for the per-operator
+# torch path alike.  The bounds admit a few flips; tests/test_sa_mlp_gpu.py and tests/test_configs_gpu.py hold the
+# flip-free float64 comparisons.
+SA_TOL = {"cpu": ((2e-5, 2e-6), (2e-4, 2e-5), (2e-4, 2e-5)), "cuda:0": ((2e-4, 2e-5), (2e-2, 3e-3), (2e-2, 3e-3))}
 
 
 @pytest.mark.parametrize("name", list(SA_CASES))

@@ -183,7 +183,7 @@ def roofline_entry(case, us, pmc=None):
     rec = (pmc or {}).get(case["name"])
     ent["traffic"] = rec.get("hbm_bytes") if rec else None
     if rec:
-        for k in ("fetch_bytes_corrected", "write_bytes", "mfma_busy_frac", "mfma_flops_counted", "profiled_us", "source"):
+        for k in ("fetch_bytes_corrected", "write_bytes", "mfma_util", "clock_GHz", "mfma_flops_counted", "profiled_us", "source"):
             if k in rec:
                 ent[k] = rec[k]
     return ent

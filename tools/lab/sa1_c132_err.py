@@ -11,6 +11,14 @@ C = int(sys.argv[1]) if len(sys.argv) > 1 else 132
 torch.manual_seed(C)
 pc = S.scene_batch(2, 40000, use_color=(C == 7), use_normal=True, use_multiview=(C == 132), seed=C).to(DEV)
 xyz, feats = pc[..., :3].contiguous(), pc[..., 3:].transpose(1, 2).contiguous()
+MODE = sys.argv[2] if len(sys.argv) > 2 else "plain"
+if MODE == "center":
+    feats = (feats - feats.mean(dim=2, keepdim=True)).contiguous()
+elif MODE == "offset":
+    feats = (feats + 10.0).contiguous()
+elif MODE == "randn":
+    feats = torch.randn_like(feats)
+print("mode", MODE, "C", C)
 sa = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[C, 64, 64, 128], use_xyz=True, normalize_xyz=True).to(DEV).train()
 new_xyz, out, inds = sa(xyz, feats)
 wsum = torch.randn(out.shape, device=DEV)
@@ -43,6 +51,8 @@ for w, l in zip(ws, sa.mlp_module.children()):
     h = torch.relu((z - mu) / torch.sqrt(var + l.bn.bn.eps) * l.bn.bn.weight.double() + l.bn.bn.bias.double())
 ref = h.max(2).values.permute(0, 2, 1)
 (ref * wsum.double()).sum().backward()
+for i, l in enumerate(sa.mlp_module.children()):
+    pass
 print("out fused vs f64", float((out.double() - ref).abs().max() / ref.abs().max()), " unfused", float((out2.double() - ref).abs().max() / ref.abs().max()))
 for i, w in enumerate(ws):
     r = w.grad
@@ -53,3 +63,10 @@ for i, w in enumerate(ws):
             msg += f"  xyz cols {float(e[:, :3].norm() / r[:, :3].norm()):.2e}  feat cols {float(e[:, 3:].norm() / r[:, 3:].norm()):.2e}"
             msg += f"  |r xyz| {float(r[:, :3].norm()):.3e} |r feat| {float(r[:, 3:].norm()):.3e}"
         print(msg)
+# statistics of the pre-activations (float64 restatement): |mean| / std per layer
+hh = torch.cat([rel, g_f], -1)
+for i, (w, l) in enumerate(zip(ws, sa.mlp_module.children())):
+    z = hh @ w.detach().t()
+    mu, sd = z.mean((0, 1, 2)), z.std((0, 1, 2))
+    print(f"layer {i}: |mean|/std max {float((mu.abs() / sd).max()):.2f} median {float((mu.abs() / sd).median()):.2f}  std min {float(sd.min()):.3e} max {float(sd.max()):.3e}")
+    hh = torch.relu((z - mu) / torch.sqrt(z.var((0, 1, 2), unbiased=False) + l.bn.bn.eps) * l.bn.bn.weight.double() + l.bn.bn.bias.double())

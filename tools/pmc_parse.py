@@ -7,8 +7,12 @@ Per case (tools/kernel_cases.py), the LAST launch of the case's kernel sequence 
   fetch_bytes_corrected = 2 * FETCH_SIZE * 1024   (gfx950: FETCH_SIZE tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM)
   write_bytes           = WRITE_SIZE * 1024
   hbm_bytes             = the sum of the two = `traffic` of the bench line
-  mfma_busy_frac        = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs * SQ_BUSY_CU_CYCLES)    (share of SIMD cycles with an MFMA in flight)
-  mfma_flops_counted    = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512
+  mfma_util             = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs): share of the chip's SIMD cycles
+                          with an MFMA executing (BUSY_CYCLES counts per-SIMD cycles: exactly flops / 64 for
+                          v_mfma_f32_16x16x4_f32; GRBM_GUI_ACTIVE is summed over the 8 XCDs) -- equals achieved / peak
+                          TFLOP/s at the clock the kernel actually ran at (GRBM_GUI_ACTIVE / 8 / duration, ~2.26 GHz
+                          under these kernels vs the 2.4 GHz of the 157.3 TFLOP/s spec figure)
+  mfma_flops_counted    = SQ_INSTS_VALU_MFMA_MOPS_F32 * 512   (matches the algorithmic flops of every GEMM case)
 """
 import collections
 import csv
@@ -89,8 +93,10 @@ def main():
             for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE"):
                 if k in c:
                     rec[k] = c[k]
-            if c.get("SQ_BUSY_CU_CYCLES"):
-                rec["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+            if c.get("GRBM_GUI_ACTIVE"):
+                rec["mfma_util"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+                if rec.get("profiled_us"):
+                    rec["clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / rec["profiled_us"] * 1e-3
             if "SQ_INSTS_VALU_MFMA_MOPS_F32" in c:
                 rec["mfma_flops_counted"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
         rec["source"] = os.path.basename(dst)
@@ -100,7 +106,7 @@ def main():
     for k, v in result.items():
         if isinstance(v, dict):
             print(f"{k:60s} us {v.get('profiled_us', 0):8.1f}  hbm {v.get('hbm_bytes', 0) / 1e6:8.1f} MB  alg {v['algorithmic_bytes'] / 1e6:8.1f} MB  "
-                  f"mfma_busy {v.get('mfma_busy_frac', 0):.3f}")
+                  f"mfma_util {v.get('mfma_util', 0):.3f}")
 
 
 if __name__ == "__main__":
