@@ -170,12 +170,22 @@ def test_five_step_trajectory_matches_the_oracle_backend():
 
     cpu = run("cpu", OracleBackend())
     gpu = run(DEV, backend.HipBackend())
+    # Step 0 (same weights): every term within 1e-3.  Later steps: the two runs' forward values differ by ~2e-5 (fp32
+    # through ~15 BatchNorm'd layers), so a ReLU whose input lies within that of zero resolves differently; at this size
+    # the proposal head sees only 2 x 64 positions, and ONE such flip was measured to change the gradient entering the
+    # backbone by 2.4 % (tools/lab/head_bisect.py: a single element of 16 384, every other channel agrees to 5e-5).  The
+    # terms far from the flip (vote / caption / relation / objectness) are held to 5e-3, box / class / total to 3e-2.
+    for k in cpu[0]:
+        assert abs(cpu[0][k] - gpu[0][k]) <= 1e-3 * max(abs(cpu[0][k]), 1e-2), (0, k, cpu[0], gpu[0])
+    tight = ("vote_loss", "cap_loss", "relation_loss", "objectness_loss")
     for i, (a, b) in enumerate(zip(cpu, gpu)):
         for k in a:
-            assert abs(a[k] - b[k]) <= 1e-3 * max(abs(a[k]), 1e-2), (i, k, a, b)
-    # the smooth terms go down on both (the box / class terms are means over a changing set of positive proposals)
+            tol = 5e-3 if k in tight else 3e-2
+            assert abs(a[k] - b[k]) <= tol * max(abs(a[k]), 1e-2), (i, k, a, b)
+    # everything goes down on both (anchored boxes, pinned proposals: a stable set of positives)
     for run_ in (cpu, gpu):
-        assert run_[-1]["vote_loss"] < run_[0]["vote_loss"] and run_[-1]["cap_loss"] < run_[0]["cap_loss"], run_
+        assert run_[-1]["loss"] < run_[0]["loss"] and run_[-1]["cap_loss"] < run_[0]["cap_loss"] \
+            and run_[-1]["vote_loss"] < run_[0]["vote_loss"], run_
 
 
 def test_twenty_steps_reduce_the_loss():
