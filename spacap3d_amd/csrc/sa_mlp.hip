@@ -170,11 +170,20 @@ struct TailArgs {
   float *pred;         // [R][NO3]
   int NO3;             // <= 16
 };
-template <int CIN, int NT, bool TAIL = false>
+// LAB != 0: timing experiments only (tools/lab/mid_variants.py; results are wrong on purpose):
+//   1 = no MFMA (loads, staging, epilogue, stores only)   2 = no global stores   3 = no global loads after the first tile
+//   4 = MFMA B operand from registers (INVALID: the compiler merges the then identical accumulators)
+//   5 = MFMA loop + LDS operand reads only (no global traffic, no staging, no barriers, no epilogue)
+template <int CIN, int NT, bool TAIL = false, int LAB = 0>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
                                                          float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
-  constexpr int LD = CIN + 4, KS = CIN / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  // LD = CIN + 8 (== 8 mod 64 words) together with the K order below makes every ds_read_b128 of the B operand
+  // conflict-free: MFMA step s of lane group lg (= lane / 16) uses channel kperm(s, lg); the four steps 4q..4q+3 of
+  // a lane are 4 consecutive words, lg 0/1 (and 2/3) interleave in 4-word chunks, lg 0,1 own the first half of the
+  // row and lg 2,3 the second (ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
+  // each holds all 16 rows with lg in {0,1} or {2,3}, and 8*row + 4*(lg&1) tiles the 64 banks exactly once).
+  constexpr int LD = CIN + 8, KS = CIN / 4, KQ = KS / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
   constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *s_a = smem;             // [TM][LD]   activations (MFMA B operand)
@@ -185,7 +194,11 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wf[j][ks] = W[(size_t)(cb + 16 * j + l15) * CIN + ks * 4 + lg];
+    for (int q = 0; q < KQ; ++q) {   // steps 4q .. 4q+3 of a lane are 4 consecutive channels: one 16-byte load
+      const f32x4 w4 = ld4(W + (size_t)(cb + 16 * j + l15) * CIN + (lg >> 1) * (CIN / 2) + q * 8 + (lg & 1) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wf[j][q * 4 + u] = w4[u];
+    }
   const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
   f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sc = mean, be = mean;
   if (!TAIL) {
@@ -231,31 +244,61 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
   auto tile = [&](long t, auto full, bool stores_pending) {
     constexpr bool FULL = decltype(full)::value;
     const long row0 = t * TM;
-    wait_prefetch(stores_pending);
+    if (LAB != 5) {
+      wait_prefetch(stores_pending);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int row = r0 + i * RSTEP;
-      f32x4 a;
+      for (int i = 0; i < NV; ++i) {
+        const int row = r0 + i * RSTEP;
+        f32x4 a;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
-      if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
-      st4(&s_a[row * LD + c4 * 4], a);
+        for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
+        st4(&s_a[row * LD + c4 * 4], a);
+      }
+      __syncthreads();
+      if (FULL && LAB != 3) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
     }
-    __syncthreads();
-    if (FULL) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
     f32x4 acc[TM / 16][NT];
 #pragma unroll
     for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (LAB != 1) {
+      // B operand by ds_read_b128, software-pipelined in chunks of (16 rows x half of K): two register buffers; the
+      // reads of chunk c + 2 are issued right after the MFMAs of chunk c, i.e. one chunk of MFMA time (16 * NT
+      // instructions) before their first use.  sched_barriers pin that order (the scheduler otherwise sinks every
+      // read to just before its use, exposing the LDS latency once per chunk).
+      constexpr int KH = KQ / 2 > 0 ? KQ / 2 : 1, NCH = (TM / 16) * (KQ / KH);
+      const float *bsrc = s_a + l15 * LD + (lg >> 1) * (CIN / 2) + (lg & 1) * 4;
+      f32x4 bq[2][KH];
+      auto bload = [&](int c) {
+        const int mt = c / (KQ / KH), h = c % (KQ / KH);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+        for (int q = 0; q < KH; ++q) bq[c & 1][q] = LAB == 4 ? f32x4{mean[0], sc[1], be[2], mean[3]} : ld4(bsrc + mt * 16 * LD + (h * KH + q) * 8);
+      };
+      bload(0);
+      if (NCH > 1) bload(1);
 #pragma unroll
-      for (int mt = 0; mt < TM / 16; ++mt) {
-        const float b = s_a[(mt * 16 + l15) * LD + ks * 4 + lg];
+      for (int c = 0; c < NCH; ++c) {
+        const int mt = c / (KQ / KH), h = c % (KQ / KH);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
+        for (int q = 0; q < KH; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[mt][j] = MFMA16(wf[j][(h * KH + q) * 4 + u], bq[c & 1][q][u], acc[mt][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) bload(c + 2);
       }
+    }
+    if (LAB == 5) {   // MFMA + LDS operand reads only: keep the accumulators alive, skip the epilogue
+#pragma unroll
+      for (int mt = 0; mt < TM / 16; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ssum[j] += acc[mt][j];
+      return;
     }
 #pragma unroll
     for (int mt = 0; mt < TM / 16; ++mt)
@@ -278,7 +321,9 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
       const int row = or0 + i * OSTEP;
-      if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
+      if (LAB == 2) {
+        if (row0 + row == R + 12345) st4(zout, ld4(&s_o[row * LDO + o4 * 4]));   // never true: keeps the LDS reads alive
+      } else if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
     }
     if (TAIL) {   // wave w: rows 16 w .. 16 w + 15 of the tile times the padded output weights
       f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
@@ -323,6 +368,230 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
           part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
       }
     }
+}
+
+// ---- the same layer on v_mfma_f32_32x32x2_f32 ------------------------------------------------------------------
+// Measured on MI355X (tools/lab/mfma_rate2.hip): from registers the 32x32x2 fp32 MFMA sustains 140 - 147 TFLOP/s with
+// any number of accumulators and waves per SIMD, the 16x16x4 form 94 - 144 depending on the accumulator rotation
+// (113 - 124 with the 8 accumulators the kernel above cycles through).  Same tile pipeline as sa_mid_fwd_kernel; only
+// the operand mapping differs:
+//   A = weights: lane (c = lane % 32, kk = lane / 32) holds W[cb + c][kperm(s, kk)] for step s (CIN / 2 registers);
+//   B = activations from LDS: lane (r = lane % 32, kk) reads row rb * 32 + r, words kk * CIN / 2 + 4 q .. + 3 with one
+//       ds_read_b128 per 4 steps -- kperm(s, kk) = kk * CIN / 2 + s; with LD = CIN + 4 (== 4 mod 64 words) the 16 rows of
+//       every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) tile the 64 banks exactly once;
+//   D: lane (r, kk), register v = channel cb + 8 (v / 4) + 4 kk + v % 4 of row r: four 16-byte chunks per row block.
+// A workgroup covers COB = 64 NT output channels in NCB = 2 NT blocks of 32; with NT = 1 two waves share a channel
+// block and split the tile's two 32-row blocks.  B reads are software-pipelined in chunks of 16 steps (two register
+// buffers, reads of chunk c + 2 issued right after the MFMAs of chunk c; sched_barriers pin the order).
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+using f32x16 = float __attribute__((ext_vector_type(16)));
+template <int CIN, int NT, bool TAIL = false, int LAB = 0>
+__global__ __launch_bounds__(256) void sa_mid_fwd32_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
+                                                           const float *__restrict__ W, int Cout, long R,
+                                                           float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
+  constexpr int LD = CIN + 4, KS2 = CIN / 2, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
+  constexpr int NCB = COB / 32, WPC = 4 / NCB, RB = (TM / 32) / WPC;   // channel blocks, waves per block, row blocks per wave
+  constexpr int CHS = 16, NCHB = KS2 / CHS, NCH = RB * NCHB;            // steps per chunk, chunks per row block, per tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_a = smem;             // [TM][LD]   activations (MFMA B operand)
+  float *s_o = smem + TM * LD;   // [TM][LDO]  output tile, row-major
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int l15 = lane & 15, lg = lane >> 4;   // (TAIL: the 9-column product keeps the 16x16x4 form)
+  const int cw = w % NCB, rw = w / NCB;         // this wave's channel block and (NT = 1) row half
+  const int cbb = blockIdx.y * COB, wc = cw * 32, cb = cbb + wc;
+  float wf[KS2];
+#pragma unroll
+  for (int q = 0; q < KS2 / 4; ++q) {
+    const f32x4 w4 = ld4(W + (size_t)(cb + l31) * CIN + kk * KS2 + q * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wf[q * 4 + u] = w4[u];
+  }
+  const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sc = mean, be = mean;
+  if (!TAIL) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+      mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+    }
+  }
+  float wf3[TAIL ? COB / 4 : 1];
+  f32x4 bv[4];
+  if (TAIL) {
+#pragma unroll
+    for (int ks = 0; ks < COB / 4; ++ks) wf3[TAIL ? ks : 0] = l15 < ta.NO3 ? ta.W3[(size_t)l15 * Cout + ks * 4 + lg] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = ld4(ta.bias + cb + 8 * b + 4 * kk);
+  }
+  f32x4 ssum[4], ssq[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ssum[b] = ssq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TM - 1) / TM;
+  f32x4 pre[NV];
+  auto fetch = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
+    }
+  };
+  auto wait_prefetch = [&](bool stores_pending) {
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));  // uses of pre[] stay below the wait
+  };
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
+    const long row0 = t * TM;
+    if (LAB != 5) {
+      wait_prefetch(stores_pending);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int row = r0 + i * RSTEP;
+        f32x4 a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
+        st4(&s_a[row * LD + c4 * 4], a);
+      }
+      __syncthreads();
+      if (FULL && LAB != 3) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
+    }
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[rb][v] = 0.f;
+    if (LAB != 1) {
+      const float *bsrc = s_a + (rw * RB * 32 + l31) * LD + kk * KS2;
+      f32x4 bq[2][CHS / 4];
+      auto bload = [&](int c) {
+        const int rb = c / NCHB, h = c % NCHB;
+#pragma unroll
+        for (int q = 0; q < CHS / 4; ++q) bq[c & 1][q] = LAB == 4 ? f32x4{mean[0], sc[1], be[2], mean[3]} : ld4(bsrc + rb * 32 * LD + h * CHS + q * 4);
+      };
+      bload(0);
+      if (NCH > 1) bload(1);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int rb = c / NCHB, h = c % NCHB;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CHS / 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[rb] = MFMA32(wf[h * CHS + q * 4 + u], bq[c & 1][q][u], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) bload(c + 2);
+      }
+    }
+    if (LAB == 5) {   // MFMA + LDS operand reads only: keep the accumulators alive, skip the epilogue
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ssum[b] += f32x4{acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+      return;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int trow = (rw * RB + rb) * 32 + l31;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 v = {acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+        if (TAIL) {
+          v += bv[b];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        } else if (FULL || row0 + trow < R) {
+          ssum[b] += v;
+          ssq[b] += v * v;
+        }
+        st4(&s_o[trow * LDO + wc + 8 * b + 4 * kk], v);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int row = or0 + i * OSTEP;
+      if (LAB == 2) {
+        if (row0 + row == R + 12345) st4(zout, ld4(&s_o[row * LDO + o4 * 4]));   // never true: keeps the LDS reads alive
+      } else if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
+    }
+    if (TAIL) {   // wave w: rows 16 w .. 16 w + 15 of the tile times the padded output weights
+      f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < COB / 4; ++ks) a3 = MFMA16(wf3[TAIL ? ks : 0], s_o[(w * 16 + l15) * LDO + ks * 4 + lg], a3);
+      const long row = row0 + w * 16 + l15;
+      if (FULL || row < R) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * lg + u < ta.NO3) ta.pred[(size_t)row * ta.NO3 + 4 * lg + u] = a3[u] + ta.b3[4 * lg + u];
+      }
+    }
+  };
+  const long nfull = R / TM;
+  bool pending = false;
+  if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(pre[i]));
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    fetch(nfull);
+    tile(nfull, std::false_type{}, false);
+  }
+  if (TAIL) return;
+  // per-lane sums -> per-wave sums over the 32 rows a lane group holds (lanes with l31 == 0 keep them)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = ssum[b][u], q = ssq[b][u];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      ssum[b][u] = a, ssq[b][u] = q;
+    }
+  if (WPC > 1) {   // two waves share a channel block: add the second wave's sums through LDS
+    __syncthreads();
+    float *s_red = smem;   // [NCB][2][32]
+    if (rw == 1 && l31 == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s_red[(cw * 2 + 0) * 32 + 8 * b + 4 * kk + u] = ssum[b][u];
+          s_red[(cw * 2 + 1) * 32 + 8 * b + 4 * kk + u] = ssq[b][u];
+        }
+    }
+    __syncthreads();
+    if (rw == 0 && l31 == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ssum[b][u] += s_red[(cw * 2 + 0) * 32 + 8 * b + 4 * kk + u];
+          ssq[b][u] += s_red[(cw * 2 + 1) * 32 + 8 * b + 4 * kk + u];
+        }
+    }
+  }
+  if (rw == 0 && l31 == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = cb + 8 * b + 4 * kk + u;
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)ssum[b][u];
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)ssq[b][u];
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
+      }
+  }
 }
 
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
@@ -436,6 +705,7 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
                                                        const float *__restrict__ st_p, long R, float *__restrict__ dyp,
                                                        double *__restrict__ part, const L1Args L = L1Args{}) {
+  constexpr int LAB = 0;  // (the MFMA loop below is shared text with sa_mid_fwd_kernel, which has timing variants)
   constexpr int LD = CK + 4, KS = CK / 4, C4 = CK / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
   constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
   constexpr bool DENSE_PF = PREFETCH && !POOLED;
@@ -537,13 +807,15 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (LAB != 1) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int mt = 0; mt < TM / 16; ++mt) {
-        const float b = s_a[(mt * 16 + l15) * LD + ks * 4 + lg];
+        for (int mt = 0; mt < TM / 16; ++mt) {
+          const float b = s_a[(mt * 16 + l15) * LD + ks * 4 + lg];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
+          for (int j = 0; j < NT; ++j) acc[mt][j] = MFMA16(wf[j][ks], b, acc[mt][j]);
+        }
       }
     }
     if (ALIAS) __syncthreads();  // every wave is done reading dz before the output tile overwrites it
@@ -977,13 +1249,26 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   SPACAP_REQUIRE(zin && st_in && W && zout && part && R >= 1, "%s: bad arguments", what);
   hipStream_t s = spacap::as_stream(stream);
   const int nt = (Cin == 64 && Cout == 64) ? 1 : 2;
-  const size_t lds = (size_t)TM * ((Cin + 4) + (64 * nt + 4)) * sizeof(float);
+  static const int lab = getenv("SPACAP_SA_LAB") ? atoi(getenv("SPACAP_SA_LAB")) : 0;   // timing experiments (tools/lab)
+  static const bool m16 = getenv("SPACAP_SA_MFMA32") == nullptr;   // default: 16x16x4 form; SPACAP_SA_MFMA32=1: the 32x32x2 variant
+  const size_t lds = (size_t)TM * ((Cin + (m16 ? 8 : 4)) + (64 * nt + 4)) * sizeof(float);
   const long tiles = (R + TM - 1) / TM;
+#define MFL(CI, NTV, GY, LABV)                                                                                       \
+  {                                                                                                                  \
+    if (m16) {                                                                                                       \
+      static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV>, lds);                          \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256),  \
+                         lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                                    \
+    } else {                                                                                                         \
+      static const int res = resident_blocks(sa_mid_fwd32_kernel<CI, NTV, false, LABV>, lds);                        \
+      hipLaunchKernelGGL((sa_mid_fwd32_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY),           \
+                         dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                         \
+    }                                                                                                                \
+  }
 #define MF(CI, NTV, GY)                                                                                              \
   {                                                                                                                  \
-    static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV>, lds);                                         \
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256), lds, s, zin,    \
-                       st_in, W, Cout, R, zout, part, TailArgs{});                                                   \
+    if (lab == 1) MFL(CI, NTV, GY, 1) else if (lab == 2) MFL(CI, NTV, GY, 2) else if (lab == 3) MFL(CI, NTV, GY, 3)  \
+    else if (lab == 4) MFL(CI, NTV, GY, 4) else if (lab == 5) MFL(CI, NTV, GY, 5) else MFL(CI, NTV, GY, 0)           \
   }
   if (Cin == 64 && Cout == 64) MF(64, 1, 1)
   else if (Cin == 64 && Cout % 128 == 0) MF(64, 2, Cout / 128)
@@ -991,6 +1276,7 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   else
     SPACAP_REQUIRE(false, "%s: (Cin=%d, Cout=%d) unsupported", what, Cin, Cout);
 #undef MF
+#undef MFL
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -1677,11 +1963,20 @@ extern "C" int spacap_rel_tail_fwd_f32(const float *hid1, const float *W2, const
                                        long R, float *hid2, float *pred, spacap_stream_t stream) {
   const char *what = "spacap_rel_tail_fwd_f32";
   SPACAP_REQUIRE(hid1 && W2 && b2 && W3 && b3 && hid2 && pred && R >= 1, "%s: bad arguments", what);
-  const size_t lds = (size_t)TM * ((128 + 4) + (128 + 4)) * sizeof(float);
+  static const bool m16 = getenv("SPACAP_SA_MFMA32") == nullptr;   // default: 16x16x4 form; SPACAP_SA_MFMA32=1: the 32x32x2 variant
+  const size_t lds = (size_t)TM * ((128 + (m16 ? 8 : 4)) + (128 + 4)) * sizeof(float);
   const long tiles = (R + TM - 1) / TM;
-  static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
-  hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds, spacap::as_stream(stream),
-                     hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr, TailArgs{b2, W3, b3, pred, RT_NO});
+  if (m16) {
+    static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds,
+                       spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
+                       TailArgs{b2, W3, b3, pred, RT_NO});
+  } else {
+    static const int res = resident_blocks(sa_mid_fwd32_kernel<128, 2, true>, lds);
+    hipLaunchKernelGGL((sa_mid_fwd32_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds,
+                       spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
+                       TailArgs{b2, W3, b3, pred, RT_NO});
+  }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
