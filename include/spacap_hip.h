@@ -365,6 +365,16 @@ int spacap_scene_sample_augment_f32(const float *const *scene_feat, const int32_
                                     const int32_t *choices, const double *aug, int B, int P, int C, int augment,
                                     float *pc, int32_t *ins_out, uint8_t *isobj_out, float *color_out,
                                     spacap_stream_t stream);
+/* Same with output rows of C_out >= C channels: source channel c >= 3 is written to channel dst_off[c] (device array of C
+ * ints, NULL = identity).  The columns in between -- colour (lib/dataset.py:312-315) and multiview (:321-328) -- are filled
+ * by spacap_scene_gather_rows_f32: out[b,p,out_off+j] = src[b][choices[b,p]*W + j], j < W, out rows of out_stride floats. */
+int spacap_scene_sample_augment_map_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
+                                        const uint8_t *const *scene_isobj, const float *const *scene_color,
+                                        const int32_t *choices, const double *aug, int B, int P, int C, int augment,
+                                        int C_out, const int *dst_off, float *pc, int32_t *ins_out, uint8_t *isobj_out,
+                                        float *color_out, spacap_stream_t stream);
+int spacap_scene_gather_rows_f32(const float *const *src, const int32_t *choices, int B, int P, int W, float *out,
+                                 int out_stride, int out_off, spacap_stream_t stream);
 /* votes f32 [B,P,9] (three identical votes: centre of the instance's sampled points - point), vmask i64 [B,P]; an
  * instance votes iff isobj of its FIRST sampled point is set; instance labels outside [0, max_inst) never vote. */
 size_t spacap_scene_votes_workspace_bytes(int B, int max_inst);

@@ -25,6 +25,7 @@ import numpy as np
 
 MAX_NUM_OBJ = 128                       # lib/dataset.py:26
 MAX_DES_LEN = 30                        # lib/config.py: CONF.TRAIN.MAX_DES_LEN
+MEAN_COLOR_RGB = np.array([109.8, 97.2, 83.8])   # lib/dataset.py:28
 NYU40IDS = np.array([3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 23, 24, 25, 26, 27, 28, 29,
                      30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40])   # model_util_scannet.py:88
 TYPE2CLASS = {'cabinet': 0, 'bed': 1, 'chair': 2, 'sofa': 3, 'table': 4, 'door': 5, 'window': 6, 'bookshelf': 7,
@@ -108,19 +109,30 @@ class SceneStoreRef:
         self.nyu40id2class = dict(nyu40id2class)
         self.raw2label = dict(raw2label)
 
-    def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None):
+    def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None, multiview=None):
         self.scenes[scene_id] = dict(vert=np.array(vert), ins=np.array(ins), sem=np.array(sem), bbox=np.array(bbox),
                                      x=None if x is None else np.array(x), y=None if y is None else np.array(y),
-                                     z=None if z is None else np.array(z))
+                                     z=None if z is None else np.array(z),
+                                     multiview=None if multiview is None else np.array(multiview))
 
     def get_item(self, scene_id, object_id, object_name, draws, num_points, use_height=True, use_normal=False,
-                 augment=True, use_relation=True):
+                 augment=True, use_relation=True, use_color=False, use_multiview=False):
         sc = self.scenes[scene_id]
         vert, bbox = sc["vert"], sc["bbox"]
-        pc = vert[:, 0:3]
-        color = vert[:, 3:6]
+        if not use_color:
+            pc = vert[:, 0:3]
+            color = vert[:, 3:6]
+        else:
+            # lib/dataset.py:312-315: `point_cloud = mesh_vertices[:, 0:6]` is a VIEW of the cached scene, so the
+            # normalisation below is written back into the cache: a scene's colours are re-normalised once more on
+            # every access (float64 arithmetic, stored as the cache's float32)
+            pc = vert[:, 0:6]
+            pc[:, 3:6] = (pc[:, 3:6] - MEAN_COLOR_RGB) / 256.0
+            color = pc[:, 3:6]
         if use_normal:
             pc = np.concatenate([pc, vert[:, 6:9]], 1)
+        if use_multiview:                                                      # :321-328 (hdf5 rows of the scene)
+            pc = np.concatenate([pc, sc["multiview"]], 1)
         if use_height:
             floor = np.percentile(pc[:, 2], 0.99)                              # :331
             pc = np.concatenate([pc, np.expand_dims(pc[:, 2] - floor, 1)], 1)

@@ -81,6 +81,8 @@ SIGNATURES = {
     "spacap_dropout_add_bwd_f32": (_i, [_p, _l, _f, _u64, _p, _p, _p]),
     "spacap_scene_aug_doubles": (_i, []),
     "spacap_scene_sample_augment_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "spacap_scene_sample_augment_map_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "spacap_scene_gather_rows_f32": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "spacap_scene_votes_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "spacap_scene_votes_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_det_npart": (_i, []),

@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void scene_sample_augment_kernel(const float *
                                                                    const float *const *__restrict__ scene_color,
                                                                    const int32_t *__restrict__ choices,
                                                                    const double *__restrict__ aug, int P, int C, int augment,
+                                                                   int C_out, const int *__restrict__ dst_off,
                                                                    float *__restrict__ pc, int32_t *__restrict__ ins_out,
                                                                    uint8_t *__restrict__ isobj_out, float *__restrict__ color_out) {
   const int b = blockIdx.y;
@@ -49,9 +50,11 @@ __global__ __launch_bounds__(256) void scene_sample_augment_kernel(const float *
     y = (float)((double)y + a[30]);
     z = (float)((double)z + a[31]);
   }
-  float *o = pc + ((size_t)b * P + p) * C;
+  // output rows have C_out channels; source channel c >= 3 goes to dst_off[c] (identity without a map): colour and
+  // multiview columns, when present, sit between them and are filled by scene_gather_rows_kernel
+  float *o = pc + ((size_t)b * P + p) * C_out;
   o[0] = x, o[1] = y, o[2] = z;
-  for (int c = 3; c < C; ++c) o[c] = row[c];
+  for (int c = 3; c < C; ++c) o[dst_off ? dst_off[c] : c] = row[c];
   ins_out[(size_t)b * P + p] = scene_ins[b][src];
   isobj_out[(size_t)b * P + p] = scene_isobj[b][src];
   if (color_out) {
@@ -59,6 +62,22 @@ __global__ __launch_bounds__(256) void scene_sample_augment_kernel(const float *
     float *co = color_out + ((size_t)b * P + p) * 3;
     co[0] = c[0], co[1] = c[1], co[2] = c[2];
   }
+}
+
+// out[b, p, off + j] = src_b[choices[b, p] * W + j], j < W: the per-vertex colour (W = 3, lib/dataset.py:312-315) and multiview
+// (W = 128, :321-328) columns of the sampled points.  LPR lanes per row (1 for narrow rows, 32 for the 512-byte multiview rows:
+// coalesced 128-byte segments both ways).
+template <int LPR>
+__global__ __launch_bounds__(256) void scene_gather_rows_kernel(const float *const *__restrict__ src,
+                                                                const int32_t *__restrict__ choices, int P, int W,
+                                                                float *__restrict__ out, int out_stride, int out_off) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int p = t / LPR, l = t % LPR;
+  if (p >= P) return;
+  const float *row = src[b] + (size_t)choices[(size_t)b * P + p] * W;
+  float *o = out + ((size_t)b * P + p) * out_stride + out_off;
+  for (int j = l; j < W; j += LPR) o[j] = row[j];
 }
 
 __device__ __forceinline__ int f2key(float f) {  // order-preserving float -> signed int
@@ -125,18 +144,45 @@ __global__ __launch_bounds__(256) void votes_write_kernel(const float *__restric
 
 extern "C" int spacap_scene_aug_doubles(void) { return AUG_DOUBLES; }
 
+extern "C" int spacap_scene_sample_augment_map_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
+                                                   const uint8_t *const *scene_isobj, const float *const *scene_color,
+                                                   const int32_t *choices, const double *aug, int B, int P, int C,
+                                                   int augment, int C_out, const int *dst_off, float *pc, int32_t *ins_out,
+                                                   uint8_t *isobj_out, float *color_out, spacap_stream_t stream) {
+  const char *what = "spacap_scene_sample_augment_f32";
+  SPACAP_REQUIRE(B >= 0 && P >= 0 && C >= 3 && C_out >= C && B <= 65535, "%s: bad sizes", what);
+  if (B == 0 || P == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(scene_feat && scene_ins && scene_isobj && choices && pc && ins_out && isobj_out && (aug || !augment) &&
+                     (scene_color || !color_out) && (dst_off || C_out == C), "%s: null pointer", what);
+  hipLaunchKernelGGL(scene_sample_augment_kernel, dim3((P + 255) / 256, B), dim3(256), 0, spacap::as_stream(stream), scene_feat,
+                     scene_ins, scene_isobj, scene_color, choices, aug, P, C, augment, C_out, dst_off, pc, ins_out, isobj_out,
+                     color_out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 extern "C" int spacap_scene_sample_augment_f32(const float *const *scene_feat, const int32_t *const *scene_ins,
                                                const uint8_t *const *scene_isobj, const float *const *scene_color,
                                                const int32_t *choices, const double *aug, int B, int P, int C,
                                                int augment, float *pc, int32_t *ins_out, uint8_t *isobj_out,
                                                float *color_out, spacap_stream_t stream) {
-  const char *what = "spacap_scene_sample_augment_f32";
-  SPACAP_REQUIRE(B >= 0 && P >= 0 && C >= 3 && B <= 65535, "%s: bad sizes", what);
+  return spacap_scene_sample_augment_map_f32(scene_feat, scene_ins, scene_isobj, scene_color, choices, aug, B, P, C, augment, C,
+                                             nullptr, pc, ins_out, isobj_out, color_out, stream);
+}
+
+extern "C" int spacap_scene_gather_rows_f32(const float *const *src, const int32_t *choices, int B, int P, int W, float *out,
+                                            int out_stride, int out_off, spacap_stream_t stream) {
+  const char *what = "spacap_scene_gather_rows_f32";
+  SPACAP_REQUIRE(B >= 0 && P >= 0 && W >= 1 && out_off >= 0 && out_stride >= out_off + W && B <= 65535, "%s: bad sizes", what);
   if (B == 0 || P == 0) return SPACAP_OK;
-  SPACAP_REQUIRE(scene_feat && scene_ins && scene_isobj && choices && pc && ins_out && isobj_out && (aug || !augment) &&
-                     (scene_color || !color_out), "%s: null pointer", what);
-  hipLaunchKernelGGL(scene_sample_augment_kernel, dim3((P + 255) / 256, B), dim3(256), 0, spacap::as_stream(stream), scene_feat,
-                     scene_ins, scene_isobj, scene_color, choices, aug, P, C, augment, pc, ins_out, isobj_out, color_out);
+  SPACAP_REQUIRE(src && choices && out, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  if (W >= 32)
+    hipLaunchKernelGGL(scene_gather_rows_kernel<32>, dim3((unsigned)(((long)P * 32 + 255) / 256), B), dim3(256), 0, s, src, choices, P, W,
+                       out, out_stride, out_off);
+  else
+    hipLaunchKernelGGL(scene_gather_rows_kernel<1>, dim3((P + 255) / 256, B), dim3(256), 0, s, src, choices, P, W, out, out_stride,
+                       out_off);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

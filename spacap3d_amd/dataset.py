@@ -3,9 +3,14 @@ once into HBM; a training batch -- random 40 000-point subsample, height feature
 vote labels, box / class / relation labels -- is then produced by two HIP kernels + batched torch ops on <= 128
 boxes, with no per-item host work on the points.
 
-Mirror of ``ScannetReferenceDataset`` (lib/dataset.py:247-531) for the ScanRefer training path
-(``use_height`` / ``use_normal`` / ``augment`` / ``use_relation``; colour and multiview features are not provided:
-the first is re-normalised in place on every access by the reference (:312), the second needs the ENet hdf5).
+Mirror of ``ScannetReferenceDataset`` (lib/dataset.py:247-531) for the ScanRefer training path: ``use_height`` /
+``use_normal`` / ``use_color`` / ``use_multiview`` / ``augment`` / ``use_relation``, output channels in the reference's
+order xyz, [rgb], [normal], [multiview 128], [height] (:309-333).  Colour keeps the reference's quirk: its
+``point_cloud[:, 3:6] = (point_cloud[:, 3:6] - MEAN_COLOR_RGB) / 256.0`` writes through a VIEW into the cached scene
+(:312-315), so a scene's colours are normalised once more on every access; here the per-scene colour tensor in HBM is
+re-normalised in place per visit, item by item (float64 arithmetic, float32 store, as numpy does).  Multiview rows
+(``enet_feats_maxpool.hdf5``: N x 128 float32 per scene, :321-328) are handed over per scene and stay resident: all
+1 513 scenes are ~116 GB of the 288 GB.
 Same keys, dtypes and shapes as the reference's ``data_dict`` with a leading batch dimension (what its DataLoader's
 default collate produces).  A 288 GB MI355X holds all 1 513 ScanNet scenes (~150 k vertices x 40 B = 9 GB) many times
 over, so nothing is re-read from disk after start-up.
@@ -41,7 +46,8 @@ def _rot(axis, t):
 
 class DeviceSceneDataset:
     def __init__(self, device, mean_size_arr, nyu40id2class, raw2label=None, num_points=40000, use_height=True,
-                 use_normal=False, augment=True, use_relation=True, max_instances=1024):
+                 use_normal=False, augment=True, use_relation=True, max_instances=1024, use_color=False,
+                 use_multiview=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("CPU not supported")
@@ -53,17 +59,31 @@ class DeviceSceneDataset:
             lut[int(k)] = int(v)
         self.nyu2class = lut.to(self.device)
         self.raw2label = dict(raw2label or {})
-        self.C = 3 + (3 if use_normal else 0) + (1 if use_height else 0)
+        self.use_color, self.use_multiview = use_color, use_multiview
+        self.Cn = 3 + (3 if use_normal else 0) + (1 if use_height else 0)      # channels of the per-scene "feat" rows
+        self.C = self.Cn + (3 if use_color else 0) + (128 if use_multiview else 0)
+        # destination channel of every "feat" channel in the output rows: xyz, [rgb], [normal], [multiview], [height]
+        off_n = 3 + (3 if use_color else 0)
+        off_mv = off_n + (3 if use_normal else 0)
+        off_h = off_mv + (128 if use_multiview else 0)
+        self._off_color, self._off_mv = 3, off_mv
+        m = [0, 1, 2] + ([off_n, off_n + 1, off_n + 2] if use_normal else []) + ([off_h] if use_height else [])
+        self._dst_off = torch.tensor(m, dtype=torch.int32, device=self.device) if self.C != self.Cn else None
+        self._mean_rgb = torch.tensor([109.8, 97.2, 83.8], dtype=torch.float64, device=self.device)   # lib/dataset.py:28
         self._scene_index = {}
         self._scenes = []       # per scene: the big per-vertex tensors (kept alive here; the kernels get pointers)
         self._items = []
         self._tables = None     # stacked per-scene / per-item label tables, built lazily by _finalize()
 
     # ---- loading -----------------------------------------------------------------------------------------------
-    def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None):
+    def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None, multiview=None):
         """Arrays as the reference loads them (lib/dataset.py:197-212): vert (N,9) f32, ins / sem (N,), bbox (M,8)
-        [centre, size, nyu40 id, object id], x / y / z (M,M) relation classes."""
+        [centre, size, nyu40 id, object id], x / y / z (M,M) relation classes; ``multiview``: the scene's (N,128)
+        float32 rows of the multiview database (required with use_multiview)."""
         vert = np.asarray(vert)
+        if self.use_multiview:
+            if multiview is None or tuple(np.shape(multiview)) != (vert.shape[0], 128):
+                raise ValueError("use_multiview needs the scene's (N, 128) multiview rows")
         pc = vert[:, 0:3]
         if self.use_normal:
             pc = np.concatenate([pc, vert[:, 6:9]], 1)
@@ -89,14 +109,18 @@ class DeviceSceneDataset:
             "isobj": torch.as_tensor(np.isin(np.asarray(sem), NYU40IDS).astype(np.uint8)).to(d),
             "n": int(vert.shape[0]), "nb": nb, "box8": box8, "rel": rel,
         })
+        if self.use_multiview:
+            self._scenes[-1]["multiview"] = torch.as_tensor(np.ascontiguousarray(multiview, dtype=np.float32)).to(d)
         self._tables = None
 
-    def load_scene(self, root, scene_id):
-        """``<root>/<scene_id>_aligned_vert.npy`` etc., the layout of CONF.PATH.SCANNET_DATA."""
+    def load_scene(self, root, scene_id, multiview_db=None):
+        """``<root>/<scene_id>_aligned_vert.npy`` etc., the layout of CONF.PATH.SCANNET_DATA.  ``multiview_db``: an
+        open mapping scene_id -> (N,128) rows (the reference's h5py.File on enet_feats_maxpool.hdf5, CONF.MULTIVIEW)."""
         base = os.path.join(root, scene_id)
         rel = [np.load(base + f"_{a}.npy") if os.path.exists(base + f"_{a}.npy") else None for a in "xyz"]
+        mv = np.asarray(multiview_db[scene_id]) if (self.use_multiview and multiview_db is not None) else None
         self.add_scene(scene_id, np.load(base + "_aligned_vert.npy"), np.load(base + "_ins_label.npy"),
-                       np.load(base + "_sem_label.npy"), np.load(base + "_aligned_bbox.npy"), *rel)
+                       np.load(base + "_sem_label.npy"), np.load(base + "_aligned_bbox.npy"), *rel, multiview=mv)
 
     def add_item(self, scene_id, object_id, object_name="", lang_feat=None, lang_ids=None, lang_len=None, ann_id=0):
         """One ScanRefer description (an entry of ``self.scanrefer``).  ``lang_feat`` (32,300) / ``lang_ids`` (32,)
@@ -124,8 +148,9 @@ class DeviceSceneDataset:
             "nb": torch.tensor([s["nb"] for s in sc], dtype=torch.int64, device=d),
             "rel": torch.as_tensor(np.stack([s["rel"] for s in sc])).to(d),                         # (S,3,128,128) i64
             "nvert": torch.tensor([s["n"] for s in sc], dtype=torch.int64, device=d),
-            "ptrs": torch.tensor([[s[k].data_ptr() for k in ("feat", "ins", "isobj", "color")] for s in sc],
-                                 dtype=torch.int64, device=d),                                     # (S,4)
+            "ptrs": torch.tensor([[s[k].data_ptr() for k in ("feat", "ins", "isobj", "color")] +
+                                  [s["multiview"].data_ptr() if "multiview" in s else 0] for s in sc],
+                                 dtype=torch.int64, device=d),                                     # (S,5)
             "parity": torch.zeros(len(sc), 2, dtype=torch.int64, device=d),                         # flip state (x, y)
             "item_scene": torch.tensor([i["scene"] for i in it], dtype=torch.int64, device=d),
             "item_object": torch.tensor([i["object_id"] for i in it], dtype=torch.float64, device=d),
@@ -214,15 +239,36 @@ class DeviceSceneDataset:
         st = torch.cuda.current_stream(dev).cuda_stream
         f64 = dict(dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
-            ptrs = t["ptrs"][sidx].t().contiguous()                                        # (4,B) device pointers
+            ptrs = t["ptrs"][sidx].t().contiguous()                                        # (5,B) device pointers
+            color_ptrs = ptrs[3]
+            if self.use_color:
+                # the reference normalises the CACHED colours of the scene on every access (see the module docstring):
+                # visit the items in order; an item whose scene comes up again later in this batch keeps a snapshot
+                order = [int(i) for i in indices]
+                scene_of = [self._items[i]["scene"] for i in order]
+                keep, cp = [], []
+                for b, sc_i in enumerate(scene_of):
+                    col = self._scenes[sc_i]["color"]
+                    col.copy_(((col.double() - self._mean_rgb) / 256.0).float())
+                    if sc_i in scene_of[b + 1:]:
+                        col = col.clone()
+                        keep.append(col)
+                    cp.append(col.data_ptr())
+                color_ptrs = torch.tensor(cp, dtype=torch.int64, device=dev)
             pc = torch.empty(B, P, C, dtype=torch.float32, device=dev)
             ins = torch.empty(B, P, dtype=torch.int32, device=dev)
             isobj = torch.empty(B, P, dtype=torch.uint8, device=dev)
             color = torch.empty(B, P, 3, dtype=torch.float32, device=dev)
-            check(lib.spacap_scene_sample_augment_f32(ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(),
-                                                      ptrs[3].data_ptr(), choices.data_ptr(), aug.data_ptr(), B, P, C,
-                                                      int(self.augment), pc.data_ptr(), ins.data_ptr(), isobj.data_ptr(),
-                                                      color.data_ptr(), st), "spacap_scene_sample_augment_f32")
+            check(lib.spacap_scene_sample_augment_map_f32(
+                ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), color_ptrs.data_ptr(), choices.data_ptr(),
+                aug.data_ptr(), B, P, self.Cn, int(self.augment), C, self._dst_off.data_ptr() if self._dst_off is not None else None,
+                pc.data_ptr(), ins.data_ptr(), isobj.data_ptr(), color.data_ptr(), st), "spacap_scene_sample_augment_map_f32")
+            if self.use_color:      # rgb columns = the (normalised) colours the kernel just gathered into pcl_color
+                check(lib.spacap_scene_gather_rows_f32(color_ptrs.data_ptr(), choices.data_ptr(), B, P, 3, pc.data_ptr(), C,
+                                                       self._off_color, st), "spacap_scene_gather_rows_f32")
+            if self.use_multiview:
+                check(lib.spacap_scene_gather_rows_f32(ptrs[4].data_ptr(), choices.data_ptr(), B, P, 128, pc.data_ptr(), C,
+                                                       self._off_mv, st), "spacap_scene_gather_rows_f32")
             votes = torch.empty(B, P, 9, dtype=torch.float32, device=dev)
             vmask = torch.empty(B, P, dtype=torch.int64, device=dev)
             ws = torch.empty(int(lib.spacap_scene_votes_workspace_bytes(B, self.max_instances)), dtype=torch.uint8, device=dev)

@@ -95,7 +95,19 @@ def main():
 
     ed.EasyDict = EasyDict
     sys.modules["easydict"] = ed
-    sys.modules["h5py"] = types.ModuleType("h5py")
+    # h5py is not installed here.  The reference opens its multiview database with h5py.File(path, "r", libver="latest")
+    # and indexes it by scene id (lib/dataset.py:321-327): the stand-in serves the same rows from an .npz written below.
+    h5 = types.ModuleType("h5py")
+
+    class _File:
+        def __init__(self, path, *a, **k):
+            self._z = np.load(path)
+
+        def __getitem__(self, key):
+            return self._z[key]
+
+    h5.File = _File
+    sys.modules["h5py"] = h5
     # utils/pc_utils.py imports PLY / mesh / plotting packages at module level (unused on this path)
     ply = types.ModuleType("plyfile")
     ply.PlyData = ply.PlyElement = object
@@ -115,6 +127,12 @@ def main():
     CONF.PATH.SCANNET_META = os.path.join(REF, "data", "scannet", "meta_data")
     CONF.PATH.DATA = tmp
     CONF.PATH.SCANNET_DATA = os.path.join(tmp, "scannet_data")
+    # multiview rows (128 per vertex): integer-hash values, regenerated identically by the tests (not stored)
+    sys.path.insert(0, HERE)
+    from detweights import _uniform
+    mv = {sid: (_uniform(v[0].shape[0] * 128, "multiview_" + sid, 5) + np.float32(0.5)).reshape(-1, 128) for sid, v in scenes.items()}
+    np.savez(os.path.join(tmp, "enet_feats_maxpool.npz"), **mv)
+    CONF.MULTIVIEW = os.path.join(tmp, "enet_feats_maxpool.npz")
     from lib.dataset import ScannetReferenceDataset
 
     num_points = 4096
@@ -157,6 +175,28 @@ def main():
             out[f"step{step}/{k}"] = np.asarray(v)
     np.savez_compressed(os.path.join(HERE, "scene_pipeline.npz"), **out)
     print("wrote scene_pipeline.npz:", len(out), "arrays;", {k: np.asarray(v).shape for k, v in d.items() if k != "load_time"})
+
+    # ---- second fixture: the extra input channels (BASELINE configs 3 and 4) -------------------------------------------
+    # colour (with the reference's re-normalisation of the cached scene on every access, lib/dataset.py:312-315), normals
+    # and the 128 multiview channels.  Inputs are those of the first fixture + the hashed multiview rows; per step only
+    # the point cloud rows ::8 (all channels) and the colours are kept.
+    feats = {}
+    for tag, kw in (("color_normal", dict(use_color=True, use_normal=True, use_multiview=False)),
+                    ("multiview_normal", dict(use_color=False, use_normal=True, use_multiview=True)),
+                    ("all", dict(use_color=True, use_normal=True, use_multiview=True))):
+        ds2 = ScannetReferenceDataset(scanrefer=scanrefer, split="train", name="ScanRefer", num_points=1024, use_height=True,
+                                      augment=True, use_relation=True, **kw)
+        for step, idx in enumerate([0, 3, 0, 1, 0]):      # scene 0 is visited four times: four different colour states
+            seed = 2000 + 13 * step
+            np.random.seed(seed)
+            d = ds2[idx]
+            feats[f"{tag}/step{step}/seed"] = seed
+            feats[f"{tag}/step{step}/idx"] = idx
+            feats[f"{tag}/step{step}/point_clouds_rows8"] = np.asarray(d["point_clouds"])[::8]
+            feats[f"{tag}/step{step}/pcl_color"] = np.asarray(d["pcl_color"])
+            feats[f"{tag}/step{step}/vote_label_mask"] = np.asarray(d["vote_label_mask"])
+    np.savez_compressed(os.path.join(HERE, "scene_pipeline_feats.npz"), **feats)
+    print("wrote scene_pipeline_feats.npz:", len(feats), "arrays; channels", {t: feats[f"{t}/step0/point_clouds_rows8"].shape for t in ("color_normal", "multiview_normal", "all")})
 
 
 if __name__ == "__main__":

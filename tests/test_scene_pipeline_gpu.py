@@ -103,3 +103,68 @@ def test_own_draws_feed_a_training_step():
     tr = Trainer(model, fx["mean_size_arr"])
     loss = tr.step(d)
     assert torch.isfinite(loss)
+
+
+def _device_dataset_feats(fx, num_points, **kw):
+    from spacap3d_amd.dataset import DeviceSceneDataset
+    from tests.test_scene_pipeline import multiview_rows
+    ds = DeviceSceneDataset(DEV, fx["mean_size_arr"], dict(zip(fx["nyu40id2class_keys"].tolist(), fx["nyu40id2class_vals"].tolist())),
+                            dict(zip(fx["raw2label_names"].tolist(), fx["raw2label_vals"].tolist())), num_points=num_points,
+                            max_instances=64, **kw)
+    for sid in fx["scene_ids"].tolist():
+        v = fx[f"{sid}/vert"]
+        ds.add_scene(sid, v, fx[f"{sid}/ins"], fx[f"{sid}/sem"], fx[f"{sid}/bbox"], fx[f"{sid}/x"], fx[f"{sid}/y"], fx[f"{sid}/z"],
+                     multiview=multiview_rows(sid, v.shape[0]) if kw.get("use_multiview") else None)
+    for i in range(int(fx["n_items"])):
+        ds.add_item(str(fx["item_scene"][i]), int(fx["item_object"][i]), str(fx["item_object_name"][i]), ann_id=int(fx["item_ann"][i]))
+    return ds
+
+
+@pytest.mark.parametrize("tag", ["color_normal", "multiview_normal", "all"])
+def test_device_pipeline_colour_and_multiview_match_the_reference(tag):
+    """BASELINE configs 3 / 4 input channels against what the reference's own dataset class returned (item by item, in
+    order: scene 0 is visited four times, each time with its colours normalised once more)."""
+    import os
+    from tests.test_scene_pipeline import FEATS, G
+    fx, _ = load_fixture()
+    ff = np.load(os.path.join(G, "scene_pipeline_feats.npz"))
+    ds = _device_dataset_feats(fx, 1024, **FEATS[tag])
+    for step in range(5):
+        idx = int(ff[f"{tag}/step{step}/idx"])
+        sid = str(fx["item_scene"][idx])
+        draws = [R.draws_from_seed(int(ff[f"{tag}/step{step}/seed"]), fx[f"{sid}/vert"].shape[0], 1024)]
+        d = ds.batch([idx], draws)
+        want = ff[f"{tag}/step{step}/point_clouds_rows8"]
+        got = d["point_clouds"][0].cpu().numpy()[::8]
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert np.array_equal(got[:, 3:], want[:, 3:]), (tag, step)          # every feature channel: bit-exact
+        ulp = np.spacing(np.maximum(np.abs(want[:, :3]), np.float32(1e-3)))
+        assert not (np.abs(got[:, :3].astype(np.float64) - want[:, :3]) > 1.01 * ulp).any()
+        assert np.array_equal(d["pcl_color"][0].cpu().numpy(), ff[f"{tag}/step{step}/pcl_color"]), (tag, step)
+        assert np.array_equal(d["vote_label_mask"][0].cpu().numpy(), ff[f"{tag}/step{step}/vote_label_mask"])
+
+
+def test_a_batch_that_repeats_a_scene_sees_successive_colour_states():
+    """Two descriptions of scene 0 and one of scene 1 in ONE batch: the second visit of scene 0 must see the colours
+    normalised twice (the reference's cache semantics), exactly as processing the items one by one."""
+    from tests.test_scene_pipeline import FEATS, multiview_rows
+    fx, _ = load_fixture()
+    kw = FEATS["all"]
+    store = R.SceneStoreRef(fx["mean_size_arr"], dict(zip(fx["nyu40id2class_keys"].tolist(), fx["nyu40id2class_vals"].tolist())),
+                            dict(zip(fx["raw2label_names"].tolist(), fx["raw2label_vals"].tolist())))
+    for sid in fx["scene_ids"].tolist():
+        v = fx[f"{sid}/vert"]
+        store.add_scene(sid, v, fx[f"{sid}/ins"], fx[f"{sid}/sem"], fx[f"{sid}/bbox"], fx[f"{sid}/x"], fx[f"{sid}/y"],
+                        fx[f"{sid}/z"], multiview=multiview_rows(sid, v.shape[0]))
+    ds = _device_dataset_feats(fx, 1024, **kw)
+    idxs = [0, 3, 1]        # items 0 and 1 describe scene 0, item 3 scene 1
+    draws = [R.draws_from_seed(70 + i, fx[f"{str(fx['item_scene'][i])}/vert"].shape[0], 1024) for i in idxs]
+    d = ds.batch(idxs, draws)
+    assert d["point_clouds"].shape == (3, 1024, 138)
+    for b, i in enumerate(idxs):
+        want = store.get_item(str(fx["item_scene"][i]), int(fx["item_object"][i]), str(fx["item_object_name"][i]), draws[b], 1024, **kw)
+        got = d["point_clouds"][b].cpu().numpy()
+        assert np.array_equal(got[:, 3:], want["point_clouds"][:, 3:]), (b, i)
+        assert np.array_equal(d["pcl_color"][b].cpu().numpy(), want["pcl_color"]), (b, i)
+    a, c = d["pcl_color"][0].std(0).max(), d["pcl_color"][2].std(0).max()
+    assert float(a) > 100 * float(c) > 0
