@@ -237,12 +237,29 @@ class deferred_slab_sums:
                       "spacap_sum_slabs_batched_f32")
 
 
-def sum_slabs(part, deferrable=False):
+# weight.data_ptr() -> a view of the trainer's flat gradient bucket covering [dW | db] of that Linear layer (set by
+# engine.Trainer: the slab sums of the Linear-layer gradients then land directly where the all-reduce / optimizer read
+# them, and the per-step gradient pack has nothing left to copy for them)
+GRAD_SLOTS = {}
+
+
+def grad_slot(weight, numel):
+    t = GRAD_SLOTS.get(weight.data_ptr())
+    return t if (t is not None and t.numel() == numel and t.device == weight.device) else None
+
+
+def sum_slabs(part, deferrable=False, out=None):
     """part (nslab, ...) float32 contiguous -> sum over dim 0 in ascending order (csrc/elementwise.hip); falls back to
-    torch.sum when the row size is not a multiple of 4.  ``deferrable``: see ``deferred_slab_sums``."""
+    torch.sum when the row size is not a multiple of 4.  ``deferrable``: see ``deferred_slab_sums``.  ``out``: optional
+    destination (float32, contiguous, same number of elements, 16-byte aligned)."""
     import torch
     n = part[0].numel()
+    if out is not None and (out.numel() != n or out.data_ptr() % 16 or not out.is_contiguous()):
+        out = None
     if part.shape[0] == 1:
+        if out is not None and not (_DEFERRED is not None and _DEFERRED.has_job_for(part)):
+            out.copy_(part[0].reshape(-1))
+            return out.view(part.shape[1:])
         return part[0]   # (inside a deferred block a queued job fills it at the flush: still the leaf gradient)
     can_defer = deferrable and _DEFERRED is not None and part.is_cuda and part.data_ptr() % 16 == 0 and n % 4 == 0 \
         and part.dtype == torch.float32 and part.is_contiguous()
@@ -253,12 +270,15 @@ def sum_slabs(part, deferrable=False):
     if not part.is_cuda or n % 4 or part.dtype != torch.float32 or not part.is_contiguous():
         return part.sum(0)
     if can_defer:
-        with torch.cuda.device(part.device):
-            out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        if out is None:
+            with torch.cuda.device(part.device):
+                out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        else:
+            out = out.view(part.shape[1:])
         _DEFERRED.items.append((part, out))
         return out
     with torch.cuda.device(part.device):
-        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device)
+        out = torch.empty(part.shape[1:], dtype=torch.float32, device=part.device) if out is None else out.view(part.shape[1:])
         check(lib.spacap_sum_slabs_f32(part.data_ptr(), part.shape[0], n, out.data_ptr(),
                                        torch.cuda.current_stream(part.device).cuda_stream), "spacap_sum_slabs_f32")
     return out

@@ -44,7 +44,7 @@ SA_NSAMPLES = (64, 32, 16, 16)        # backbone_module.py:31,40,49,58
 
 
 def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPLES):
-    """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 (+3 on the GPU) tensors:
+    """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 (+7 on the GPU) tensors:
     the four sampling index sets (``sampling_pyramid``), the four ball-query groupings of the SA modules
     (pointnet2_modules.py:241-247) and (idx, weight) of the two feature-propagation modules' three-nearest-neighbour
     interpolation (:399-405; fp1: SA3 points from SA4's, fp2: SA2 points from SA3's, backbone_module.py:115-119).
@@ -68,6 +68,8 @@ def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPL
         # features are an input and get no gradient)
         from .sa_mlp import rows_index
         out = out + tuple(rows_index(idx_all[l], xyzs[l].shape[1]) for l in (1, 2, 3))
+        # + the sampled centres themselves (each SA module otherwise gathers them again: an index conversion + a gather)
+        out = out + tuple(x.contiguous() for x in xyzs[1:])
     return out
 
 
@@ -97,17 +99,17 @@ class Pointnet2Backbone(nn.Module):
     def forward(self, data_dict):
         xyz, features = self._break_up_pc(data_dict["point_clouds"])
         # optional precomputed sampling pyramid (see sampling_pyramid); None -> each SA module samples itself
-        # (4 tensors: sampling_pyramid; 12 / 15: geometry_pyramid, which adds the groupings, the interpolation weights and, on
-        # the GPU, the inverted indices of the SA2..SA4 groupings)
+        # (4 tensors: sampling_pyramid; 12 / 19: geometry_pyramid, which adds the groupings, the interpolation weights and, on
+        # the GPU, the inverted indices of the SA2..SA4 groupings and the four sets of sampled centres)
         pyr = tuple(data_dict.get("fps_pyramid") or ())
-        pyr = pyr + (None,) * (15 - len(pyr))
-        xyz, features, fps_inds = self.sa1(xyz, features, pyr[0], pyr[4])
+        pyr = pyr + (None,) * (19 - len(pyr))
+        xyz, features, fps_inds = self.sa1(xyz, features, pyr[0], pyr[4], None, pyr[15])
         data_dict["sa1_inds"], data_dict["sa1_xyz"], data_dict["sa1_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1], pyr[5], pyr[12])
+        xyz, features, fps_inds = self.sa2(xyz, features, pyr[1], pyr[5], pyr[12], pyr[16])
         data_dict["sa2_inds"], data_dict["sa2_xyz"], data_dict["sa2_features"] = fps_inds, xyz, features
-        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2], pyr[6], pyr[13])
+        xyz, features, fps_inds = self.sa3(xyz, features, pyr[2], pyr[6], pyr[13], pyr[17])
         data_dict["sa3_xyz"], data_dict["sa3_features"] = xyz, features
-        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3], pyr[7], pyr[14])
+        xyz, features, fps_inds = self.sa4(xyz, features, pyr[3], pyr[7], pyr[14], pyr[18])
         data_dict["sa4_xyz"], data_dict["sa4_features"] = xyz, features
         features = self.fp1(data_dict["sa3_xyz"], data_dict["sa4_xyz"], data_dict["sa3_features"],
                             data_dict["sa4_features"], nn=(pyr[8], pyr[9]) if pyr[8] is not None else None)
@@ -119,6 +121,13 @@ class Pointnet2Backbone(nn.Module):
         # VoteNet quirk kept on purpose (backbone_module.py:127): the vote loss gathers labels with it.
         data_dict["fp2_inds"] = data_dict["sa1_inds"][:, 0:num_seed]
         return data_dict
+
+
+def _bn_relu(bn, x, training):
+    """relu(bn(x)); in training mode one fused op of the backend (batch statistics, csrc/bn_relu.hip) when it has one."""
+    from .backend import ops
+    f = getattr(ops(), "bn_relu_train", None) if (training and x.is_cuda) else None
+    return f(x.contiguous(), bn) if f is not None else F.relu(bn(x))
 
 
 def _conv(conv, x, training):
@@ -147,8 +156,8 @@ class VotingModule(nn.Module):
     def forward(self, seed_xyz, seed_features):
         B, num_seed = seed_xyz.shape[0], seed_xyz.shape[1]
         num_vote = num_seed * self.vote_factor
-        net = F.relu(self.bn1(_conv(self.conv1, seed_features, self.training)))
-        net = F.relu(self.bn2(_conv(self.conv2, net, self.training)))
+        net = _bn_relu(self.bn1, _conv(self.conv1, seed_features, self.training), self.training)
+        net = _bn_relu(self.bn2, _conv(self.conv2, net, self.training), self.training)
         net = self.conv3(net)
         net = net.transpose(2, 1).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, num_vote, 3)
@@ -209,8 +218,18 @@ class ProposalModule(nn.Module):
         data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
         net = features.contiguous() if self.training else features
-        for layer in self.proposal:
-            net = _conv(layer, net, self.training) if isinstance(layer, nn.Conv1d) else layer(net)
+        layers = list(self.proposal)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            if isinstance(layer, nn.Conv1d):
+                net = _conv(layer, net, self.training)
+            elif isinstance(layer, nn.BatchNorm1d) and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                net = _bn_relu(layer, net, self.training)   # BatchNorm1d -> ReLU as one op in training mode
+                i += 1
+            else:
+                net = layer(net)
+            i += 1
         return self.decode_scores(net, data_dict)
 
     def decode_pred_box(self, data_dict):

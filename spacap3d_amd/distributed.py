@@ -95,7 +95,11 @@ class FlatGradBucket:
             return
         if sources is None:
             sources = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, list(sources))
+        # gradients that were produced directly inside the flat buffer (engine.Trainer registers [dW | db] slots for
+        # the Linear layers, _native.GRAD_SLOTS) need no copy
+        pairs = [(v, s) for v, s in zip(self.views, sources) if s.data_ptr() != v.data_ptr()]
+        if pairs:
+            torch._foreach_copy_([v for v, _ in pairs], [s for _, s in pairs])
         for p, v in zip(self.params, self.views):
             p.grad = v
 

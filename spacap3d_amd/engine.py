@@ -33,6 +33,7 @@ class Trainer:
         self._graph_grads = None
         self._capture_stream = None
         self.last_losses = {}
+        self._bn_counters = None
         self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
@@ -99,14 +100,44 @@ class Trainer:
         # gradients are assigned by autograd (no per-parameter accumulate kernels) and packed into the flat
         # bucket only when there is something to all-reduce
         used = self._group_qkv(used)
+        self._adopt_bn_counters()
         self.bucket = FlatGradBucket(used, views=False)
         kw = dict(lr=self.lr, weight_decay=self.weight_decay, eps=self.adam_eps)
         if used[0].is_cuda:
             from .optim import FlatAdam   # one launch over a flat parameter buffer (spacap3d_amd/optim.py)
             self.optimizer = FlatAdam(self.bucket, **kw)
             self._attach_packed_qkv()
+            self._register_grad_slots()
         else:
             self.optimizer = torch.optim.Adam(used, **kw)
+
+    def _adopt_bn_counters(self):
+        """The ``num_batches_tracked`` buffers of the BatchNorm layers whose training forward runs through the fused ops
+        (fused_bn.bump_counter) become views of ONE int64 buffer that the step bumps once: ~25 one-element add launches
+        per step fewer.  Values, names and state_dict entries are unchanged.  (Only inside this Trainer's steps: a
+        train-mode forward outside it no longer advances these counters.)"""
+        from .detector import ProposalModule, VotingModule
+        from .pointnet2_modules import _BN2d
+        from .transformer_captioner import PositionalEncodingLearned
+        bns = []
+        for m in self.model.modules():
+            if isinstance(m, _BN2d):
+                bns.append(m.bn)
+            elif isinstance(m, VotingModule):
+                bns += [m.bn1, m.bn2]
+            elif isinstance(m, ProposalModule):
+                bns += [l for l in m.proposal if isinstance(l, torch.nn.BatchNorm1d)]
+            elif isinstance(m, PositionalEncodingLearned):
+                bns.append(m.position_embedding_head[1])
+        bns = [b for b in bns if b.track_running_stats and b.num_batches_tracked is not None and b.momentum is not None]
+        if not bns or not bns[0].num_batches_tracked.is_cuda:
+            return
+        flat = torch.stack([b.num_batches_tracked.detach() for b in bns]).contiguous()
+        for i, b in enumerate(bns):
+            view = flat[i]
+            view._spacap_deferred = True
+            b._buffers["num_batches_tracked"] = view
+        self._bn_counters = flat
 
     def _attention_modules(self):
         from .transformer_captioner import MultiHeadedAttention
@@ -126,6 +157,32 @@ class Trainer:
         rest = [p for p in used if id(p) not in moved]
         return rest + [p for g in groups for p in g]
 
+    def _register_grad_slots(self):
+        """[dW | db] of every Linear layer whose weight is directly followed by its bias in the flat bucket (and of the
+        packed q | k | v groups: three weights, then three biases) -> the matching slice of the flat gradient buffer
+        (_native.GRAD_SLOTS): the deferred slab sums write there, the gradient pack skips them."""
+        from . import _native
+        _native.GRAD_SLOTS.clear()
+        ps, flat = self.bucket.params, self.bucket.flat
+        offs, o = [], 0
+        for p in ps:
+            offs.append(o)
+            o += p.numel()
+        pos = {id(p): i for i, p in enumerate(ps)}
+        for i, p in enumerate(ps[:-1]):
+            b = ps[i + 1]
+            if p.dim() == 2 and b.dim() == 1 and b.shape[0] == p.shape[0] and (offs[i] * 4) % 16 == 0:
+                _native.GRAD_SLOTS[p.data_ptr()] = flat[offs[i]:offs[i] + p.numel() + b.numel()]
+        for m in self._attention_modules():
+            pk = getattr(m, "_packed_qkv", None)
+            ws, bs = [l.weight for l in m.linears[:3]], [l.bias for l in m.linears[:3]]
+            if pk is None or not all(id(t) in pos for t in ws + bs):
+                continue
+            i0 = pos[id(ws[0])]
+            if [pos[id(t)] for t in ws + bs] == list(range(i0, i0 + 6)) and (offs[i0] * 4) % 16 == 0:
+                n = sum(t.numel() for t in ws + bs)
+                _native.GRAD_SLOTS[pk[0].data_ptr()] = flat[offs[i0]:offs[i0] + n]
+
     def _attach_packed_qkv(self):
         from .linear import packed_views
         for m in self._attention_modules():
@@ -140,6 +197,8 @@ class Trainer:
             from .attention import advance_rng
             advance_rng(pc.device)  # new attention-dropout masks every step, also under graph replay
         self.bucket.zero()
+        if self._bn_counters is not None:
+            self._bn_counters.add_(1)    # every BatchNorm layer's num_batches_tracked, one launch (see _adopt_bn_counters)
         d = self.loss(data_dict)
         if pc.is_cuda:
             # the ~70 weight-gradient slab sums of the backward are only read by the optimizer: queue them and run them
@@ -273,6 +332,7 @@ class Trainer:
             self._capture(static, warmup=0)
         pre = data_dict.pop("_fps_prefetch", None)
         static_pyr = self._static.get("fps_pyramid")
+        dsts, srcs = [], []
         if static_pyr is not None:
             # The captured graph READS the pyramid (sampling / grouping / interpolation indices) from static buffers
             # and never computes it.  A batch that arrives without a prefetched pyramid (first batch after
@@ -288,15 +348,18 @@ class Trainer:
             if len(pyr) != len(static_pyr):
                 raise RuntimeError(f"prefetched pyramid has {len(pyr)} tensors, the captured graph expects "
                                    f"{len(static_pyr)} (prefetch_geometry changed after enable_graph?)")
-            for dst, src in zip(static_pyr, pyr):
-                dst.copy_(src, non_blocking=True)
+            dsts, srcs = list(static_pyr), list(pyr)
+            for src in pyr:
                 src.record_stream(torch.cuda.current_stream(src.device))
         elif pre is not None:
             # graph captured WITHOUT a pyramid: it samples / groups inside the replay; the prefetched one is not needed
             torch.cuda.current_stream(pre[0][0].device).wait_event(pre[1])
         for k, dst in self._static.items():
             if k != "fps_pyramid" and k in data_dict and data_dict[k] is not dst:
-                dst.copy_(data_dict[k], non_blocking=True)
+                dsts.append(dst)
+                srcs.append(data_dict[k])
+        if dsts:   # the batch and its pyramid into the graph's static buffers: one multi-tensor copy per dtype, not ~32 launches
+            torch._foreach_copy_(dsts, srcs, non_blocking=True)
         if next_data is not None:
             self.prefetch(next_data)
         self.graph.replay()

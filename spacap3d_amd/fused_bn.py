@@ -74,12 +74,20 @@ class BNReLU(Function):
         return dz, dg, db, None, None, None, None, None
 
 
+def bump_counter(bn):
+    """bn.num_batches_tracked += 1 -- unless a training engine has taken the counter over (the buffer then carries the
+    attribute ``_spacap_deferred``: engine.Trainer._adopt_bn_counters bumps all of them with one add per step instead
+    of one tiny launch per layer; with momentum set the counter never enters the arithmetic)."""
+    t = bn.num_batches_tracked
+    if bn.track_running_stats and t is not None and not getattr(t, "_spacap_deferred", False):
+        t.add_(1)
+
+
 def bn_relu_train(z, bn, pool_S=None):
     """z (B,C,...) -> relu(batch_norm(z)) with batch statistics; with ``pool_S`` the trailing dimension (size
     pool_S) is max-reduced as well ((B,C,P,S) -> (B,C,P)).  ``bn`` is the torch BatchNorm module whose
     parameters / running statistics are used and updated (momentum semantics of torch.nn.BatchNorm)."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_counter(bn)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return BNReLU.apply(z, bn.weight, bn.bias, rm, rv, momentum, bn.eps, pool_S)

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch.autograd import Function
 
-from ._native import check, conv1x1_wgrad_partials, lib, linear_wgrad_partials, sum_slabs
+from ._native import check, conv1x1_wgrad_partials, grad_slot, lib, linear_wgrad_partials, sum_slabs
 
 
 def rows_product(a2, W, bias, trans_w):
@@ -70,7 +70,7 @@ class FusedLinear(Function):
         part = linear_wgrad_partials(g2.contiguous(), x2.contiguous(), True, deferrable=True) if g2.is_cuda else None
         if part is None:
             return dx, g2.t() @ x2, g2.sum(0)
-        s = sum_slabs(part, deferrable=True)
+        s = sum_slabs(part, deferrable=True, out=grad_slot(weight, CK * CP + CK))
         return dx, s[:CK * CP].view(CK, CP), s[CK * CP:]
 
 
@@ -117,7 +117,7 @@ class FFNTail(Function):
             if part is None:
                 dw, db = g2.t() @ y2, g2.sum(0)
             else:
-                s = sum_slabs(part, deferrable=True)
+                s = sum_slabs(part, deferrable=True, out=grad_slot(weight, CK * CP + CK))
                 dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         return dh.view_as(y), dw, db, None, None
 
@@ -156,7 +156,7 @@ class PackedLinear(Function):
         if part is None:
             dw, db = g2.t() @ x2, g2.sum(0)
         else:
-            s = sum_slabs(part, deferrable=True)
+            s = sum_slabs(part, deferrable=True, out=grad_slot(weight, CK * CP + CK))
             dw, db = s[:CK * CP].view(CK, CP), s[CK * CP:]
         a, b, _ = ctx.split
         return (dx, None, None, dw[:a], dw[a:a + b], dw[a + b:], db[:a], db[a:a + b], db[a + b:])

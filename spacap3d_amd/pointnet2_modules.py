@@ -94,17 +94,21 @@ class PointnetSAModuleVotes(nn.Module):
         self.mlp_module = SharedMLP(mlp_spec, bn=bn)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None,
-                idx: torch.Tensor = None, rows_idx: torch.Tensor = None):
+                idx: torch.Tensor = None, rows_idx: torch.Tensor = None, new_xyz: torch.Tensor = None):
         """``inds`` (B,npoint) / ``idx`` (B,npoint,nsample): optionally precomputed sampling and grouping indices
         (they depend on the coordinates only: detector.geometry_pyramid computes them ahead of the step);
-        ``rows_idx``: optionally the inverted index of ``idx`` (sa_mlp.rows_index) for the fused op's backward."""
+        ``rows_idx``: optionally the inverted index of ``idx`` (sa_mlp.rows_index) for the fused op's backward;
+        ``new_xyz``: optionally the sampled centres xyz[inds] themselves."""
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
         from .backend import ops
         fused = getattr(ops(), "sa_mlp_train", None) if self.training else None
-        if fused is not None and xyz.is_cuda:
+        if new_xyz is not None and not xyz.requires_grad:
+            # precomputed centres xyz[inds] (detector.geometry_pyramid); never for coordinates that need a gradient
+            assert new_xyz.shape == (xyz.shape[0], self.npoint, 3)
+        elif fused is not None and xyz.is_cuda:
             # centres as a row gather of the (B,N,3) coordinates (same values as gather_operation on the transposed
             # copy, :239-241, without the two transposes)
             new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))

@@ -47,8 +47,9 @@ class _SAMLP(Function):
                 bn = bns[k]
                 mom = 0.0 if bn.momentum is None else float(bn.momentum)
                 track = bn.track_running_stats and bn.running_mean is not None
-                if track and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
+                if track:
+                    from .fused_bn import bump_counter
+                    bump_counter(bn)
                 check(lib.spacap_sa_bn_finalize_f32(part.data_ptr(), C, R, float(bn.eps), mom, gamma.data_ptr(),
                                                     beta.data_ptr(), _ptr(bn.running_mean if track else None),
                                                     _ptr(bn.running_var if track else None), stats[k].data_ptr(), st),

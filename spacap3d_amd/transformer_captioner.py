@@ -252,7 +252,13 @@ class PositionalEncodingLearned(nn.Module):
             nn.Conv1d(d_model, d_model, kernel_size=1))
 
     def forward(self, x, xyz):
-        return x + self.position_embedding_head(xyz.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+        h = self.position_embedding_head
+        t = xyz.transpose(1, 2).contiguous()
+        if self.training and t.is_cuda and getattr(ops(), "bn_relu_train", None) is not None:
+            t = h[3](ops().bn_relu_train(h[0](t), h[1]))       # Conv1d -> [BatchNorm1d -> ReLU as one fused op] -> Conv1d
+        else:
+            t = h(t)
+        return x + t.transpose(1, 2).contiguous()
 
 
 class Encoder(nn.Module):

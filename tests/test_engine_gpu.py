@@ -220,7 +220,7 @@ def test_geometry_pyramid_equals_what_the_modules_compute_themselves():
     net = Pointnet2Backbone(input_feature_dim=1).to(DEV).train()
     pc = S.scene_batch(2, 9000, seed=5).to(DEV)
     pyr = geometry_pyramid(pc[..., :3].contiguous())
-    assert len(pyr) == 15 and pyr[4].shape == (2, 2048, 64) and pyr[11].shape == (2, 1024, 3) and pyr[12].dtype == torch.uint8
+    assert len(pyr) == 19 and pyr[15].shape == (2, 2048, 3) and pyr[4].shape == (2, 2048, 64) and pyr[11].shape == (2, 1024, 3) and pyr[12].dtype == torch.uint8
     outs = []
     for p in (None, sampling_pyramid(pc[..., :3].contiguous()), pyr):
         d = {"point_clouds": pc}
