@@ -44,6 +44,7 @@ class HipBackend:
         self.relation_tail = _lin.relation_tail
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
+        self.sa_mlp_eval = _sa.sa_mlp_eval
 
 
 def ops():

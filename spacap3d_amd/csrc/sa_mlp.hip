@@ -594,6 +594,178 @@ __global__ __launch_bounds__(256) void sa_mid_fwd32_kernel(const float *__restri
   }
 }
 
+// ---- the same layer on the bf16 matrix cores with fp32-equivalent accuracy ("bf16 x 3") ---------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950, which makes these 128-wide layers matrix-core bound.  Here every
+// fp32 operand is split exactly into three bf16 pieces, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 -
+// x2): 3 x 8 = 24 significant bits), and the product a*w is evaluated as the six bf16 products with weight >= 2^-16
+//     a1 w1 + a1 w2 + a2 w1 + a2 w2 + a1 w3 + a3 w1        (dropped: a2 w3, a3 w2, a3 w3 <= 2^-24 |a w|)
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: 6/16 of the fp32-MFMA time for the same fp32-level result
+// (the dropped terms are of the size of ONE fp32 rounding of the product; the summation order differs from the fp32 kernel
+// as it does between any two GEMM implementations).  The kernel is then HBM bound.
+//   weights: split once per workgroup into registers (lane (c = lane % 32, g = lane / 32): 8 consecutive k of channel cb + c
+//            per MFMA step and piece);
+//   activations: BN + ReLU as before while staging, then split; three bf16 images [TM][CIN + 8] in LDS (row stride == 4
+//            words mod 64: conflict-free ds_read_b128 of the B operand, 8 consecutive k of row r per lane);
+//   accumulators are stored straight from registers (16-byte pieces, 32 bytes per row and instruction, 4 instructions per
+//            128-byte line back to back): no output tile in LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l) {
+  h = (__bf16)v;
+  const float r = v - (float)h;
+  m = (__bf16)r;
+  l = (__bf16)(r - (float)m);
+}
+template <int CIN, int LAB = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void sa_mid_fwd_bf3_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
+                                                             const float *__restrict__ W, int Cout, long R,
+                                                             float *__restrict__ zout, double *__restrict__ part) {
+  constexpr int LDB = CIN + 8, KS = CIN / 16, IMG = TM * LDB, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  constexpr int COB = 128, RB = TM / 32, NCH = RB * KS;
+  extern __shared__ __attribute__((aligned(16))) __bf16 simg[];   // [3][TM][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int cbb = blockIdx.y * COB, cb = cbb + 32 * w;
+  bf16x8 wsp[3][KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float *src = W + (size_t)(cb + l31) * CIN + 16 * s + 8 * kk;
+    const f32x4 lo = ld4(src), hi = ld4(src + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __bf16 a, b, c;
+      split3(i < 4 ? lo[i] : hi[i - 4], a, b, c);
+      wsp[0][s][i] = a, wsp[1][s][i] = b, wsp[2][s][i] = c;
+    }
+  }
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 mean, sc, be;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+    mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+  }
+  f32x4 ssum[4], ssq[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ssum[b] = ssq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TM - 1) / TM;
+  f32x4 pre[NV];
+  auto fetch = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
+    }
+  };
+  constexpr int NST = RB * 4;   // global stores per lane and tile
+  auto wait_prefetch = [&](bool stores_pending) {
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));
+  };
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
+    const long row0 = t * TM;
+    wait_prefetch(stores_pending);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      bf16x4 p0, p1, p2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a = fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        if (!FULL && row0 + row >= R) a = 0.f;
+        __bf16 h, m, l;
+        split3(a, h, m, l);
+        p0[u] = h, p1[u] = m, p2[u] = l;
+      }
+      __bf16 *dst = simg + row * LDB + c4 * 4;
+      *reinterpret_cast<bf16x4 *>(dst) = p0;
+      *reinterpret_cast<bf16x4 *>(dst + IMG) = p1;
+      *reinterpret_cast<bf16x4 *>(dst + 2 * IMG) = p2;
+    }
+    __syncthreads();
+    if (FULL && LAB != 3) fetch(t + gridDim.x);
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[rb][v] = 0.f;
+    {
+      const __bf16 *bsrc = simg + l31 * LDB + 8 * kk;
+      bf16x8 bq[2][3];
+      auto bload = [&](int c) {
+        const int rb = c / KS, s = c % KS;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz)
+          bq[c & 1][pz] = *reinterpret_cast<const bf16x8 *>(bsrc + pz * IMG + rb * 32 * LDB + 16 * s);
+      };
+      bload(0);
+      bload(1);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int rb = c / KS, s = c % KS;
+        __builtin_amdgcn_sched_barrier(0);
+        // smallest terms first
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][2], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[2][s], bq[c & 1][0], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[1][s], bq[c & 1][1], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][1], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[1][s], bq[c & 1][0], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][0], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) bload(c + 2);
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const long grow = row0 + rb * 32 + l31;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const f32x4 v = {acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+        if (FULL || grow < R) {
+          ssum[b] += v;
+          ssq[b] += v * v;
+          if (LAB != 2) st4(zout + (size_t)grow * Cout + cb + 8 * b + 4 * kk, v);
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the images before the next tile is staged over them
+  };
+  const long nfull = R / TM;
+  bool pending = false;
+  if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(pre[i]));
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    fetch(nfull);
+    tile(nfull, std::false_type{}, false);
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = ssum[b][u], q = ssq[b][u];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      if (l31 == 0) {
+        const int c = cb + 8 * b + 4 * kk + u;
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)a;
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)q;
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
+      }
+    }
+}
+
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
 __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ st,
                                                           long G, int S, int C, float *__restrict__ out,
@@ -1269,6 +1441,21 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   {                                                                                                                  \
     if (lab == 1) MFL(CI, NTV, GY, 1) else if (lab == 2) MFL(CI, NTV, GY, 2) else if (lab == 3) MFL(CI, NTV, GY, 3)  \
     else if (lab == 4) MFL(CI, NTV, GY, 4) else if (lab == 5) MFL(CI, NTV, GY, 5) else MFL(CI, NTV, GY, 0)           \
+  }
+  static const bool bf3 = getenv("SPACAP_SA_BF16X3") != nullptr;   // split-bf16 matrix-core path (see sa_mid_fwd_bf3_kernel)
+  if (bf3 && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && lab != 1 && lab != 4 && lab != 5) {
+    const size_t lds3 = (size_t)3 * TM * (Cin + 8) * sizeof(__bf16);
+#define MB(CI, LABV)                                                                                                 \
+  {                                                                                                                  \
+    static const int res = resident_blocks(sa_mid_fwd_bf3_kernel<CI, LABV>, lds3);                                   \
+    hipLaunchKernelGGL((sa_mid_fwd_bf3_kernel<CI, LABV>), dim3(grid_rows(res, Cout / 128, tiles), Cout / 128),        \
+                       dim3(256), lds3, s, zin, st_in, W, Cout, R, zout, part);                                      \
+  }
+    if (Cin == 64) { if (lab == 2) MB(64, 2) else if (lab == 3) MB(64, 3) else MB(64, 0) }
+    else { if (lab == 2) MB(128, 2) else if (lab == 3) MB(128, 3) else MB(128, 0) }
+#undef MB
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
   }
   if (Cin == 64 && Cout == 64) MF(64, 1, 1)
   else if (Cin == 64 && Cout % 128 == 0) MF(64, 2, Cout / 128)

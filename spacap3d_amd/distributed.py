@@ -64,14 +64,14 @@ class FlatGradBucket:
         assert self.params, "no trainable parameters"
         self.views_mode = views
         dev, dt = self.params[0].device, self.params[0].dtype
-        total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=dt, device=dev)
-        self.views = []
-        off = 0
+        # every tensor starts on a 16-byte boundary of the flat buffer (kernels that write gradients in place, and the
+        # flat optimizer, use 16-byte accesses); the padding elements stay zero and ride along in the all-reduce
+        self.offsets, off = [], 0
         for p in self.params:
-            n = p.numel()
-            self.views.append(self.flat[off:off + n].view_as(p))
-            off += n
+            self.offsets.append(off)
+            off = (off + p.numel() + 3) // 4 * 4
+        self.flat = torch.zeros(off, dtype=dt, device=dev)
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
         if views:
             for p, v in zip(self.params, self.views):
                 p.grad = v

@@ -163,15 +163,11 @@ class Trainer:
         (_native.GRAD_SLOTS): the deferred slab sums write there, the gradient pack skips them."""
         from . import _native
         _native.GRAD_SLOTS.clear()
-        ps, flat = self.bucket.params, self.bucket.flat
-        offs, o = [], 0
-        for p in ps:
-            offs.append(o)
-            o += p.numel()
+        ps, flat, offs = self.bucket.params, self.bucket.flat, self.bucket.offsets
         pos = {id(p): i for i, p in enumerate(ps)}
         for i, p in enumerate(ps[:-1]):
             b = ps[i + 1]
-            if p.dim() == 2 and b.dim() == 1 and b.shape[0] == p.shape[0] and (offs[i] * 4) % 16 == 0:
+            if p.dim() == 2 and b.dim() == 1 and b.shape[0] == p.shape[0] and offs[i + 1] == offs[i] + p.numel():
                 _native.GRAD_SLOTS[p.data_ptr()] = flat[offs[i]:offs[i] + p.numel() + b.numel()]
         for m in self._attention_modules():
             pk = getattr(m, "_packed_qkv", None)
@@ -179,8 +175,8 @@ class Trainer:
             if pk is None or not all(id(t) in pos for t in ws + bs):
                 continue
             i0 = pos[id(ws[0])]
-            if [pos[id(t)] for t in ws + bs] == list(range(i0, i0 + 6)) and (offs[i0] * 4) % 16 == 0:
-                n = sum(t.numel() for t in ws + bs)
+            n = sum(t.numel() for t in ws + bs)
+            if [pos[id(t)] for t in ws + bs] == list(range(i0, i0 + 6)) and offs[i0 + 5] + bs[2].numel() == offs[i0] + n:
                 _native.GRAD_SLOTS[pk[0].data_ptr()] = flat[offs[i0]:offs[i0] + n]
 
     def _attach_packed_qkv(self):
@@ -359,7 +355,13 @@ class Trainer:
                 dsts.append(dst)
                 srcs.append(data_dict[k])
         if dsts:   # the batch and its pyramid into the graph's static buffers: one multi-tensor copy per dtype, not ~32 launches
-            torch._foreach_copy_(dsts, srcs, non_blocking=True)
+            groups = {}
+            for dst, src in zip(dsts, srcs):
+                g = groups.setdefault((dst.dtype, src.dtype), ([], []))
+                g[0].append(dst)
+                g[1].append(src)
+            for gd, gs in groups.values():
+                torch._foreach_copy_(gd, gs, non_blocking=True)
         if next_data is not None:
             self.prefetch(next_data)
         self.graph.replay()

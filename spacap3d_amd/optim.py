@@ -20,15 +20,12 @@ class FlatAdam:
         flat_g = bucket.flat
         if not flat_g.is_cuda:
             raise RuntimeError("CPU not supported")
-        self.flat_p = torch.empty_like(flat_g)
-        off = 0
+        self.flat_p = torch.zeros_like(flat_g)
         with torch.no_grad():
-            for p in bucket.params:
-                n = p.numel()
-                view = self.flat_p[off:off + n].view_as(p)
+            for p, off in zip(bucket.params, bucket.offsets):   # same (16-byte aligned) layout as the gradient bucket
+                view = self.flat_p[off:off + p.numel()].view_as(p)
                 view.copy_(p)
                 p.data = view          # the module's parameter now lives in the flat buffer
-                off += n
         self.m = torch.zeros_like(flat_g)
         self.v = torch.zeros_like(flat_g)
         self.step_t = torch.zeros((), dtype=torch.float32, device=flat_g.device)

@@ -125,6 +125,13 @@ class PointnetSAModuleVotes(nn.Module):
                         self.use_xyz, rows_idx)
             if out is not None:
                 return new_xyz, out, inds
+        fused_eval = getattr(ops(), "sa_mlp_eval", None) if (not self.training and not torch.is_grad_enabled()) else None
+        if fused_eval is not None and xyz.is_cuda:
+            # inference: the same fused kernels with the BatchNorm layers folded to their running statistics
+            out = fused_eval(xyz, new_xyz, features, idx, self.mlp_module, self.radius if self.normalize_xyz else 1.0,
+                             self.use_xyz)
+            if out is not None:
+                return new_xyz, out, inds
         if features is not None:
             features = features.contiguous()
         grouped_features, _grouped_xyz = self.grouper(xyz, new_xyz, features, idx=idx)  # (B, C+3, npoint, nsample)

@@ -18,12 +18,14 @@ def _ptr(t):
 
 class _SAMLP(Function):
     """inputs: xyz (B,Np,3), new_xyz (B,N,3), idx (B,N,S) int32, feat (B,Np) or None [inline 1-channel feature],
-    Y (B,Np,C1) or None [features already multiplied by W1[:,3:]], W1 (C1, 3 or 4), W2 (C2,C1), W3 (C3,C2),
-    gamma/beta x3, then the three BatchNorm modules (running statistics are updated in place) and rdiv.
-    output: (B,N,C3) pooled features."""
+    pm (B,Np,Cf) or None [point-major features of the source points: the first layer commutes with the gather, so
+    Y = pm W1[:, 3:]^T is formed once per SOURCE point], W1 (C1, 3 + Cf) the FULL first-layer weight (the kernels read
+    its first 3 / 4 columns through the row stride), W2 (C2,C1), W3 (C3,C2), gamma/beta x3, then the three BatchNorm
+    modules (running statistics are updated in place) and rdiv.  output: (B,N,C3) pooled features.
+    One node for the whole module: W1's gradient is assembled once ([xyz columns | feature columns])."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, idx, feat, Y, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv, rows_index=None):
+    def forward(ctx, xyz, new_xyz, idx, feat, pm, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv, rows_index=None):
         dev = xyz.device
         B, Np, _ = xyz.shape
         N, S = idx.shape[1], idx.shape[2]
@@ -34,7 +36,7 @@ class _SAMLP(Function):
         xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
         W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
         feat = feat.contiguous() if feat is not None else None
-        Y = Y.contiguous() if Y is not None else None
+        Y = torch.matmul(pm, W1c[:, 3:].t()).contiguous() if pm is not None else None
         nparts = int(lib.spacap_sa_nparts())
         with torch.cuda.device(dev):
             part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
@@ -70,6 +72,7 @@ class _SAMLP(Function):
             check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
                                              st), "spacap_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg)
+        ctx.pm = pm                   # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)
         ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
         ctx.has_Y = Y is not None
@@ -146,11 +149,11 @@ class _SAMLP(Function):
             drel = torch.empty(R, 3, **f32) if ctx.need_xyz else None
             check(lib.spacap_sa_l1_bwd_f32(dy1.data_ptr(), z1.data_ptr(), coef[0].data_ptr(), _ptr(feat), xyz.data_ptr(),
                                            new_xyz.data_ptr(), idx.data_ptr(), W1.data_ptr(), W1.shape[1], ctx.rdiv, B, Np,
-                                           N, S, C1, pw1.data_ptr(), _ptr(drel), int(ctx.has_Y and ctx.needs_input_grad[4]), st),
+                                           N, S, C1, pw1.data_ptr(), _ptr(drel), int(ctx.has_Y), st),
                   "spacap_sa_l1_bwd_f32")
-            dW1 = sum_slabs(pw1)[:, :W1.shape[1]].contiguous()
+            dWx = sum_slabs(pw1)                      # (C1, 4): rel x, y, z, inline feature
             dY = None
-            if ctx.has_Y and ctx.needs_input_grad[4]:
+            if ctx.has_Y:
                 dY = torch.empty(B, Np, C1, **f32)
                 nbytes = int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S))
                 ri = ctx.rows_index
@@ -162,6 +165,17 @@ class _SAMLP(Function):
                     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     check(lib.spacap_sa_rows_scatter_f32(dy1.data_ptr(), idx.data_ptr(), B, Np, N * S, C1, dY.data_ptr(),
                                                          ws.data_ptr(), st), "spacap_sa_rows_scatter_f32")
+            dpm = None
+            if ctx.has_Y:
+                # gradient of Y = pm W1[:, 3:]^T: d pm = dY W1[:, 3:]; the weight part reduces over all B*Np source points
+                pm = ctx.pm
+                Cf = W1.shape[1] - 3
+                g2, x2 = dY.view(-1, C1), pm.reshape(-1, Cf)
+                if ctx.needs_input_grad[4]:
+                    dpm = torch.matmul(g2, W1[:, 3:]).view_as(pm)
+                dW1 = torch.cat([dWx[:, :3], _feature_weight_gradient(g2, x2)], 1)
+            else:
+                dW1 = dWx[:, :W1.shape[1]].contiguous()
             dxyz = dnew = None
             if drel is not None:
                 d3 = drel.view(B, N * S, 3)
@@ -170,7 +184,7 @@ class _SAMLP(Function):
                     dxyz.scatter_add_(1, idx.view(B, N * S, 1).expand(-1, -1, 3).long(), d3)
                 if ctx.needs_input_grad[1]:
                     dnew = -drel.view(B, N, S, 3).sum(2)
-        return (dxyz, dnew, None, None, dY, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
+        return (dxyz, dnew, None, None, dpm, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
 
 
 def supported(mlp_module, nsample):
@@ -183,46 +197,27 @@ def supported(mlp_module, nsample):
     return bool(lib.spacap_sa_mlp_supported(*c)) and 1 <= nsample <= 255
 
 
-class _FeatureProduct(Function):
-    """Y = F W1[:, 3:]^T for the point-major features F (B,Np,Cf) of the source points (the first shared-MLP layer
-    commutes with the gather).  The weight gradient reduces over all B*Np rows into a (C1, Cf) matrix -- the BLAS
-    heuristics run that without a K split (96 us at SA2) -- so it takes the slab kernel of the Linear layers
-    (csrc/sa_mlp.hip: linear_wgrad_kernel, ~15 us) and lands in columns 3.. of a W1-shaped gradient."""
-
-    @staticmethod
-    def forward(ctx, pm, W1):
-        ctx.save_for_backward(pm, W1)
-        return torch.matmul(pm, W1[:, 3:].t())
-
-    @staticmethod
-    def backward(ctx, g):
-        pm, W1 = ctx.saved_tensors
-        C1, Cf = W1.shape[0], W1.shape[1] - 3
-        g2 = g.reshape(-1, C1).contiguous()
-        x2 = pm.reshape(-1, Cf)
-        R = g2.shape[0]
-        dpm = torch.matmul(g2, W1[:, 3:]).view_as(pm) if ctx.needs_input_grad[0] else None
-        dW = torch.zeros_like(W1)
-        nslab = int(lib.spacap_linear_wgrad_slabs(R, C1, Cf)) if x2.is_contiguous() else 0
-        if nslab == 0:
-            # Channel counts without a slab kernel (cfg3: 7, cfg4: 132 input channels).  The reduction runs over every
-            # source point of the batch (320 000 at cfg2 sizes) and the incoming gradient sums to ~0 per channel
-            # (BatchNorm), so one long fp32 accumulation loses digits to cancellation (4e-3 of the result against
-            # float64 at C = 132) and the BLAS heuristics do not split K: 64 row slabs as one batched GEMM + an ordered
-            # sum instead (as relation-head weight gradients, transformer_captioner._TallLinear).
-            S = 64
-            if R % S == 0 and R >= 64 * S:
-                pw = torch.bmm(g2.view(S, R // S, C1).transpose(1, 2), x2.reshape(S, R // S, Cf))
-                dW[:, 3:] = sum_slabs(pw.view(S, C1 * Cf) if (C1 * Cf) % 4 == 0 else pw).view(C1, Cf)
-            else:
-                dW[:, 3:] = g2.t() @ x2
-        else:
-            with torch.cuda.device(g2.device):
-                part = torch.empty(nslab, C1 * Cf, dtype=torch.float32, device=g2.device)
-                check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, C1, Cf, 0, part.data_ptr(),
-                                                  torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-                dW[:, 3:] = sum_slabs(part).view(C1, Cf)
-        return dpm, dW
+def _feature_weight_gradient(g2, x2):
+    """dW_f = g2^T x2 for g2 (R, C1) = the gradient of Y = F W1[:, 3:]^T and x2 (R, Cf) = the point-major source features F.
+    The reduction runs over all R = B*Np source points into a small (C1, Cf) matrix: the BLAS heuristics run that without
+    a K split (96 us at SA2) -> the slab kernel of the Linear layers (csrc/sa_mlp.hip: linear_wgrad_kernel, ~15 us) for
+    multiples of 128 channels, else (cfg3: 7, cfg4: 132 input channels) 64 row slabs as one batched GEMM + an ordered sum
+    -- one long fp32 accumulation of a gradient that sums to ~0 per channel (BatchNorm) would also lose digits."""
+    R, C1 = g2.shape
+    Cf = x2.shape[1]
+    x2 = x2.contiguous()
+    nslab = int(lib.spacap_linear_wgrad_slabs(R, C1, Cf))
+    if nslab:
+        with torch.cuda.device(g2.device):
+            part = torch.empty(nslab, C1 * Cf, dtype=torch.float32, device=g2.device)
+            check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, C1, Cf, 0, part.data_ptr(),
+                                              torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
+        return sum_slabs(part).view(C1, Cf)
+    S = 64
+    if R % S == 0 and R >= 64 * S:
+        pw = torch.bmm(g2.view(S, R // S, C1).transpose(1, 2), x2.view(S, R // S, Cf))
+        return sum_slabs(pw.view(S, C1 * Cf) if (C1 * Cf) % 4 == 0 else pw).view(C1, Cf)
+    return g2.t() @ x2
 
 
 def rows_index(idx, Np):
@@ -245,25 +240,88 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True, ro
     l1, l2, l3 = list(mlp_module.children())
     W1 = l1.conv.weight.view(l1.conv.out_channels, -1)
     Cf = W1.shape[1] - 3
-    feat = Y = None
+    feat = pm = None
     if features is not None:
         assert features.shape[1] == Cf
         if Cf == 1 and not features.requires_grad:
-            feat, W1a = features.reshape(features.shape[0], -1), W1          # inline: no (B,Np,C1) product needed
+            feat = features.reshape(features.shape[0], -1)                   # inline: no (B,Np,C1) product needed
         else:
-            # the first layer commutes with the gather: multiply once per source point
+            # the first layer commutes with the gather: multiply once per source point (inside the op)
             pm = getattr(features, "_point_major", None)   # (B,Np,Cf) form of a previous module's output, if any
-            Y = _FeatureProduct.apply(pm if pm is not None else features.transpose(1, 2), W1)
-            W1a = W1[:, :3]
+            pm = pm if pm is not None else features.transpose(1, 2)
     else:
         assert Cf == 0
-        W1a = W1
     bns = [l.bn.bn for l in (l1, l2, l3)]
-    out = _SAMLP.apply(xyz, new_xyz, idx, feat, Y, W1a, l2.conv.weight.view(l2.conv.out_channels, -1),
+    out = _SAMLP.apply(xyz, new_xyz, idx, feat, pm, W1, l2.conv.weight.view(l2.conv.out_channels, -1),
                        l3.conv.weight.view(l3.conv.out_channels, -1), bns[0].weight, bns[0].bias, bns[1].weight,
                        bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv, rows_idx)
     # (B,C3,N) as a transposed VIEW of the point-major result: the next SA module and the proposal head read the
     # point-major tensor itself (``_point_major``), so no transposed copy is made unless a consumer asks for one
+    res = out.transpose(1, 2)
+    res._point_major = out
+    return res
+
+
+def _running_stats_rows(bn):
+    """stats rows (mean, 1/std, gamma/std, beta) of a BatchNorm layer in inference mode: running statistics."""
+    istd = torch.rsqrt(bn.running_var + bn.eps)
+    return torch.stack([bn.running_mean, istd, bn.weight * istd, bn.bias], 1).contiguous()
+
+
+@torch.no_grad()
+def sa_mlp_eval(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
+    """Inference-mode counterpart of ``sa_mlp_train``: the same fused point-major kernels with the BatchNorm layers
+    folded to their running statistics (what ``model.eval()`` computes per operator: QueryAndGroup -> [Conv2d 1x1 ->
+    BatchNorm2d(running stats) -> ReLU] x 3 -> max_pool2d, lib/pointnet2/pointnet2_modules.py:241-259) -- no grouped
+    (B, C+3, P, S) tensor, no statistics passes.  Returns (B, C3, N) or None when the shape has no fused kernels."""
+    if not use_xyz or not xyz.is_cuda or not supported(mlp_module, idx.shape[2]):
+        return None
+    l1, l2, l3 = list(mlp_module.children())
+    bns = [l.bn.bn for l in (l1, l2, l3)]
+    if any(not b.track_running_stats or b.running_mean is None for b in bns):
+        return None
+    dev = xyz.device
+    B, Np, _ = xyz.shape
+    N, S = idx.shape[1], idx.shape[2]
+    W1 = l1.conv.weight.view(l1.conv.out_channels, -1)
+    W2 = l2.conv.weight.view(l2.conv.out_channels, -1).contiguous()
+    W3 = l3.conv.weight.view(l3.conv.out_channels, -1).contiguous()
+    C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]
+    Cf = W1.shape[1] - 3
+    feat = Y = None
+    if features is not None:
+        assert features.shape[1] == Cf
+        if Cf == 1:
+            feat, W1a = features.reshape(B, -1).contiguous(), W1.contiguous()
+        else:
+            pm = getattr(features, "_point_major", None)
+            Y = torch.matmul(pm if pm is not None else features.transpose(1, 2), W1[:, 3:].t()).contiguous()
+            W1a = W1[:, :3].contiguous()
+    else:
+        W1a = W1.contiguous()
+    R, G = B * N * S, B * N
+    st = torch.cuda.current_stream(dev).cuda_stream
+    f32 = dict(dtype=torch.float32, device=dev)
+    xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+    with torch.cuda.device(dev):
+        part = torch.empty(int(lib.spacap_sa_nparts()) * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)   # (ignored)
+        stats = [_running_stats_rows(b) for b in bns]
+        z1 = torch.empty(R, C1, **f32)
+        check(lib.spacap_sa_l1_fwd_f32(_ptr(Y), _ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), W1a.data_ptr(),
+                                       W1a.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(), part.data_ptr(), st),
+              "spacap_sa_l1_fwd_f32")
+        z2 = torch.empty(R, C2, **f32)
+        check(lib.spacap_sa_mid_fwd_f32(z1.data_ptr(), stats[0].data_ptr(), W2.data_ptr(), R, C1, C2, z2.data_ptr(),
+                                        part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+        del z1
+        z3 = torch.empty(R, C3, **f32)
+        check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3.data_ptr(), R, C2, C3, z3.data_ptr(),
+                                        part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+        del z2
+        out = torch.empty(B, N, C3, **f32)
+        arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
+        check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(), st),
+              "spacap_sa_pool_fwd_f32")
     res = out.transpose(1, 2)
     res._point_major = out
     return res

@@ -82,7 +82,9 @@ def test_two_ranks_match_single_process_full_batch():
 def test_flat_bucket_views_and_zero():
     m = _make_model(0)
     b = FlatGradBucket(m.parameters())
-    assert b.flat.numel() == sum(p.numel() for p in m.parameters())
+    n = sum(p.numel() for p in m.parameters())
+    assert n <= b.flat.numel() <= n + 3 * len(b.params)                  # every tensor starts 16-byte aligned
+    assert all(o % 4 == 0 for o in b.offsets) and all(v.data_ptr() % 16 == 0 for v in b.views)
     m(torch.ones(2, 6)).sum().backward()
     assert float(b.flat.abs().sum()) > 0
     for p in m.parameters():

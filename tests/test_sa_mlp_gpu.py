@@ -171,3 +171,37 @@ def test_unsupported_mlp_uses_the_per_operator_path():
     xyz = S.scene_batch(1, 256, use_height=False, seed=1).to(DEV)
     _, out, _ = sa(xyz, torch.randn(1, 6, 256, device=DEV))
     assert out.shape == (1, 32, 32)
+
+
+@pytest.mark.parametrize("mlp,Cf,Sn", [([1, 64, 64, 128], 1, 64), ([7, 64, 64, 128], 7, 64), ([128, 128, 128, 256], 128, 32),
+                                       ([256, 128, 128, 128], 256, 16)])
+def test_eval_mode_fused_path_folds_the_running_statistics(mlp, Cf, Sn):
+    """model.eval(): the fused kernels with BatchNorm folded to its running statistics (sa_mlp.sa_mlp_eval) against the
+    per-operator inference path (QueryAndGroup -> Conv2d -> BatchNorm2d(running stats) -> ReLU -> max) on the same
+    module, after two training steps have moved the running statistics away from their initial values."""
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(11)
+    sa = PointnetSAModuleVotes(npoint=128, radius=0.5, nsample=Sn, mlp=list(mlp), use_xyz=True, normalize_xyz=True).to(DEV)
+    for layer in sa.mlp_module.children():
+        layer.bn.bn.weight.data.uniform_(0.5, 1.5)
+        layer.bn.bn.bias.data.uniform_(-0.3, 0.3)
+    xyz = S.scene_batch(2, 1500, use_height=False, seed=4).to(DEV)
+    feats = torch.randn(2, Cf, 1500, device=DEV)
+    sa.train()
+    for _ in range(2):
+        sa(xyz, feats + 0.3)
+    sa.eval()
+    hip = backend.ops()
+    with torch.no_grad():
+        _, fused, inds = sa(xyz, feats)
+        assert getattr(fused, "_point_major", None) is not None, "the fused inference path did not run"
+        saved = hip.sa_mlp_eval
+        hip.sa_mlp_eval = None
+        try:
+            _, plain, inds2 = sa(xyz, feats)
+        finally:
+            hip.sa_mlp_eval = saved
+    assert torch.equal(inds, inds2)
+    assert getattr(plain, "_point_major", None) is None
+    err = float((fused - plain).abs().max() / plain.abs().max())
+    assert err < 2e-5, err
