@@ -473,6 +473,21 @@ int spacap_linear_rows_supported(long R, int K, int CO);
 int spacap_linear_rows_f32(const float *a, const float *W, const float *bias, long R, int K, int CO, int trans_w,
                            float *out, spacap_stream_t stream);
 
+/* ---- row-wise L2 normalisation y = x / |x| (models/SpaCapNet.py:66-67, no epsilon); x, y f32 [rows, D], D % 4 == 0;
+ * inv_norm f32 [rows] is kept for the backward dx = (g - y (g . y)) / |x|. */
+int spacap_l2norm_rows_fwd_f32(const float *x, long rows, int D, float *y, float *inv_norm, spacap_stream_t stream);
+int spacap_l2norm_rows_bwd_f32(const float *g, const float *y, const float *inv_norm, long rows, int D, float *dx,
+                               spacap_stream_t stream);
+
+/* ---- caption head loss: log-softmax over the vocabulary (models/transformer_captioner.py:93-99) + compute_cap_loss
+ * (lib/loss_helper.py:199-238).  logits f32 [B*W, V]; target i64 [B, tstride] (word w of scene b at b*tstride + w, 0 = pad:
+ * ignored); good u8 [B].  Outputs: logp f32 [B*W, V] (= data_dict["lang_cap"]), rowstat f32 [B*W, 4] (workspace),
+ * out f32 [4] = (cap_loss, cap_acc, 1 / (sum good + 1e-6), sum good).  Backward: dlogits = gloss[0] * d cap_loss / d logits. */
+int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *target, const uint8_t *good, int B, int W, int V, int tstride,
+                            float *logp, float *rowstat, float *out, spacap_stream_t stream);
+int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target, const uint8_t *good, const float *out, const float *gloss,
+                            int B, int W, int V, int tstride, float *dlogits, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,10 @@ SIGNATURES = {
     "spacap_scene_sample_augment_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_scene_sample_augment_map_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "spacap_scene_gather_rows_f32": (_i, [_p, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "spacap_l2norm_rows_fwd_f32": (_i, [_p, _l, _i, _p, _p, _p]),
+    "spacap_l2norm_rows_bwd_f32": (_i, [_p, _p, _p, _l, _i, _p, _p]),
+    "spacap_cap_loss_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "spacap_cap_loss_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_scene_votes_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "spacap_scene_votes_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_det_npart": (_i, []),

@@ -34,6 +34,8 @@ class HipBackend:
         from . import fused_losses as _fl
         self.detection_losses = _fl.detection_losses
         self.relation_losses = _fl.relation_losses
+        self.caption_head_loss = _fl.caption_head_loss
+        self.l2norm_rows = _fl.l2norm_rows
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout
         self.dropout_add = _fd.dropout_add

@@ -292,3 +292,69 @@ extern "C" int spacap_sum_slabs_f32(const float *part, int nslab, long n, float 
   SPACAP_CHECK_LAUNCH("spacap_sum_slabs_f32");
   return SPACAP_OK;
 }
+
+// ---- row-wise L2 normalisation: y = x / |x|  (models/SpaCapNet.py:66-67: vote features, no epsilon) ---------------------
+// One wavefront per row (D <= 1024 floats, multiple of 4).  Backward: dx = (g - y (g . y)) / |x|.
+// PyTorch: norm + div forward, ~8 launches backward.
+namespace {
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float *__restrict__ x, long rows, int D, float *__restrict__ y,
+                                                         float *__restrict__ inv_norm) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float *xr = x + (size_t)r * D;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+    s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  s = spacap::wave_sum_f32(s);
+  const float nrm = sqrtf(s);
+  for (int c = lane * 4; c < D; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4 *>(xr + c);
+    v[0] /= nrm, v[1] /= nrm, v[2] /= nrm, v[3] /= nrm;      // true division, as torch.div
+    *reinterpret_cast<f32x4 *>(y + (size_t)r * D + c) = v;
+  }
+  if (lane == 0) inv_norm[r] = 1.0f / nrm;
+}
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y,
+                                                         const float *__restrict__ inv_norm, long rows, int D,
+                                                         float *__restrict__ dx) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float *gr = g + (size_t)r * D, *yr = y + (size_t)r * D;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(gr + c), b = *reinterpret_cast<const f32x4 *>(yr + c);
+    s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  }
+  s = spacap::wave_sum_f32(s);
+  const float inv = inv_norm[r];
+  for (int c = lane * 4; c < D; c += 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(gr + c), b = *reinterpret_cast<const f32x4 *>(yr + c);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = (a[u] - b[u] * s) * inv;
+    *reinterpret_cast<f32x4 *>(dx + (size_t)r * D + c) = o;
+  }
+}
+}  // namespace
+
+extern "C" int spacap_l2norm_rows_fwd_f32(const float *x, long rows, int D, float *y, float *inv_norm, spacap_stream_t stream) {
+  SPACAP_REQUIRE(rows >= 0 && D >= 4 && D % 4 == 0 && D <= 4096, "spacap_l2norm_rows_fwd_f32: bad sizes rows=%ld D=%d", rows, D);
+  if (rows == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(x && y && inv_norm, "spacap_l2norm_rows_fwd_f32: null pointer");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, spacap::as_stream(stream), x, rows, D, y, inv_norm);
+  SPACAP_CHECK_LAUNCH("spacap_l2norm_rows_fwd_f32");
+  return SPACAP_OK;
+}
+extern "C" int spacap_l2norm_rows_bwd_f32(const float *g, const float *y, const float *inv_norm, long rows, int D, float *dx,
+                                          spacap_stream_t stream) {
+  SPACAP_REQUIRE(rows >= 0 && D >= 4 && D % 4 == 0 && D <= 4096, "spacap_l2norm_rows_bwd_f32: bad sizes rows=%ld D=%d", rows, D);
+  if (rows == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(g && y && inv_norm && dx, "spacap_l2norm_rows_bwd_f32: null pointer");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, spacap::as_stream(stream), g, y, inv_norm, rows, D, dx);
+  SPACAP_CHECK_LAUNCH("spacap_l2norm_rows_bwd_f32");
+  return SPACAP_OK;
+}

@@ -448,3 +448,112 @@ extern "C" int spacap_det_losses_bwd_f32(const float *dnet_num, const float *dce
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ---- caption head: log-softmax over the vocabulary + masked cross entropy + accuracy ------------------------------------
+// Replaces Generator.forward's F.log_softmax (models/transformer_captioner.py:93-99) and compute_cap_loss
+// (lib/loss_helper.py:199-238: F.cross_entropy(ignore_index=0, reduction="none") on the log-probabilities -- a second,
+// idempotent log-softmax -- masked by good_bbox_masks, summed and divided by (#good words + 1e-6); accuracy = arg-max hits
+// over the non-pad words of good boxes): ~25 PyTorch launches forward + backward -> 2 + 1.
+//   cap_rows_kernel   one workgroup per (scene, word) row of V logits: max, log-sum-exp, writes the log-probabilities
+//                     (data_dict["lang_cap"]), per row (loss term, hit, valid);
+//   cap_final_kernel  fixed-order sums over the rows -> out[0..3] = (cap_loss, cap_acc, 1 / (sum good + 1e-6), -)
+//   cap_bwd_kernel    dlogits[r, v] = w_r (softmax - onehot) with w_r = g * good_r [target_r != 0] / (sum good + 1e-6)
+//                     (+ the gradient that arrives on lang_cap itself, if any, through the log-softmax Jacobian: not used
+//                     by the training loss, so it is not supported here and the Python side refuses it).
+namespace {
+constexpr int CAP_T = 256;
+__global__ __launch_bounds__(CAP_T) void cap_rows_kernel(const float *__restrict__ logits, const int64_t *__restrict__ target,
+                                                        const uint8_t *__restrict__ good, int W, int V, int tstride,
+                                                        float *__restrict__ logp, float *__restrict__ rowstat) {
+  __shared__ float s_f[CAP_T / 64];
+  __shared__ int s_i[CAP_T / 64];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float *x = logits + (size_t)r * V;
+  float m = -INFINITY;
+  int am = 0;
+  for (int v = tid; v < V; v += CAP_T) {
+    const float a = x[v];
+    if (a > m) m = a, am = v;        // first maximum per thread (ascending v)
+  }
+  // block arg-max with the lowest index among equal maxima (torch.argmax returns the first)
+  float wm = spacap::wave_max_f32(m);
+  int cand = (m == wm) ? am : 0x7fffffff;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+  if (lane == 0) s_f[wv] = wm, s_i[wv] = cand;
+  __syncthreads();
+  float M = s_f[0];
+  for (int i = 1; i < CAP_T / 64; ++i) M = fmaxf(M, s_f[i]);
+  int AM = 0x7fffffff;
+  for (int i = 0; i < CAP_T / 64; ++i)
+    if (s_f[i] == M) AM = min(AM, s_i[i]);
+  __syncthreads();
+  float s = 0.f;
+  for (int v = tid; v < V; v += CAP_T) s += expf(x[v] - M);
+  s = spacap::wave_sum_f32(s);
+  if (lane == 0) s_f[wv] = s;
+  __syncthreads();
+  float S = 0.f;
+  for (int i = 0; i < CAP_T / 64; ++i) S += s_f[i];
+  const float lse = M + logf(S);
+  for (int v = tid; v < V; v += CAP_T) logp[(size_t)r * V + v] = x[v] - lse;
+  if (tid == 0) {
+    const int b = r / W, wd = r % W;
+    const int64_t t = target[(size_t)b * tstride + wd];
+    const float gd = good[b] ? 1.f : 0.f;
+    const float lt = (t != 0) ? -(x[t] - lse) : 0.f;              // ignore_index = 0
+    rowstat[r * 4 + 0] = lt * gd;
+    rowstat[r * 4 + 1] = gd;
+    rowstat[r * 4 + 2] = (AM == (int)t) ? ((t != 0) ? gd : 0.f) : 0.f;   // hit * valid
+    rowstat[r * 4 + 3] = (t != 0) ? gd : 0.f;                          // valid
+  }
+}
+__global__ __launch_bounds__(64) void cap_final_kernel(const float *__restrict__ rowstat, int rows, float *__restrict__ out) {
+  if (threadIdx.x != 0) return;
+  float a = 0.f, g = 0.f, h = 0.f, v = 0.f;
+  for (int r = 0; r < rows; ++r) a += rowstat[r * 4], g += rowstat[r * 4 + 1], h += rowstat[r * 4 + 2], v += rowstat[r * 4 + 3];
+  const float inv = 1.0f / (g + 1e-6f);
+  out[0] = a * inv;
+  out[1] = h / fmaxf(v, 1.0f);
+  out[2] = inv;
+  out[3] = g;
+}
+__global__ __launch_bounds__(CAP_T) void cap_bwd_kernel(const float *__restrict__ logp, const int64_t *__restrict__ target,
+                                                       const uint8_t *__restrict__ good, const float *__restrict__ out,
+                                                       const float *__restrict__ gloss, int W, int V, int tstride,
+                                                       float *__restrict__ dlogits) {
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int b = r / W, wd = r % W;
+  const int64_t t = target[(size_t)b * tstride + wd];
+  const float w = (good[b] && t != 0) ? gloss[0] * out[2] : 0.f;
+  for (int v = tid; v < V; v += CAP_T) {
+    const float p = expf(logp[(size_t)r * V + v]);
+    dlogits[(size_t)r * V + v] = w * (p - (v == (int)t ? 1.f : 0.f));
+  }
+}
+}  // namespace
+
+extern "C" int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *target, const uint8_t *good, int B, int W, int V,
+                                       int tstride, float *logp, float *rowstat, float *out, spacap_stream_t stream) {
+  const char *what = "spacap_cap_loss_fwd_f32";
+  SPACAP_REQUIRE(B >= 0 && W >= 1 && V >= 2 && tstride >= W, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(logits && target && good && logp && rowstat && out, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  hipLaunchKernelGGL(cap_rows_kernel, dim3(B * W), dim3(CAP_T), 0, s, logits, target, good, W, V, tstride, logp, rowstat);
+  hipLaunchKernelGGL(cap_final_kernel, dim3(1), dim3(64), 0, s, rowstat, B * W, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+extern "C" int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target, const uint8_t *good, const float *out,
+                                       const float *gloss, int B, int W, int V, int tstride, float *dlogits,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_cap_loss_bwd_f32";
+  SPACAP_REQUIRE(B >= 0 && W >= 1 && V >= 2 && tstride >= W, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(logp && target && good && out && gloss && dlogits, "%s: null pointer", what);
+  hipLaunchKernelGGL(cap_bwd_kernel, dim3(B * W), dim3(CAP_T), 0, spacap::as_stream(stream), logp, target, good, out, gloss, W, V,
+                     tstride, dlogits);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

@@ -122,3 +122,85 @@ def relation_losses(d):
     out = RelationLoss.apply(d["relation_pred"], d["object_assignment"], d["box_label_mask_int"], d["objectness_label"],
                              d["x_label"], d["y_label"], d["z_label"])
     return {"x_loss": out[0], "y_loss": out[1], "z_loss": out[2], "x_acc": out[3], "y_acc": out[4], "z_acc": out[5]}
+
+
+class CaptionHeadLoss(Function):
+    """logits (B, W, V) -> (log-probabilities (B, W, V), out (4,) = (cap_loss, cap_acc, 1 / (sum good + 1e-6), sum good)):
+    ``Generator``'s log-softmax (models/transformer_captioner.py:93-99) and ``compute_cap_loss`` (lib/loss_helper.py:199-238)
+    as two launches forward and one backward (csrc/losses.hip).  The log-probabilities are returned for ``data_dict
+    ["lang_cap"]`` and are not differentiable here (the training loss reaches the logits through ``out[0]`` only)."""
+
+    @staticmethod
+    def forward(ctx, logits, lang_ids, good):
+        if not logits.is_cuda:
+            raise RuntimeError("CPU not supported")
+        logits = logits.contiguous()
+        B, W, V = logits.shape
+        ids = lang_ids.contiguous()
+        assert ids.dtype == torch.int64 and ids.shape[0] == B and ids.shape[1] >= W + 1
+        g8 = good.to(torch.uint8).contiguous()
+        dev = logits.device
+        with torch.cuda.device(dev):
+            logp = torch.empty_like(logits)
+            rowstat = torch.empty(B * W, 4, dtype=torch.float32, device=dev)
+            out = torch.empty(4, dtype=torch.float32, device=dev)
+            # targets = lang_ids[:, 1 : W + 1]: same rows, starting one word later
+            check(lib.spacap_cap_loss_fwd_f32(logits.data_ptr(), ids.data_ptr() + 8, g8.data_ptr(), B, W, V, ids.shape[1],
+                                              logp.data_ptr(), rowstat.data_ptr(), out.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "spacap_cap_loss_fwd_f32")
+        ctx.save_for_backward(logp, ids, g8, out)
+        ctx.mark_non_differentiable(logp)
+        return logp, out
+
+    @staticmethod
+    def backward(ctx, _g_logp, g_out):
+        logp, ids, g8, out = ctx.saved_tensors
+        B, W, V = logp.shape
+        dev = logp.device
+        gl = g_out[0:1].contiguous()
+        with torch.cuda.device(dev):
+            dlogits = torch.empty_like(logp)
+            check(lib.spacap_cap_loss_bwd_f32(logp.data_ptr(), ids.data_ptr() + 8, g8.data_ptr(), out.data_ptr(), gl.data_ptr(),
+                                              B, W, V, ids.shape[1], dlogits.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "spacap_cap_loss_bwd_f32")
+        return dlogits, None, None
+
+
+def caption_head_loss(logits, lang_ids, good):
+    """(lang_cap log-probabilities, cap_loss, cap_acc) -- see CaptionHeadLoss."""
+    logp, out = CaptionHeadLoss.apply(logits, lang_ids, good)
+    return logp, out[0], out[1]
+
+
+class L2NormRows(Function):
+    """y = x / |x|_2 over the last dimension (models/SpaCapNet.py:66-67: the vote features, no epsilon)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        if not x.is_cuda:
+            raise RuntimeError("CPU not supported")
+        x = x.contiguous()
+        D = x.shape[-1]
+        rows = x.numel() // D
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+            check(lib.spacap_l2norm_rows_fwd_f32(x.data_ptr(), rows, D, y.data_ptr(), inv.data_ptr(),
+                                                 torch.cuda.current_stream(x.device).cuda_stream), "spacap_l2norm_rows_fwd_f32")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, inv = ctx.saved_tensors
+        g = g.contiguous()
+        D = y.shape[-1]
+        with torch.cuda.device(y.device):
+            dx = torch.empty_like(y)
+            check(lib.spacap_l2norm_rows_bwd_f32(g.data_ptr(), y.data_ptr(), inv.data_ptr(), y.numel() // D, D, dx.data_ptr(),
+                                                 torch.cuda.current_stream(y.device).cuda_stream), "spacap_l2norm_rows_bwd_f32")
+        return dx
+
+
+def l2norm_rows(x):
+    return L2NormRows.apply(x)

@@ -218,7 +218,8 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     if box_loss is None and not fast:   # the fused detection-loss op leaves the box sum to this function
         box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
     if caption:
-        d["cap_loss"], d["cap_acc"] = compute_cap_loss(d)
+        pair = d.pop("_cap_loss", None)   # computed with the vocabulary log-softmax by the fused caption head (HIP backend)
+        d["cap_loss"], d["cap_acc"] = pair if pair is not None else compute_cap_loss(d)
     else:
         d["cap_loss"], d["cap_acc"], d["pred_ious"] = zero, zero, zero
     streams.join("detection_loss", d["seed_xyz"])

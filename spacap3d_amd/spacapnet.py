@@ -45,7 +45,9 @@ class SpaCapNet(nn.Module):
         xyz, features = self.vgen(xyz, features)
         pm = getattr(features, "_point_major", None)
         if pm is not None:   # same L2 normalisation over the channels, on the point-major tensor
-            pm = pm.div(torch.norm(pm, p=2, dim=2).unsqueeze(2))
+            from .backend import ops
+            f = getattr(ops(), "l2norm_rows", None) if (pm.is_cuda and pm.shape[-1] % 4 == 0) else None
+            pm = f(pm) if f is not None else pm.div(torch.norm(pm, p=2, dim=2).unsqueeze(2))
             features = pm.transpose(1, 2)
             features._point_major = pm
         else:

@@ -474,8 +474,15 @@ class TransformerDecoderModel(nn.Module):
                          obj_indicator=ref_obj_feature, src_pos=src_pos,
                          obj_idx=idx if self.use_transformer_encoder else None, memory=memory)
         out = out[:, 1:, :] if self.early_guide else out
-        ep["lang_cap"] = self.model.generator(out)
         good = (target_ious > -1).squeeze(1)
+        fused = getattr(ops(), "caption_head_loss", None) if (out.is_cuda and self.training and "lang_ids" in ep) else None
+        if fused is not None and ep["lang_ids"].shape[1] >= out.shape[1] + 1:
+            # vocabulary projection, then log-softmax + the caption loss / accuracy in one op (fused_losses.CaptionHeadLoss);
+            # loss_helper.get_scene_cap_loss picks the pair up instead of recomputing it from the log-probabilities
+            ep["lang_cap"], cl, ca = fused(self.model.generator.proj(out), ep["lang_ids"], good)
+            ep["_cap_loss"] = (cl, ca)
+        else:
+            ep["lang_cap"] = self.model.generator(out)
         # mean over the good boxes without a host sync (the reference branches on .sum() > 0, :385)
         n_good = good.sum()
         ep["pred_ious"] = (target_ious.squeeze(1) * good).sum() / n_good.clamp(min=1)
