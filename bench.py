@@ -126,22 +126,27 @@ def _cpu_ops(ext, B, N, m=2048, radius=0.2, nsample=64):
             "ball_query_s": t_bq}
 
 
-def cpu_baseline(cfg, omp_batch, steps):
+def cpu_baseline(cfg, omp_batch, steps, threads=8):
     """the same training step on the host CPU, this repo's host code on device "cpu" with the C oracle
     ops + torch CPU (kind "port"), (i) single thread, canonical oracle; (ii) OpenMP oracle + all torch threads."""
     from oracle.attention_ref import OracleBackend
     omp = OracleBackend(openmp=True)
-    cores = omp._ext.num_threads()
+    # torch's CPU kernels stop scaling early on this model (measured on the MI355X box's 128-thread host, B = 2:
+    # 8 threads 1.52 scenes/s, 16: 1.44, 32: 1.24, 64: 0.68, 128: 0.34, 1: 0.74; tools/lab/cpu_threads.py): the multi-core
+    # variant uses the best count, not every hardware thread
+    cores = min(omp._ext.num_threads(), threads)
     t_omp = _cpu_steps(cfg, omp, cores, omp_batch, steps)
     t_one = _cpu_steps(cfg, OracleBackend(openmp=False), 1, 1, steps)
     ops_one = _cpu_ops(OracleBackend(openmp=False)._ext, 2, cfg["n_points"])
     ops_omp = _cpu_ops(omp._ext, 8, cfg["n_points"])
-    torch.set_num_threads(cores)
+    host_threads = omp._ext.num_threads()
+    torch.set_num_threads(host_threads)
     mean = lambda v: sum(v) / len(v)
     return {"value": omp_batch / mean(t_omp), "unit": "scenes/s", "cores": cores, "kind": "port",
             "sample": f"OpenMP variant: 1 warm-up + {steps} timed full training steps on B = {omp_batch} synthetic scenes of "
                       f"{cfg['n_points']} points ({', '.join(f'{t:.1f}' for t in t_omp)} s): this repo's host code on device cpu + "
-                      f"the C oracle ops (OpenMP over scene / centre) + torch CPU with {cores} threads",
+                      f"the C oracle ops (OpenMP over scene / centre) + torch CPU with {cores} threads (the fastest count on this "
+                      f"host of {host_threads} hardware threads)",
             "single_thread": {"value": 1 / mean(t_one), "unit": "scenes/s", "cores": 1,
                               "sample": f"canonical single-thread oracle + torch with 1 thread: 1 warm-up + {steps} timed steps on "
                                         f"B = 1 ({', '.join(f'{t:.1f}' for t in t_one)} s)"},
@@ -178,7 +183,8 @@ def main():
     ap.add_argument("--streams", action="store_true", help="run the detection losses as a side-stream branch (slower since they are fused)")
     ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
                                                  "relation head, 'caption' the whole captioner")
-    ap.add_argument("--cpu-sample", type=int, default=2, help="scenes per step in the OpenMP CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=4, help="scenes per step in the multi-core CPU-baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads of the multi-core CPU baseline (8 is the fastest on the box's host)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up at size)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the extra unpipelined (drop-in caller) measurement")
     args = ap.parse_args()
@@ -326,7 +332,7 @@ def main():
         if args.ablate:
             line["metric"] += f" [ABLATION {args.ablate}: not the headline metric]"
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, args.cpu_steps)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, args.cpu_steps, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()
