@@ -174,7 +174,7 @@ struct TailArgs {
 //   1 = no MFMA (loads, staging, epilogue, stores only)   2 = no global stores   3 = no global loads after the first tile
 //   4 = MFMA B operand from registers (INVALID: the compiler merges the then identical accumulators)
 //   5 = MFMA loop + LDS operand reads only (no global traffic, no staging, no barriers, no epilogue)
-template <int CIN, int NT, bool TAIL = false, int LAB = 0>
+template <int CIN, int NT, bool TAIL = false, int LAB = 0, int TMT = 64>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
                                                          float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
@@ -183,11 +183,11 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
   // a lane are 4 consecutive words, lg 0/1 (and 2/3) interleave in 4-word chunks, lg 0,1 own the first half of the
   // row and lg 2,3 the second (ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...:
   // each holds all 16 rows with lg in {0,1} or {2,3}, and 8*row + 4*(lg&1) tiles the 64 banks exactly once).
-  constexpr int LD = CIN + 8, KS = CIN / 4, KQ = KS / 4, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
-  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
+  constexpr int LD = CIN + 8, KS = CIN / 4, KQ = KS / 4, C4 = CIN / 4, NV = TMT * C4 / 256, RSTEP = 256 / C4;
+  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TMT * O4 / 256, OSTEP = 256 / O4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *s_a = smem;             // [TM][LD]   activations (MFMA B operand)
-  float *s_o = smem + TM * LD;   // [TM][LDO]  output tile, row-major
+  float *s_a = smem;             // [TMT][LD]   activations (MFMA B operand)
+  float *s_o = smem + TMT * LD;   // [TMT][LDO]  output tile, row-major
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int cbb = blockIdx.y * COB, wc = w * 16 * NT, cb = cbb + wc;
   float wf[NT][KS];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
   f32x4 ssum[NT], ssq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) ssum[j] = ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const long ntiles = (R + TM - 1) / TM;
+  const long ntiles = (R + TMT - 1) / TMT;
   f32x4 pre[NV];
   // Prefetch with hand-issued loads: the compiler's wait-count insertion would drain the previous tile's stores
   // too (vmcnt is one in-order counter for loads and stores on gfx9); here the wait before staging is
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
   auto fetch = [&](long t) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      long grow = t * TM + r0 + i * RSTEP;
+      long grow = t * TMT + r0 + i * RSTEP;
       grow = grow < R ? grow : R - 1;
       const float *src = zin + (size_t)grow * CIN + c4 * 4;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
@@ -240,10 +240,10 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));  // uses of pre[] stay below the wait
   };
-  // one tile; FULL = all TM rows exist (no bounds checks: the stores are then straight-line code too)
+  // one tile; FULL = all TMT rows exist (no bounds checks: the stores are then straight-line code too)
   auto tile = [&](long t, auto full, bool stores_pending) {
     constexpr bool FULL = decltype(full)::value;
-    const long row0 = t * TM;
+    const long row0 = t * TMT;
     if (LAB != 5) {
       wait_prefetch(stores_pending);
 #pragma unroll
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       __syncthreads();
       if (FULL && LAB != 3) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
     }
-    f32x4 acc[TM / 16][NT];
+    f32x4 acc[TMT / 16][NT];
 #pragma unroll
-    for (int mt = 0; mt < TM / 16; ++mt)
+    for (int mt = 0; mt < TMT / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (LAB != 1) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       // reads of chunk c + 2 are issued right after the MFMAs of chunk c, i.e. one chunk of MFMA time (16 * NT
       // instructions) before their first use.  sched_barriers pin that order (the scheduler otherwise sinks every
       // read to just before its use, exposing the LDS latency once per chunk).
-      constexpr int KH = KQ / 2 > 0 ? KQ / 2 : 1, NCH = (TM / 16) * (KQ / KH);
+      constexpr int KH = KQ / 2 > 0 ? KQ / 2 : 1, NCH = (TMT / 16) * (KQ / KH);
       const float *bsrc = s_a + l15 * LD + (lg >> 1) * (CIN / 2) + (lg & 1) * 4;
       f32x4 bq[2][KH];
       auto bload = [&](int c) {
@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     }
     if (LAB == 5) {   // MFMA + LDS operand reads only: keep the accumulators alive, skip the epilogue
 #pragma unroll
-      for (int mt = 0; mt < TM / 16; ++mt)
+      for (int mt = 0; mt < TMT / 16; ++mt)
 #pragma unroll
         for (int j = 0; j < NT; ++j) ssum[j] += acc[mt][j];
       return;
     }
 #pragma unroll
-    for (int mt = 0; mt < TM / 16; ++mt)
+    for (int mt = 0; mt < TMT / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (TAIL) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       }
     }
   };
-  const long nfull = R / TM;
+  const long nfull = R / TMT;
   bool pending = false;
   if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
   for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
@@ -1423,11 +1423,18 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   const int nt = (Cin == 64 && Cout == 64) ? 1 : 2;
   static const int lab = getenv("SPACAP_SA_LAB") ? atoi(getenv("SPACAP_SA_LAB")) : 0;   // timing experiments (tools/lab)
   static const bool m16 = getenv("SPACAP_SA_MFMA32") == nullptr;   // default: 16x16x4 form; SPACAP_SA_MFMA32=1: the 32x32x2 variant
+  static const bool tm32 = getenv("SPACAP_SA_TM32") != nullptr;    // 32-row tiles (lab: more resident workgroups)
   const size_t lds = (size_t)TM * ((Cin + (m16 ? 8 : 4)) + (64 * nt + 4)) * sizeof(float);
   const long tiles = (R + TM - 1) / TM;
 #define MFL(CI, NTV, GY, LABV)                                                                                       \
   {                                                                                                                  \
-    if (m16) {                                                                                                       \
+    if (m16 && tm32) {                                                                                               \
+      const size_t lds32 = (size_t)32 * ((CI + 8) + (64 * NTV + 4)) * sizeof(float);                                 \
+      const long tiles32 = (R + 31) / 32;                                                                            \
+      static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>, lds32);                    \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(res, GY, tiles32), GY),       \
+                         dim3(256), lds32, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                       \
+    } else if (m16) {                                                                                                \
       static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV>, lds);                          \
       hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256),  \
                          lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                                    \
