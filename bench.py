@@ -134,12 +134,15 @@ def cpu_baseline(cfg, omp_batch, steps, threads=8):
     # torch's CPU kernels stop scaling early on this model (measured on the MI355X box's 128-thread host, B = 2:
     # 8 threads 1.52 scenes/s, 16: 1.44, 32: 1.24, 64: 0.68, 128: 0.34, 1: 0.74; tools/lab/cpu_threads.py): the multi-core
     # variant uses the best count, not every hardware thread
-    cores = min(omp._ext.num_threads(), threads)
+    host_threads = os.cpu_count() or 1
+    cores = min(host_threads, threads)
     t_omp = _cpu_steps(cfg, omp, cores, omp_batch, steps)
+    # (torch.set_num_threads also sets the OpenMP thread count the oracle's OpenMP build runs with)
+    torch.set_num_threads(min(host_threads, 8))
+    ops_omp = _cpu_ops(omp._ext, 8, cfg["n_points"])          # parallel over the 8 scenes / the centres
+    ops_omp["threads"] = min(host_threads, 8)
     t_one = _cpu_steps(cfg, OracleBackend(openmp=False), 1, 1, steps)
     ops_one = _cpu_ops(OracleBackend(openmp=False)._ext, 2, cfg["n_points"])
-    ops_omp = _cpu_ops(omp._ext, 8, cfg["n_points"])
-    host_threads = omp._ext.num_threads()
     torch.set_num_threads(host_threads)
     mean = lambda v: sum(v) / len(v)
     return {"value": omp_batch / mean(t_omp), "unit": "scenes/s", "cores": cores, "kind": "port",
