@@ -766,6 +766,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
 }
 
+#include "sa_bf3.inc"
+#include "sa_stream.inc"
+
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
 __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ st,
                                                           long G, int S, int C, float *__restrict__ out,
@@ -1449,7 +1452,51 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
     if (lab == 1) MFL(CI, NTV, GY, 1) else if (lab == 2) MFL(CI, NTV, GY, 2) else if (lab == 3) MFL(CI, NTV, GY, 3)  \
     else if (lab == 4) MFL(CI, NTV, GY, 4) else if (lab == 5) MFL(CI, NTV, GY, 5) else MFL(CI, NTV, GY, 0)           \
   }
-  static const bool bf3 = getenv("SPACAP_SA_BF16X3") != nullptr;   // split-bf16 matrix-core path (see sa_mid_fwd_bf3_kernel)
+  static const bool streaming = getenv("SPACAP_SA_STREAM") != nullptr;   // the wave-streaming fp32 kernel (sa_stream.inc)
+  if (streaming && ((Cin == 64 && Cout == 64) || ((Cin == 64 || Cin == 128) && Cout % 128 == 0))) {
+    static const int cus = resident_blocks(sa_mid_fwd_s_kernel<128, 4>, 100 * 1024);   // = CUs: one workgroup per CU
+    const int cob = Cout == 64 ? 64 : 128, gy = Cout / cob;
+    const size_t ldss = sa_stream_lds_bytes(Cin, cob);
+    const long wtiles = (R + 31) / 32;
+    long gx = cus / gy;
+    gx = gx > NPART ? NPART : gx;
+    gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+#define MS(CI, NCQV, LABV)                                                                                            \
+  hipLaunchKernelGGL((sa_mid_fwd_s_kernel<CI, NCQV, LABV>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, \
+                     R, zout, part)
+    if (lab == 1) { if (Cin == 64 && cob == 64) MS(64, 2, 1); else if (Cin == 64) MS(64, 4, 1); else MS(128, 4, 1); }
+    else if (lab == 2) { if (Cin == 64 && cob == 64) MS(64, 2, 2); else if (Cin == 64) MS(64, 4, 2); else MS(128, 4, 2); }
+    else { if (Cin == 64 && cob == 64) MS(64, 2, 0); else if (Cin == 64) MS(64, 4, 0); else MS(128, 4, 0); }
+#undef MS
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
+  }
+  // default: the streaming split-bf16 kernel (fp32-equivalent products); SPACAP_SA_BF16X3=0 selects the
+  // fp32-MFMA kernels, =1 the first split-bf16 kernel (activations staged through LDS)
+  static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
+  static const bool bf3 = bf3v != 0;   // split-bf16 matrix-core path (1: sa_mid_fwd_bf3_kernel, 2: the streaming kernel)
+  if (bf3v == 2 && (Cin == 64 || Cin == 128) && Cout % 128 == 0) {
+    static const int ksplit = getenv("SPACAP_SA_INTER") ? atoi(getenv("SPACAP_SA_INTER")) : 1;
+    static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
+    const size_t ldss = bf3s_lds_bytes(Cin);
+    const long wtiles = (R + 31) / 32;
+    const int gy = Cout / 128;
+    long gx = cus / gy;
+    gx = gx > NPART ? NPART : gx;
+    gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+#define MS(CI, KSP, LABV)                                                                                             \
+  hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<CI, KSP, LABV>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, R, \
+                     zout, part)
+    if (lab == 1) { if (Cin == 64) MS(64, 1, 1); else MS(128, 1, 1); }
+    else if (lab == 2) { if (Cin == 64) MS(64, 1, 2); else MS(128, 1, 2); }
+    else if (lab == 9 && ksplit == 2) { if (Cin == 64) MS(64, 2, 9); else MS(128, 2, 9); }
+    else if (lab == 9) { if (Cin == 64) MS(64, 1, 9); else MS(128, 1, 9); }
+    else if (Cin == 64) { if (ksplit == 2) MS(64, 2, 0); else MS(64, 1, 0); }
+    else { if (ksplit == 2) MS(128, 2, 0); else MS(128, 1, 0); }
+#undef MS
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
+  }
   if (bf3 && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && lab != 1 && lab != 4 && lab != 5) {
     const size_t lds3 = (size_t)3 * TM * (Cin + 8) * sizeof(__bf16);
 #define MB(CI, LABV)                                                                                                 \
@@ -1473,6 +1520,12 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
 #undef MFL
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
+}
+
+// lab only: the cycle stamps written by the LAB == 9 build of the streaming kernel ([4 workgroups][8 waves][32 phases][5])
+extern "C" int spacap_lab_bf3s_trace(unsigned long long *out_host, unsigned long long *io_host) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bf3s_dbg), sizeof(bf3s_dbg)) != hipSuccess) return SPACAP_E_LAUNCH;
+  return hipMemcpyFromSymbol(io_host, HIP_SYMBOL(bf3s_dbg_io), sizeof(bf3s_dbg_io)) == hipSuccess ? SPACAP_OK : SPACAP_E_LAUNCH;
 }
 
 extern "C" int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out,
