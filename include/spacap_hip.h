@@ -275,6 +275,17 @@ int spacap_sa_bn_finalize_f32(const double *part, int C, long count, float eps, 
 /* zout = relu(bn(zin)) W^T, W f32 [Cout, Cin]; part receives the sums of zout. */
 int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const float *W, long R, int Cin, int Cout,
                           float *zout, double *part, spacap_stream_t stream);
+/* The same layer when its output is max-pooled over groups of S consecutive rows (the LAST layer of an SA module's shared
+   MLP, pointnet2_modules.py:258-259): additionally leaves, per sub-group of min(S,32) rows and channel, the two best
+   pooling candidates (cand_v f32, cand_i u8: [R / min(S,32)][Cout][2]); spacap_sa_pool_finalize_f32 turns them into
+   (out, arg) once this layer's batch statistics are final, so that the pooling pass never reads z_out.
+   gamma_out = BatchNorm weight of this layer's output.  _supported: 1 when there is a kernel for (Cin, Cout, S). */
+int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S);
+int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, const float *W, const float *gamma_out, long R,
+                               int Cin, int Cout, int S, float *zout, double *part, float *cand_v, uint8_t *cand_i,
+                               spacap_stream_t stream);
+int spacap_sa_pool_finalize_f32(const float *cand_v, const uint8_t *cand_i, const float *stats, const float *gamma, long G,
+                                int S, int C, float *out, uint8_t *arg, spacap_stream_t stream);
 /* out[g,c] = max_s relu(bn(z[g*S+s,c])) (first maximum), arg u8 [G,C]. */
 int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out, uint8_t *arg,
                            spacap_stream_t stream);

@@ -1522,10 +1522,108 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   return SPACAP_OK;
 }
 
+// ---- pooling from the candidates the streaming layer kernel left (PoolArgs in sa_bf3.inc) -----------------------------
+// per (group, channel): merge the sub-groups' candidate lists (S = 64: two halves, the second with indices + 32), evaluate the
+// activation of the best and of the runner-up, and keep the reference's first maximum:
+//   equal activations -> smaller row index;  activation 0 (or a constant channel) -> row 0, as a strict ">" scan from -1 does.
+__global__ __launch_bounds__(256) void sa_pool_finalize_kernel(const float *__restrict__ cand_v, const uint8_t *__restrict__ cand_i,
+                                                               const float *__restrict__ st, const float *__restrict__ gamma,
+                                                               long G, int S, int C, float *__restrict__ out,
+                                                               uint8_t *__restrict__ arg) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= G * C) return;
+  const long g = i / C;
+  const int c = (int)(i % C);
+  const int nsub = S > 32 ? S / 32 : 1;
+  size_t o = ((size_t)(g * nsub) * C + c) * 2;
+  float t1 = cand_v[o], t2 = cand_v[o + 1];
+  int i1 = cand_i[o], i2 = cand_i[o + 1];
+  for (int h = 1; h < nsub; ++h) {   // later sub-groups: all their indices are larger, ties go to what we have
+    o = ((size_t)(g * nsub + h) * C + c) * 2;
+    const float u1 = cand_v[o], u2 = cand_v[o + 1];
+    const int j1 = cand_i[o] + 32 * h, j2 = cand_i[o + 1] + 32 * h;
+    const bool mine = !(u1 > t1);
+    const float w1 = mine ? t1 : u1, l1 = mine ? u1 : t1;
+    const int wi = mine ? i1 : j1, li = mine ? j1 : i1;
+    float c2 = l1 < w1 ? l1 : -INFINITY;
+    int ci = li;
+    if (t2 > c2 || (t2 == c2 && i2 < ci)) c2 = t2, ci = i2;
+    if (u2 > c2 || (u2 == c2 && j2 < ci)) c2 = u2, ci = j2;
+    t1 = w1, i1 = wi, t2 = c2, i2 = ci;
+  }
+  const float *s = st + (size_t)c * 4;
+  const float mean = s[0], sc = s[2], be = s[3], sg = gamma[c] >= 0.f ? 1.f : -1.f;
+  const float v1 = fmaxf((sg * t1 - mean) * sc + be, 0.f);
+  int a = i1;
+  if (t2 > -INFINITY) {
+    const float v2 = fmaxf((sg * t2 - mean) * sc + be, 0.f);
+    if (v2 == v1 && i2 < i1) a = i2;
+  }
+  if (!(v1 > 0.f) || sc == 0.f) a = 0;
+  out[i] = v1;
+  arg[i] = (uint8_t)a;
+}
+
 // lab only: the cycle stamps written by the LAB == 9 build of the streaming kernel ([4 workgroups][8 waves][32 phases][5])
 extern "C" int spacap_lab_bf3s_trace(unsigned long long *out_host, unsigned long long *io_host) {
   if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bf3s_dbg), sizeof(bf3s_dbg)) != hipSuccess) return SPACAP_E_LAUNCH;
   return hipMemcpyFromSymbol(io_host, HIP_SYMBOL(bf3s_dbg_io), sizeof(bf3s_dbg_io)) == hipSuccess ? SPACAP_OK : SPACAP_E_LAUNCH;
+}
+
+/* 1 when spacap_sa_mid_fwd_pool_f32 has a kernel for this layer (the streaming split-bf16 kernel is the active one). */
+extern "C" int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S) {
+  static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
+  static const bool off = getenv("SPACAP_SA_LAB") != nullptr || getenv("SPACAP_SA_STREAM") != nullptr ||
+                          getenv("SPACAP_SA_NO_POOL_FUSION") != nullptr;
+  return bf3v == 2 && !off && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && (S == 16 || S == 32 || S == 64);
+}
+
+/* spacap_sa_mid_fwd_f32 for the LAST layer of a shared MLP whose output is max-pooled over groups of S consecutive rows:
+   also leaves the pooling candidates (cand_v f32 / cand_i u8, [R / min(S,32)][Cout][2]) for spacap_sa_pool_finalize_f32.
+   gamma_out: BatchNorm weight of this layer's output (its sign orders the activations). */
+extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, const float *W, const float *gamma_out, long R,
+                                          int Cin, int Cout, int S, float *zout, double *part, float *cand_v,
+                                          uint8_t *cand_i, spacap_stream_t stream) {
+  const char *what = "spacap_sa_mid_fwd_pool_f32";
+  SPACAP_REQUIRE(zin && st_in && W && gamma_out && zout && part && cand_v && cand_i && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(spacap_sa_mid_fwd_pool_supported(Cin, Cout, S) && R % S == 0, "%s: (Cin=%d, Cout=%d, S=%d) unsupported", what,
+                 Cin, Cout, S);
+  hipStream_t s = spacap::as_stream(stream);
+  static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
+  const size_t ldss = bf3s_lds_bytes(Cin);
+  const long wtiles = (R + 31) / 32;
+  const int gy = Cout / 128;
+  long gx = cus / gy;
+  gx = gx > NPART ? NPART : gx;
+  gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+  const PoolArgs pa{gamma_out, S, cand_v, cand_i};
+  static const int plab = getenv("SPACAP_POOL_LAB") ? atoi(getenv("SPACAP_POOL_LAB")) : 0;
+  if (plab == 11 && Cin == 64)
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 11, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+                       R, zout, part, pa);
+  else if (plab == 12 && Cin == 64)
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 12, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+                       R, zout, part, pa);
+  else if (Cin == 64)
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 0, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+                       R, zout, part, pa);
+  else
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, 0, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+                       R, zout, part, pa);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* out[g,c] = max_s relu(bn(z[g*S+s,c])) (first maximum) and its arg, from the candidates of spacap_sa_mid_fwd_pool_f32. */
+extern "C" int spacap_sa_pool_finalize_f32(const float *cand_v, const uint8_t *cand_i, const float *stats, const float *gamma,
+                                           long G, int S, int C, float *out, uint8_t *arg, spacap_stream_t stream) {
+  const char *what = "spacap_sa_pool_finalize_f32";
+  SPACAP_REQUIRE(cand_v && cand_i && stats && gamma && out && arg && G >= 1 && C >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(S == 16 || S == 32 || S == 64, "%s: S=%d unsupported", what, S);
+  hipLaunchKernelGGL(sa_pool_finalize_kernel, dim3(nblocks(G * C, 256)), dim3(256), 0, spacap::as_stream(stream), cand_v, cand_i,
+                     stats, gamma, G, S, C, out, arg);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
 }
 
 extern "C" int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out,

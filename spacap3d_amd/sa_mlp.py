@@ -64,13 +64,45 @@ class _SAMLP(Function):
             check(lib.spacap_sa_mid_fwd_f32(z1.data_ptr(), stats[0].data_ptr(), W2c.data_ptr(), R, C1, C2, z2.data_ptr(),
                                             part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
             finalize(1, C2, g2, b2)
-            check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), R, C2, C3, z3.data_ptr(),
-                                            part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
-            finalize(2, C3, g3, b3)
             out = torch.empty(B, N, C3, **f32)
             arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
-            check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
-                                             st), "spacap_sa_pool_fwd_f32")
+            if lib.spacap_sa_mid_fwd_pool_supported(C2, C3, S):
+                # the last layer's kernel leaves the two best pooling candidates per (sub-group, channel); once the layer's
+                # statistics are final a G x C3 pass picks the first maximum: z3 is not read again in the forward
+                nsub = R // min(S, 32)
+                g3c = g3.contiguous()
+                cand_v = torch.empty(nsub, C3, 2, **f32)
+                cand_i = torch.empty(nsub, C3, 2, dtype=torch.uint8, device=dev)
+                check(lib.spacap_sa_mid_fwd_pool_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), g3c.data_ptr(), R, C2, C3,
+                                                     S, z3.data_ptr(), part.data_ptr(), cand_v.data_ptr(), cand_i.data_ptr(), st),
+                      "spacap_sa_mid_fwd_pool_f32")
+                finalize(2, C3, g3, b3)
+                check(lib.spacap_sa_pool_finalize_f32(cand_v.data_ptr(), cand_i.data_ptr(), stats[2].data_ptr(), g3c.data_ptr(),
+                                                      G, S, C3, out.data_ptr(), arg.data_ptr(), st), "spacap_sa_pool_finalize_f32")
+                import os
+                if os.environ.get("SPACAP_SA_POOL_DEBUG"):
+                    out2, arg2 = torch.empty_like(out), torch.empty_like(arg)
+                    check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out2.data_ptr(), arg2.data_ptr(),
+                                                     st), "spacap_sa_pool_fwd_f32")
+                    torch.cuda.synchronize()
+                    bad = (out != out2) | (arg != arg2)
+                    print("POOL DEBUG", (B, N, S, C2, C3), "value mismatches", int((out != out2).sum()), "arg mismatches",
+                          int((arg != arg2).sum()), "of", out.numel(), flush=True)
+                    if bad.any():
+                        b, n, c = [int(v[0]) for v in bad.nonzero(as_tuple=True)]
+                        g = b * N + n
+                        zz = z3.view(G, S, C3)[g, :, c]
+                        print("  first at group", g, "channel", c, "out", float(out[b, n, c]), float(out2[b, n, c]), "arg", int(arg[b, n, c]),
+                              int(arg2[b, n, c]), "gamma", float(g3[c]), "stats", stats[2][c].tolist(), flush=True)
+                        print("  z column", zz.tolist()[:S], flush=True)
+                        nsub1 = max(1, S // 32)
+                        print("  cand", cand_v.view(-1, C3, 2)[g * nsub1:(g + 1) * nsub1, c].tolist(), cand_i.view(-1, C3, 2)[g * nsub1:(g + 1) * nsub1, c].tolist(), flush=True)
+            else:
+                check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), R, C2, C3, z3.data_ptr(),
+                                                part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+                finalize(2, C3, g3, b3)
+                check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
+                                                 st), "spacap_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg)
         ctx.pm = pm                   # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)

@@ -1,0 +1,124 @@
+"""The shared-MLP layer kernel behind ``spacap_sa_mid_fwd_f32`` (z_out = relu(bn(z_in)) W^T + per-channel sums of z_out:
+one Conv2d(1x1) -> BatchNorm2d -> ReLU link of the reference's SharedMLP, lib/pointnet2/pytorch_utils.py) in its three
+implementations, each against float64 on the same inputs:
+
+  * default                 streaming split-bf16 kernel (csrc/sa_bf3.inc): every fp32 product as six bf16 MFMA products,
+  * SPACAP_SA_BF16X3=0      fp32-MFMA kernels (v_mfma_f32_16x16x4_f32),
+  * SPACAP_SA_BF16X3=1      first split-bf16 kernel (activations staged through LDS),
+  * SPACAP_SA_STREAM=1      streaming fp32-MFMA kernel (csrc/sa_stream.inc).
+
+The bar is the same for all of them -- fp32 GEMM accuracy, 2e-6 of the output's scale at K <= 128 (measured 2.5e-7 .. 4.5e-7
+for every variant, tools/lab/bf3_variants.py) -- which is the gate under which the split-bf16 kernel is the default: it must be
+indistinguishable from an fp32 GEMM, not merely "close".  The switches are read once per process, so the non-default
+variants run in a child process.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = [(77, 64, 128), (4096, 64, 128), (33007, 128, 256), (8192, 128, 128), (65536 + 31, 128, 128), (20000, 64, 64),
+          (300000, 128, 256)]
+TOL = 2e-6
+
+
+def _check(R, ci, co, dev="cuda:0"):
+    from spacap3d_amd._native import check, lib
+    torch.manual_seed(R)
+    zin = torch.randn(R, ci, device=dev)
+    st = torch.empty(ci, 4, device=dev)
+    st[:, 0] = 0.05 * torch.randn(ci, device=dev)
+    st[:, 1] = 1.0
+    st[:, 2] = 1.0 + 0.2 * torch.rand(ci, device=dev)
+    st[:, 3] = 0.1 * torch.randn(ci, device=dev)
+    W = 0.1 * torch.randn(co, ci, device=dev)
+    zout = torch.full((R, co), float("nan"), device=dev)
+    nparts = int(lib.spacap_sa_nparts())
+    part = torch.full((nparts * 2 * co,), float("nan"), dtype=torch.float64, device=dev)
+    check(lib.spacap_sa_mid_fwd_f32(zin.data_ptr(), st.data_ptr(), W.data_ptr(), R, ci, co, zout.data_ptr(), part.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "sa_mid_fwd")
+    torch.cuda.synchronize()
+    assert not torch.isnan(zout).any(), "rows left unwritten"
+    a = torch.relu((zin - st[:, 0]) * st[:, 2] + st[:, 3]).double()   # the kernel's own fp32 activation, then exact
+    ref = a @ W.double().t()
+    err = ((zout.double() - ref).abs().max() / ref.abs().max()).item()
+    p = part.view(nparts, 2, co).sum(0)
+    s_ref, q_ref = zout.double().sum(0), (zout.double() ** 2).sum(0)
+    es = ((p[0] - s_ref).abs().max() / s_ref.abs().max().clamp_min(1e-30)).item()
+    eq = ((p[1] - q_ref).abs().max() / q_ref.abs().max()).item()
+    return err, es, eq
+
+
+@pytest.mark.parametrize("R,ci,co", SHAPES)
+def test_layer_kernel_matches_float64(R, ci, co):
+    err, es, eq = _check(R, ci, co)
+    assert err < TOL, (R, ci, co, err)
+    assert es < 2e-6 and eq < 2e-6, (es, eq)      # per-workgroup float partial sums, combined in double
+
+
+@pytest.mark.parametrize("env", [{"SPACAP_SA_BF16X3": "0"}, {"SPACAP_SA_BF16X3": "1"}, {"SPACAP_SA_STREAM": "1"}],
+                         ids=["fp32-mfma", "split-bf16-lds", "fp32-mfma-streaming"])
+def test_other_layer_kernels_meet_the_same_bar(env):
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_sa_gemm_kernels_gpu as T\n"
+            "for s in T.SHAPES:\n"
+            "    err, es, eq = T._check(*s)\n"
+            "    assert err < T.TOL and es < 2e-6 and eq < 2e-6, (s, err, es, eq)\n"
+            "print('OK')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("R,ci,co,S", [(64 * 300, 64, 128, 64), (32 * 513, 128, 256, 32), (16 * 1001, 128, 256, 16),
+                                       (16 * 7, 128, 128, 16), (64 * 4096, 64, 128, 64)])
+@pytest.mark.parametrize("negative_gamma", [False, True])
+def test_pooling_from_the_layer_kernels_candidates_equals_the_pooling_pass(R, ci, co, S, negative_gamma):
+    """spacap_sa_mid_fwd_pool_f32 + spacap_sa_pool_finalize_f32 against spacap_sa_pool_fwd_f32 on the z_out the same launch
+    wrote: identical pooled values AND identical first-maximum indices, for both signs of the BatchNorm weight, with exact
+    ties planted (duplicated rows) and with groups whose activations are all zero."""
+    from spacap3d_amd._native import check, lib
+    if not lib.spacap_sa_mid_fwd_pool_supported(ci, co, S):
+        pytest.skip("the streaming layer kernel is not the active one")
+    dev = "cuda:0"
+    torch.manual_seed(R + S)
+    G = R // S
+    zin = torch.randn(G, S, ci, device=dev)
+    zin[::3, S // 2] = zin[::3, 1]            # planted exact ties: row S/2 repeats row 1 in every third group
+    zin[1::5, 3:] = zin[1::5, 2:3]            # ... and groups whose rows 2.. are all the same row
+    zin = zin.view(R, ci).contiguous()
+    st_in = torch.tensor([0.0, 1.0, 1.0, 0.0], device=dev).repeat(ci, 1).contiguous()
+    W = 0.1 * torch.randn(co, ci, device=dev)
+    gamma = (torch.rand(co, device=dev) + 0.5) * (-1.0 if negative_gamma else 1.0)
+    gamma[::7] *= -1.0
+    zout = torch.empty(R, co, device=dev)
+    nparts = int(lib.spacap_sa_nparts())
+    part = torch.empty(nparts * 2 * co, dtype=torch.float64, device=dev)
+    nsub = R // min(S, 32)
+    cand_v = torch.empty(nsub, co, 2, device=dev)
+    cand_i = torch.empty(nsub, co, 2, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    check(lib.spacap_sa_mid_fwd_pool_f32(zin.data_ptr(), st_in.data_ptr(), W.data_ptr(), gamma.data_ptr(), R, ci, co, S,
+                                         zout.data_ptr(), part.data_ptr(), cand_v.data_ptr(), cand_i.data_ptr(), s), "pool layer")
+    torch.cuda.synchronize()
+    ref = torch.relu(zin).double() @ W.double().t()          # (the input statistics above are the identity)
+    assert ((zout.double() - ref).abs().max() / ref.abs().max()).item() < TOL
+    p = part.view(nparts, 2, co).sum(0)
+    assert ((p[0] - zout.double().sum(0)).abs().max() / zout.double().sum(0).abs().max()).item() < 2e-6
+    # statistics of this layer's output, as spacap_sa_bn_finalize_f32 lays them out: (mean, istd, gamma * istd, beta)
+    mean, var = zout.double().mean(0), zout.double().var(0, unbiased=False)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    beta = 0.3 * torch.randn(co, device=dev)
+    beta[::4] = -50.0                          # channels whose activations are all zero
+    stats = torch.stack([mean.float(), istd.float(), (gamma.double() * istd).float(), beta], dim=1).contiguous()
+    out_a, out_b = torch.empty(G, co, device=dev), torch.empty(G, co, device=dev)
+    arg_a, arg_b = torch.empty(G, co, dtype=torch.uint8, device=dev), torch.empty(G, co, dtype=torch.uint8, device=dev)
+    check(lib.spacap_sa_pool_fwd_f32(zout.data_ptr(), stats.data_ptr(), G, S, co, out_a.data_ptr(), arg_a.data_ptr(), s), "pool pass")
+    check(lib.spacap_sa_pool_finalize_f32(cand_v.data_ptr(), cand_i.data_ptr(), stats.data_ptr(), gamma.data_ptr(), G, S, co,
+                                          out_b.data_ptr(), arg_b.data_ptr(), s), "pool finalize")
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(arg_a, arg_b), (arg_a != arg_b).sum().item()

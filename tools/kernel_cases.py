@@ -16,6 +16,7 @@ from spacap3d_amd._native import check, lib
 
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (about 6.3 TB/s achievable)
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
+PEAK_MFMA_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (sustained by a pure MFMA loop on this pool: 2 100, tools/lab/clock_cal.hip)
 
 
 def _st(dev):
@@ -46,7 +47,9 @@ def sa_mid_fwd(R, cin, cout, dev, label):
     def run():
         check(lib.spacap_sa_mid_fwd_f32(zin.data_ptr(), st.data_ptr(), W.data_ptr(), R, cin, cout, zout.data_ptr(),
                                         part.data_ptr(), _st(dev)), "sa_mid_fwd")
-    return dict(name=f"sa_mid_fwd {cin}->{cout} R={R} ({label})", kernel="sa_mid_fwd_kernel", run=run,
+    import os
+    split = os.environ.get("SPACAP_SA_BF16X3", "2") != "0" and cout % 128 == 0   # the library's default for these shapes
+    return dict(name=f"sa_mid_fwd {cin}->{cout} R={R} ({label})", kernel="sa_mid_fwd", run=run, bf16_products=6 if split else 0,
                 flops=2.0 * cin * cout * R, bytes=4.0 * R * (cin + cout), keep=(zin, st, W, zout, part),
                 what=f"{label}: z_out = relu(bn(z_in)) W^T + batch statistics of z_out, {R} rows, {cin} -> {cout} channels")
 
@@ -180,10 +183,17 @@ def roofline_entry(case, us, pmc=None):
         a = case["bytes"] / us * 1e-3
         ent = dict(bound="hbm", kernel=case["name"], achieved=a, peak=PEAK_HBM_GBS, unit="GB/s", frac=a / PEAK_HBM_GBS)
     ent.update(launch_us=us, algorithmic_flops=case["flops"], algorithmic_bytes=case["bytes"], what=case["what"])
+    if case.get("bf16_products"):
+        # fp32 results from bf16 matrix instructions: every fp32 product is evaluated as 6 exact bf16 x bf16 products with
+        # fp32 accumulation (csrc/sa_bf3.inc).  `achieved` stays the ALGORITHMIC fp32 flops of the layer / time and `peak`
+        # the fp32-MFMA peak it replaces; the matrix pipe itself executes 6x those flops in bf16:
+        ent["implementation"] = "split-bf16: 6 bf16 MFMA products per fp32 product, fp32 accumulate (fp32-equivalent result)"
+        ent["mfma_bf16_TFLOPs"] = case["bf16_products"] * case["flops"] / us * 1e-6
+        ent["mfma_bf16_frac_of_peak"] = ent["mfma_bf16_TFLOPs"] / PEAK_MFMA_BF16_TFLOPS
     rec = (pmc or {}).get(case["name"])
     ent["traffic"] = rec.get("hbm_bytes") if rec else None
     if rec:
-        for k in ("fetch_bytes_corrected", "write_bytes", "mfma_util", "clock_GHz", "mfma_flops_counted", "profiled_us", "source"):
+        for k in ("fetch_bytes_corrected", "write_bytes", "mfma_util", "clock_GHz", "mfma_flops_counted", "mfma_bf16_flops_counted", "profiled_us", "source"):
             if k in rec:
                 ent[k] = rec[k]
     return ent

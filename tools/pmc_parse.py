@@ -90,7 +90,8 @@ def main():
             rec["hbm_bytes"] = rec["fetch_bytes_corrected"] + rec["write_bytes"]
         if m:
             c = m[-1]
-            for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE"):
+            for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16",
+                      "GRBM_GUI_ACTIVE"):
                 if k in c:
                     rec[k] = c[k]
             if c.get("GRBM_GUI_ACTIVE"):
@@ -99,6 +100,8 @@ def main():
                     rec["clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / rec["profiled_us"] * 1e-3
             if "SQ_INSTS_VALU_MFMA_MOPS_F32" in c:
                 rec["mfma_flops_counted"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
+            if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+                rec["mfma_bf16_flops_counted"] = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"] * 512.0
         rec["source"] = os.path.basename(dst)
         result["_cases"][o["name"]] = rec
     result.update(result.pop("_cases"))
