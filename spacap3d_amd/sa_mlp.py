@@ -79,24 +79,6 @@ class _SAMLP(Function):
                 finalize(2, C3, g3, b3)
                 check(lib.spacap_sa_pool_finalize_f32(cand_v.data_ptr(), cand_i.data_ptr(), stats[2].data_ptr(), g3c.data_ptr(),
                                                       G, S, C3, out.data_ptr(), arg.data_ptr(), st), "spacap_sa_pool_finalize_f32")
-                import os
-                if os.environ.get("SPACAP_SA_POOL_DEBUG"):
-                    out2, arg2 = torch.empty_like(out), torch.empty_like(arg)
-                    check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out2.data_ptr(), arg2.data_ptr(),
-                                                     st), "spacap_sa_pool_fwd_f32")
-                    torch.cuda.synchronize()
-                    bad = (out != out2) | (arg != arg2)
-                    print("POOL DEBUG", (B, N, S, C2, C3), "value mismatches", int((out != out2).sum()), "arg mismatches",
-                          int((arg != arg2).sum()), "of", out.numel(), flush=True)
-                    if bad.any():
-                        b, n, c = [int(v[0]) for v in bad.nonzero(as_tuple=True)]
-                        g = b * N + n
-                        zz = z3.view(G, S, C3)[g, :, c]
-                        print("  first at group", g, "channel", c, "out", float(out[b, n, c]), float(out2[b, n, c]), "arg", int(arg[b, n, c]),
-                              int(arg2[b, n, c]), "gamma", float(g3[c]), "stats", stats[2][c].tolist(), flush=True)
-                        print("  z column", zz.tolist()[:S], flush=True)
-                        nsub1 = max(1, S // 32)
-                        print("  cand", cand_v.view(-1, C3, 2)[g * nsub1:(g + 1) * nsub1, c].tolist(), cand_i.view(-1, C3, 2)[g * nsub1:(g + 1) * nsub1, c].tolist(), flush=True)
             else:
                 check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), R, C2, C3, z3.data_ptr(),
                                                 part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
