@@ -768,6 +768,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 
 #include "sa_bf3.inc"
 #include "sa_stream.inc"
+#include "sa_bf3_dgrad.inc"
 
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
 __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ st,
@@ -1656,6 +1657,26 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   SPACAP_REQUIRE(dy && zk && coef && Wk && zp && st_p && dyp && part && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
   hipStream_t s = spacap::as_stream(stream);
+  // default: the streaming split-bf16 kernel (sa_bf3_dgrad.inc); SPACAP_SA_BF16X3=0 / SPACAP_SA_DGRAD_F32=1: the fp32-MFMA kernels
+  static const bool split = (getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2) == 2 &&
+                            getenv("SPACAP_SA_DGRAD_F32") == nullptr && getenv("SPACAP_SA_LAB") == nullptr;
+  if (split && (CK == 128 || CK == 256) && CP % 64 == 0) {
+    static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
+    const size_t ldsd = bf3s_dgrad_lds_bytes(CK);
+    const long wtiles = (R + 31) / 32;
+    const int gy = CP / 64;
+    long gx = cus / gy;
+    gx = gx > NPART ? NPART : gx;
+    gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+#define DS(CKV, PV)                                                                                                   \
+  hipLaunchKernelGGL((sa_dgrad_bf3s_kernel<CKV, PV>), dim3((unsigned)gx, gy), dim3(512), ldsd, s, dy, arg, S, zk, coef, Wk, CP, zp, \
+                     st_p, R, dyp, part)
+    if (CK == 128) { if (arg) DS(128, true); else DS(128, false); }
+    else { if (arg) DS(256, true); else DS(256, false); }
+#undef DS
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
+  }
 #define DG(CKV, NTV, PV, PF, AL, GY)                                                                                 \
   {                                                                                                                  \
     const size_t lds = (size_t)TM * ((CKV + 4) + ((AL) ? 0 : (64 * NTV + 4))) * sizeof(float);                       \

@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "spacap3d_amd", "csrc")
-KERNELS = ("sa_mid_fwd_bf3s_kernel", "sa_mid_fwd_s_kernel")
+KERNELS = ("sa_mid_fwd_bf3s_kernel", "sa_mid_fwd_s_kernel", "sa_dgrad_bf3s_kernel")
 AREG = re.compile(r"\ba\[(\d+):(\d+)\]|\ba(\d+)\b")
 
 
