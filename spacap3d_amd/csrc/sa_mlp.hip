@@ -1660,7 +1660,7 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   // default: the streaming split-bf16 kernel (sa_bf3_dgrad.inc); SPACAP_SA_BF16X3=0 / SPACAP_SA_DGRAD_F32=1: the fp32-MFMA kernels
   static const bool split = (getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2) == 2 &&
                             getenv("SPACAP_SA_DGRAD_F32") == nullptr && getenv("SPACAP_SA_LAB") == nullptr;
-  if (split && (CK == 128 || CK == 256) && CP % 64 == 0) {
+  if (split && (CK == 128 || CK == 256) && CP % 64 == 0 && R >= 49152) {   // (below: too few tiles per wave to pay for the weight staging)
     static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
     const size_t ldsd = bf3s_dgrad_lds_bytes(CK);
     const long wtiles = (R + 31) / 32;

@@ -122,3 +122,67 @@ def test_pooling_from_the_layer_kernels_candidates_equals_the_pooling_pass(R, ci
     torch.cuda.synchronize()
     assert torch.equal(out_a, out_b)
     assert torch.equal(arg_a, arg_b), (arg_a != arg_b).sum().item()
+
+
+DG_SHAPES = [(65536, 256, 128, 32), (49152 + 16, 256, 128, 16), (64 * 1024, 128, 64, 64), (50000, 128, 128, 0), (48 * 1100, 128, 64, 48),
+             (262144, 128, 128, 0)]
+
+
+def _check_dgrad(R, ck, cp, S, dev="cuda:0"):
+    """spacap_sa_dgrad_f32 against float64: dy_prev = [relu(bn(z_prev)) > 0] (dz W), dz = g d + k0 - k1 z_k, d dense (S == 0)
+    or the max-pool's routed gradient; and its BatchNorm sums."""
+    from spacap3d_amd._native import check, lib
+    torch.manual_seed(R + ck)
+    pooled = S > 0
+    G = R // S if pooled else R
+    dy = torch.randn(G, ck, device=dev)
+    arg = torch.randint(0, S, (G, ck), dtype=torch.uint8, device=dev) if pooled else None
+    zk, zp = torch.randn(R, ck, device=dev), torch.randn(R, cp, device=dev)
+    coef = torch.stack([1 + 0.1 * torch.rand(ck, device=dev), 0.1 * torch.randn(ck, device=dev), 0.1 * torch.randn(ck, device=dev),
+                        torch.zeros(ck, device=dev)], dim=1).contiguous()
+    stp = torch.stack([0.05 * torch.randn(cp, device=dev), 1 + 0.1 * torch.rand(cp, device=dev), 1 + 0.2 * torch.rand(cp, device=dev),
+                       0.1 * torch.randn(cp, device=dev)], dim=1).contiguous()
+    W = 0.1 * torch.randn(ck, cp, device=dev)
+    dyp = torch.full((R, cp), float("nan"), device=dev)
+    nparts = int(lib.spacap_sa_nparts())
+    part = torch.full((nparts * 2 * cp,), float("nan"), dtype=torch.float64, device=dev)
+    check(lib.spacap_sa_dgrad_f32(dy.data_ptr(), arg.data_ptr() if pooled else None, S, zk.data_ptr(), coef.data_ptr(), W.data_ptr(),
+                                  zp.data_ptr(), stp.data_ptr(), R, ck, cp, dyp.data_ptr(), part.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "sa_dgrad")
+    torch.cuda.synchronize()
+    assert not torch.isnan(dyp).any()
+    rows = torch.arange(R, device=dev)
+    if pooled:
+        d = torch.where(arg[rows // S].long() == (rows % S).unsqueeze(1), dy[rows // S], torch.zeros((), device=dev))
+    else:
+        d = dy
+    dz = (coef[:, 0] * d + coef[:, 1] - coef[:, 2] * zk).double()
+    da = dz @ W.double()
+    pre = (zp - stp[:, 0]) * stp[:, 2] + stp[:, 3]
+    ref = torch.where(pre > 0, da, torch.zeros((), dtype=torch.float64, device=dev))
+    near = pre.abs() < 1e-5          # the mask may legitimately flip within rounding of 0
+    err = (((dyp.double() - ref).abs() * (~near)).max() / ref.abs().max()).item()
+    p = part.view(nparts, 2, cp).sum(0)
+    s_ref = dyp.double().sum(0)
+    q_ref = (dyp.double() * ((zp - stp[:, 0]) * stp[:, 1]).double()).sum(0)
+    es = ((p[0] - s_ref).abs().max() / s_ref.abs().max()).item()
+    eq = ((p[1] - q_ref).abs().max() / q_ref.abs().max()).item()
+    return err, es, eq
+
+
+@pytest.mark.parametrize("R,ck,cp,S", DG_SHAPES)
+def test_data_gradient_kernel_matches_float64(R, ck, cp, S):
+    err, es, eq = _check_dgrad(R, ck, cp, S)
+    assert err < 3e-6 and es < 3e-6 and eq < 3e-6, (err, es, eq)   # K = 256: twice the summands of the forward bar
+
+
+def test_fp32_mfma_data_gradient_kernel_meets_the_same_bar():
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_sa_gemm_kernels_gpu as T\n"
+            "for s in T.DG_SHAPES:\n"
+            "    err, es, eq = T._check_dgrad(*s)\n"
+            "    assert err < 3e-6 and es < 3e-6 and eq < 3e-6, (s, err, es, eq)\n"
+            "print('OK')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPACAP_SA_DGRAD_F32="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
