@@ -24,7 +24,7 @@ Extra objects on the line (tier contract):
                 (fp32 MFMA).  traffic = HBM bytes per launch from the tracked rocprofv3 --pmc passes
                 (profiles/rNN_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_parse.py) next to the algorithmic
                 4*R*(cin+cout).
-  roofline_more the same object for an HBM-bound layer (SA1 layer 2, 64 -> 64 on 1 048 576 rows) and for the SA1
+  roofline_more the same object for the largest data-gradient GEMM (SA2 layer 3, 256 -> 128, split-bf16 streaming kernel), for an HBM-bound layer (SA1 layer 2, 64 -> 64 on 1 048 576 rows) and for the SA1
                 furthest-point sampling, which is neither: an on-chip latency chain (bound "latency", us per round;
                 `in_step_us` = its duration on the prefetch side stream inside the timed steps, from events).
   step          algorithmic flops of the whole training step and the resulting fraction of the fp32-MFMA peak.
@@ -277,6 +277,8 @@ def main():
                    "what": "same training step without Trainer-level pipelining: furthest-point sampling, ball queries and "
                            "interpolation weights computed inside the step (what a caller of SpaCapNet.forward gets)"}
 
+    trainer_prefetch_graph = bool(getattr(trainer, "prefetch_graph", False))
+    reserved_cus = int(per_gpu) if nxt is not None else 0
     if rank == 0:
         import glob
         import kernel_cases as KC
@@ -292,16 +294,23 @@ def main():
         roof = KC.roofline_entry(c_mfma, KC.time_case(c_mfma), pmc)
         roof["launches_timed"] = 20
         roof["how"] = ("20 back-to-back launches through the C ABI between two HIP events on the launch stream, right after the "
-                       "timed steps; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+                       "timed steps, with the grid the step uses (" + str(reserved_cus) + " CUs left to the side stream's sampling chain); traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
         del c_mfma
         c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
         roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)
         del c_hbm
+        c_dg = KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3")
+        roof_dg = KC.roofline_entry(c_dg, KC.time_case(c_dg), pmc)
+        del c_dg
         c_fps = KC.fps(B, N, m, dev)
         t_fps_us = KC.time_case(c_fps, iters=5, warm=1)
         roof_fps = KC.roofline_entry(c_fps, t_fps_us, pmc)
         roof_fps["in_step_us"] = fps_timer.mean_ms() * 1e3 if fps_timer.events else None
         roof_fps["in_step_launches_timed"] = len(fps_timer.events)
+        if not fps_timer.events:
+            roof_fps["in_step_note"] = ("the next batch's pyramid replays as ONE side-stream graph beside the step (Trainer.prefetch), so "
+                                        "events cannot bracket the sampling kernel; its in-step duration is in the rocprofv3 window "
+                                        "table under profiles/ (fps_bucket_kernel); SPACAP_PREFETCH_GRAPH=0 launches it eagerly")
         roof_fps["compulsory_bytes"] = c_fps["compulsory_bytes"]
         del c_fps
         # isolated SA1-shaped op rates (second half of the BASELINE metric)
@@ -325,12 +334,13 @@ def main():
                                    f"grad all-reduce + Adam)"
                                    + (f"; transformer {cfg['transformer']} with the 128->512 token projection" if cfg["transformer"] else ""),
                        "global_batch": per_gpu * world, "parallelism": f"dp{world}",
-                       "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
+                       "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None,
+                       "prefetch_as_graph": bool(graphed and nxt is not None and trainer_prefetch_graph), "reserved_cus_forward": reserved_cus, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
                        "side_stream_branches": bool(args.streams),
                        "sa_forward_gemm": {"0": "fp32 MFMA (v_mfma_f32_16x16x4_f32)", "1": "split-bf16 x3, LDS-staged activations"}.get(
                            os.environ.get("SPACAP_SA_BF16X3", "2"), "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
-            "roofline": roof, "roofline_more": [roof_hbm, roof_fps],
+            "roofline": roof, "roofline_more": [roof_dg, roof_hbm, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
                      "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
             "ops": ops, "final_loss": loss_val,

@@ -281,6 +281,10 @@ int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const float *W, 
    (out, arg) once this layer's batch statistics are final, so that the pooling pass never reads z_out.
    gamma_out = BatchNorm weight of this layer's output.  _supported: 1 when there is a kernel for (Cin, Cout, S). */
 int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S);
+/* n CUs (0..64) are left free by the forward layer kernels' persistent grids: for callers that run other kernels (the next
+   batch's sampling chain) beside the forward pass, whose workgroups would otherwise push the grid's last ones into a second
+   round. */
+int spacap_sa_reserve_cus(int n);
 int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, const float *W, const float *gamma_out, long R,
                                int Cin, int Cout, int S, float *zout, double *part, float *cand_v, uint8_t *cand_i,
                                spacap_stream_t stream);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "spacap_sa_mid_fwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_pool_fwd_f32": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_mid_fwd_pool_supported": (_i, [_i, _i, _i]),
+    "spacap_sa_reserve_cus": (_i, [_i]),
     "spacap_sa_mid_fwd_pool_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_sa_pool_finalize_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),

@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include <atomic>
 
 namespace {
 
@@ -1325,6 +1326,14 @@ bool rows_layout(int B, int Np, long E, RowsLayout &L) {
 
 // Workgroups (256 threads) of `kernel` that are resident on the whole device at once.  The GEMM kernels are
 // persistent: a grid larger than this would run its surplus as a second, nearly empty round.
+// CUs left to the side stream by the FORWARD layer kernels (spacap_sa_reserve_cus).  While the next batch's sampling chain
+// runs beside the step (one workgroup per scene: 8 CUs for the first ~4.4 of the step's ~9.8 ms, i.e. during the backbone's
+// forward), a persistent grid sized to ALL CUs leaves its last workgroups waiting for a free CU: they run as a second round
+// and the kernel takes 1.3 - 2.1x as long (tools/lab/fps_interference.py; the side-stream work cost the main stream 0.86 ms
+// per step, tools/lab/step_without_side_stream.py).  A grid of (CUs - 8) workgroups costs one more tile round in nine
+// when nothing runs beside it.
+static std::atomic<int> g_reserved_cus{0};
+inline int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
 template <typename K>
 int resident_blocks(K kernel, size_t lds) {
   int per = 0, dev = 0, cus = 0;
@@ -1334,6 +1343,17 @@ int resident_blocks(K kernel, size_t lds) {
   (void)hipGetLastError();
   return per * cus;
 }
+inline int device_cus() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    return cus;
+  }();
+  return n;
+}
+// resident workgroups of a FORWARD kernel with the reserved CUs left out
+inline int fwd_resident(int resident) { return resident - (resident / device_cus()) * reserved_cus(); }
 inline int grid_rows(int resident, int gy, long tiles) {
   long g = resident / gy;
   if (g > NPART) g = NPART;
@@ -1436,11 +1456,11 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
       const size_t lds32 = (size_t)32 * ((CI + 8) + (64 * NTV + 4)) * sizeof(float);                                 \
       const long tiles32 = (R + 31) / 32;                                                                            \
       static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>, lds32);                    \
-      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(res, GY, tiles32), GY),       \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(fwd_resident(res), GY, tiles32), GY),       \
                          dim3(256), lds32, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                       \
     } else if (m16) {                                                                                                \
       static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV>, lds);                          \
-      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256),  \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(fwd_resident(res), GY, tiles), GY), dim3(256),  \
                          lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                                    \
     } else {                                                                                                         \
       static const int res = resident_blocks(sa_mid_fwd32_kernel<CI, NTV, false, LABV>, lds);                        \
@@ -1482,7 +1502,7 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
     const size_t ldss = bf3s_lds_bytes(Cin);
     const long wtiles = (R + 31) / 32;
     const int gy = Cout / 128;
-    long gx = cus / gy;
+    long gx = (cus - reserved_cus()) / gy;
     gx = gx > NPART ? NPART : gx;
     gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
 #define MS(CI, KSP, LABV)                                                                                             \
@@ -1572,6 +1592,14 @@ extern "C" int spacap_lab_bf3s_trace(unsigned long long *out_host, unsigned long
 }
 
 /* 1 when spacap_sa_mid_fwd_pool_f32 has a kernel for this layer (the streaming split-bf16 kernel is the active one). */
+/* n CUs are left free by the forward layer kernels' persistent grids (0 <= n <= 64): set by a caller that runs other work
+   (the next batch's sampling chain) beside the forward pass. */
+extern "C" int spacap_sa_reserve_cus(int n) {
+  if (n < 0 || n > 64) return SPACAP_E_INVALID;
+  g_reserved_cus.store(n, std::memory_order_relaxed);
+  return SPACAP_OK;
+}
+
 extern "C" int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S) {
   static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
   static const bool off = getenv("SPACAP_SA_LAB") != nullptr || getenv("SPACAP_SA_STREAM") != nullptr ||
@@ -1594,7 +1622,7 @@ extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, 
   const size_t ldss = bf3s_lds_bytes(Cin);
   const long wtiles = (R + 31) / 32;
   const int gy = Cout / 128;
-  long gx = cus / gy;
+  long gx = (cus - reserved_cus()) / gy;
   gx = gx > NPART ? NPART : gx;
   gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
   const PoolArgs pa{gamma_out, S, cand_v, cand_i};
@@ -2334,7 +2362,7 @@ extern "C" int spacap_rel_tail_fwd_f32(const float *hid1, const float *W2, const
   const long tiles = (R + TM - 1) / TM;
   if (m16) {
     static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds,
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(fwd_resident(res), 1, tiles), 1), dim3(256), lds,
                        spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
                        TailArgs{b2, W3, b3, pred, RT_NO});
   } else {

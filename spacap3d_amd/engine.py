@@ -3,6 +3,8 @@ gradient all-reduce + Adam -- what ``Solver._forward/_compute_loss/_backward`` d
 reference (lib/solver.py:343-385), without its host synchronisations (``.item()`` x9, timers,
 CUDA_LAUNCH_BLOCKING=1) and without logging / checkpointing (out of scope).
 """
+import os
+
 import torch
 
 from . import streams
@@ -40,6 +42,8 @@ class Trainer:
         # independent branches of the step (relation head, detection losses) on side streams (spacap3d_amd/streams.py);
         # off by default: with the detection losses fused into four launches the single-stream graph is faster
         self.multi_stream = multi_stream
+        self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
+        self._prefetch_graph_key = self._prefetch_graph_obj = self._prefetch_in = self._prefetch_out = None
         broadcast_parameters(model)
 
     # -- sampling-pyramid prefetch ---------------------------------------------------------------------------
@@ -54,11 +58,39 @@ class Trainer:
             return
         if self.side_stream is None:
             self.side_stream = torch.cuda.Stream(device=pc.device)
+            # the sampling chain holds one CU per scene while the backbone's forward runs beside it: the forward layer
+            # kernels size their persistent grids to the rest of the chip (csrc/sa_mlp.hip: spacap_sa_reserve_cus)
+            from ._native import check, lib
+            check(lib.spacap_sa_reserve_cus(min(64, int(pc.shape[0]))), "spacap_sa_reserve_cus")
         cur = torch.cuda.current_stream(pc.device)
         self.side_stream.wait_stream(cur)
+        fn = geometry_pyramid if self.prefetch_geometry else sampling_pyramid
+        if self.graph is not None and self.prefetch_graph and not torch.cuda.is_current_stream_capturing():
+            # beside a replayed step the pyramid is ONE graph launch as well: ~60 eager launches per step from the host cost
+            # the main stream ~0.27 ms (tools/lab/step_without_side_stream.py).  Static input / outputs: the step copies
+            # the outputs into its own static buffers before the next prefetch may overwrite them (wait_stream above).
+            key = (tuple(pc.shape), fn is geometry_pyramid)
+            if self._prefetch_graph_key != key:
+                with torch.cuda.stream(self.side_stream), torch.no_grad():
+                    self._prefetch_in = pc[..., :3].contiguous().clone()
+                    for _ in range(2):
+                        fn(self._prefetch_in)
+                self.side_stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.no_grad(), torch.cuda.graph(g, stream=self.side_stream):
+                    self._prefetch_out = fn(self._prefetch_in)
+                self._prefetch_graph_obj, self._prefetch_graph_key = g, key
+                self.side_stream.wait_stream(cur)
+            with torch.cuda.stream(self.side_stream), torch.no_grad():
+                self._prefetch_in.copy_(pc[..., :3], non_blocking=True)
+                self._prefetch_graph_obj.replay()
+                ev = torch.cuda.Event()
+                ev.record(self.side_stream)
+            next_data["_fps_prefetch"] = (self._prefetch_out, ev)
+            return
         with torch.cuda.stream(self.side_stream), torch.no_grad():
             # sampling indices + ball-query groupings + interpolation weights: all functions of the coordinates
-            pyr = (geometry_pyramid if self.prefetch_geometry else sampling_pyramid)(pc[..., :3].contiguous())
+            pyr = fn(pc[..., :3].contiguous())
             ev = torch.cuda.Event()
             ev.record(self.side_stream)
         next_data["_fps_prefetch"] = (pyr, ev)

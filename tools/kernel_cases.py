@@ -68,8 +68,11 @@ def sa_dgrad(R, ck, cp, pooled, S, dev, label):
                                       part.data_ptr(), _st(dev)), "sa_dgrad")
     # reads: z_k (dense dz is rebuilt from it), z_prev (ReLU mask), dy (dense) or the pooled gradient; writes dy_prev
     byts = 4.0 * R * (ck + 2 * cp) + (4.0 * G * ck + G * ck if pooled else 4.0 * R * ck)
+    import os
+    split = (os.environ.get("SPACAP_SA_BF16X3", "2") == "2" and not os.environ.get("SPACAP_SA_DGRAD_F32") and ck in (128, 256)
+             and cp % 64 == 0 and R >= 49152)   # the library's default for these shapes (csrc/sa_bf3_dgrad.inc)
     return dict(name=f"sa_dgrad {ck}->{cp} R={R} {'pooled' if pooled else 'dense'} ({label})", kernel="sa_dgrad", run=run,
-                flops=2.0 * ck * cp * R, bytes=byts, keep=(dy, arg, zk, zp, coef, stp, W, dyp, part),
+                bf16_products=6 if split else 0, flops=2.0 * ck * cp * R, bytes=byts, keep=(dy, arg, zk, zp, coef, stp, W, dyp, part),
                 what=f"{label}: dy_prev = (dz W) * relu'(bn(z_prev)) + BN sums, {R} rows")
 
 
