@@ -43,6 +43,10 @@ class Trainer:
         # off by default: with the detection losses fused into four launches the single-stream graph is faster
         self.multi_stream = multi_stream
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
+        if next(model.parameters()).is_cuda:
+            # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
+            from ._native import check, lib
+            check(lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
         self._prefetch_graph_key = self._prefetch_graph_obj = self._prefetch_in = self._prefetch_out = None
         broadcast_parameters(model)
 

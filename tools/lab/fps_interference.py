@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch, kernel_cases as KC
 dev = torch.device("cuda:0")
+if os.environ.get("RESERVE"):
+    KC.check(KC.lib.spacap_sa_reserve_cus(int(os.environ["RESERVE"])), "reserve")
 B, R2, R1 = 8, 8 * 1024 * 32, 8 * 2048 * 64
 fps = KC.fps(B, 40000, 2048, dev)
 side = torch.cuda.Stream(device=dev)
