@@ -290,11 +290,18 @@ def main():
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
         pmc = json.load(open(pmc_files[-1])) if (pmc_files and (B, N) == (8, 40000)) else {}
         R2, R1 = B * 1024 * 32, B * 2048 * 64
+        # the layer kernels are timed with their full grid (nothing runs beside them here); the step launches the forward
+        # ones with `reserved_cus` CUs left to the sampling chain: that launch is timed as well
+        KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
         c_mfma = KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3")
         roof = KC.roofline_entry(c_mfma, KC.time_case(c_mfma), pmc)
+        if reserved_cus:
+            KC.check(KC.lib.spacap_sa_reserve_cus(reserved_cus), "spacap_sa_reserve_cus")
+            roof["launch_us_with_the_steps_grid"] = KC.time_case(c_mfma)
+            KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
         roof["launches_timed"] = 20
         roof["how"] = ("20 back-to-back launches through the C ABI between two HIP events on the launch stream, right after the "
-                       "timed steps, with the grid the step uses (" + str(reserved_cus) + " CUs left to the side stream's sampling chain); traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+                       "timed steps (full grid; launch_us_with_the_steps_grid: " + str(reserved_cus) + " CUs left to the side stream's sampling chain, as the step launches it); traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
         del c_mfma
         c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
         roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)

@@ -1352,7 +1352,9 @@ inline int device_cus() {
   }();
   return n;
 }
-// resident workgroups of a FORWARD kernel with the reserved CUs left out.  Kernels with several workgroups per CU need slack
+// resident workgroups of a FORWARD kernel with the reserved CUs left out (used by the relation tail; the HBM-bound 64-channel
+// fp32 layer kernel runs 1.3x as long beside the sampling kernel with or without it and only loses from a smaller grid when
+// alone, so it keeps the full one).  Kernels with several workgroups per CU need slack
 // beyond the occupied CUs themselves (the dispatcher does not pack the rest perfectly: measured, the relation tail beside the
 // sampling kernel runs 1.5x as long with 8 CUs left out and 1.04x with 24)
 inline int fwd_resident(int resident) {
@@ -1461,11 +1463,11 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
       const size_t lds32 = (size_t)32 * ((CI + 8) + (64 * NTV + 4)) * sizeof(float);                                 \
       const long tiles32 = (R + 31) / 32;                                                                            \
       static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>, lds32);                    \
-      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(fwd_resident(res), GY, tiles32), GY),       \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(res, GY, tiles32), GY),       \
                          dim3(256), lds32, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                       \
     } else if (m16) {                                                                                                \
       static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV>, lds);                          \
-      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(fwd_resident(res), GY, tiles), GY), dim3(256),  \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256),  \
                          lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                                    \
     } else {                                                                                                         \
       static const int res = resident_blocks(sa_mid_fwd32_kernel<CI, NTV, false, LABV>, lds);                        \
