@@ -1504,7 +1504,6 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
   static const bool bf3 = bf3v != 0;   // split-bf16 matrix-core path (1: sa_mid_fwd_bf3_kernel, 2: the streaming kernel)
   if (bf3v == 2 && (Cin == 64 || Cin == 128) && Cout % 128 == 0) {
-    static const int ksplit = getenv("SPACAP_SA_INTER") ? atoi(getenv("SPACAP_SA_INTER")) : 1;
     static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
     const size_t ldss = bf3s_lds_bytes(Cin);
     const long wtiles = (R + 31) / 32;
@@ -1517,10 +1516,9 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
                      zout, part)
     if (lab == 1) { if (Cin == 64) MS(64, 1, 1); else MS(128, 1, 1); }
     else if (lab == 2) { if (Cin == 64) MS(64, 1, 2); else MS(128, 1, 2); }
-    else if (lab == 9 && ksplit == 2) { if (Cin == 64) MS(64, 2, 9); else MS(128, 2, 9); }
     else if (lab == 9) { if (Cin == 64) MS(64, 1, 9); else MS(128, 1, 9); }
-    else if (Cin == 64) { if (ksplit == 2) MS(64, 2, 0); else MS(64, 1, 0); }
-    else { if (ksplit == 2) MS(128, 2, 0); else MS(128, 1, 0); }
+    else if (Cin == 64) MS(64, 1, 0);
+    else MS(128, 1, 0);
 #undef MS
     SPACAP_CHECK_LAUNCH(what);
     return SPACAP_OK;
@@ -1633,14 +1631,7 @@ extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, 
   gx = gx > NPART ? NPART : gx;
   gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
   const PoolArgs pa{gamma_out, S, cand_v, cand_i};
-  static const int plab = getenv("SPACAP_POOL_LAB") ? atoi(getenv("SPACAP_POOL_LAB")) : 0;
-  if (plab == 11 && Cin == 64)
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 11, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
-                       R, zout, part, pa);
-  else if (plab == 12 && Cin == 64)
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 12, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
-                       R, zout, part, pa);
-  else if (Cin == 64)
+  if (Cin == 64)
     hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 0, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
                        R, zout, part, pa);
   else

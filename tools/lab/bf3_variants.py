@@ -36,7 +36,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "run":
         print(f"{tag} {ci:3d}->{co:3d} R={R:8d}: {us:7.1f} us {c['flops'] / us * 1e-6:6.1f} TF/s {c['bytes'] / us * 1e-3:7.1f} GB/s | err {err:.2e} sum {es:.1e} sq {eq:.1e} nan {nan}", flush=True)
         del c
 else:
-    for v, inter, lab in (("2", "1", ""),):
+    for v, inter, lab in (("0", "", ""), ("1", "", ""), ("2", "", ""), ("2", "", "1"), ("2", "", "2")):
         env = dict(os.environ)
         if v == "S":
             env["SPACAP_SA_STREAM"] = "1"; v = ""
