@@ -112,6 +112,10 @@ class Pointnet2Backbone(nn.Module):
             side = Pointnet2Backbone._side_streams[dev] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         levels = []
+        # the chain holds one CU per scene while the first SA modules' layer kernels run beside it: they size their
+        # persistent grids to the rest of the chip (csrc/sa_mlp.hip: spacap_sa_reserve_cus; cheap, idempotent)
+        from ._native import check, lib
+        check(lib.spacap_sa_reserve_cus(min(64, int(xyz.shape[0]))), "spacap_sa_reserve_cus")
         with torch.cuda.stream(side), torch.no_grad():
             cur = xyz
             for n in SA_NPOINTS:
