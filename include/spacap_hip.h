@@ -191,6 +191,10 @@ size_t spacap_bn_workspace_bytes(int C);
 int spacap_bn_stats_f32(const float *z, int B, int C, long L, float eps, float momentum, float *running_mean,
                         float *running_var, float *stats, void *workspace, spacap_stream_t stream);
 /* out[b,c,l] = relu((z - mean) * invstd * gamma + beta) */
+/* spacap_bn_stats_f32 + spacap_bn_relu_apply_f32 in one call: one launch when a channel has <= 32 768 elements. */
+int spacap_bn_relu_train_f32(const float *z, int B, int C, long L, float eps, float momentum, float *running_mean,
+                             float *running_var, const float *gamma, const float *beta, float *stats, float *out,
+                             void *workspace, spacap_stream_t stream);
 int spacap_bn_relu_apply_f32(const float *z, const float *stats, const float *gamma, const float *beta, int B,
                              int C, long L, float *out, spacap_stream_t stream);
 /* same followed by the max over the S samples of every (b,c,p): out f32 [B,C,P], arg u8 [B,C,P]; S in {16,32,64,128} */

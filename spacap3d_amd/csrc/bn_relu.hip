@@ -283,6 +283,94 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float *__restrict_
   }
 }
 
+// ---- small tensors: statistics + apply (forward) and sums + dz (backward) of one channel in ONE launch --------------------
+// The three-launch forms above exist to spread a channel's reduction over several workgroups; with <= 32 768 elements per
+// channel and >= 64 channels (vote module, proposal head, position nets: 2 048 .. 8 192 elements) one workgroup per channel
+// fills the chip by itself and the two extra launches + the round trip through the partial-sum workspace only cost time
+// (9 + 9 such layers per step).  Same arithmetic, expression for expression, as the kernels above; the sums are fp64.
+__global__ __launch_bounds__(STAT_THREADS) void bn_relu_train_small_kernel(
+    const float *__restrict__ z, int B, int C, long L, double M, float eps, float momentum, float *__restrict__ running_mean,
+    float *__restrict__ running_var, const float *__restrict__ gamma, const float *__restrict__ beta, float *__restrict__ stats,
+    float *__restrict__ out) {
+  __shared__ double s_buf[STAT_THREADS / 64];
+  const int c = blockIdx.x;
+  const long per_b = L / 4, total = (long)B * per_b;
+  double s = 0.0, q = 0.0;
+  for (long i = threadIdx.x; i < total; i += STAT_THREADS) {
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(z + ((size_t)(i / per_b) * C + c) * L + (i % per_b) * 4);
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  s = block_sum_f64(s, s_buf);
+  q = block_sum_f64(q, s_buf);
+  const double mean_d = s / M;
+  double var = q / M - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, istd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    stats[c * 2 + 0] = mean;
+    stats[c * 2 + 1] = istd;
+    if (running_mean) {
+      const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean_d);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+  const float sc = istd * gamma[c], sh = beta[c];
+  for (long i = threadIdx.x; i < total; i += STAT_THREADS) {
+    const size_t off = ((size_t)(i / per_b) * C + c) * L + (i % per_b) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4 *>(z + off);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = fmaxf((v[u] - mean) * sc + sh, 0.f);
+    *reinterpret_cast<f32x4 *>(out + off) = v;
+  }
+}
+
+__global__ __launch_bounds__(STAT_THREADS) void bn_relu_bwd_small_kernel(
+    const float *__restrict__ z, const float *__restrict__ dA, const float *__restrict__ stats, const float *__restrict__ gamma,
+    const float *__restrict__ beta, int B, int C, long L, double M, float *__restrict__ dz, float *__restrict__ dgamma,
+    float *__restrict__ dbeta) {
+  __shared__ double s_buf[STAT_THREADS / 64];
+  const int c = blockIdx.x;
+  const float mean = stats[c * 2], r = stats[c * 2 + 1], g = gamma[c], bt = beta[c];
+  const long per_b = L / 4, total = (long)B * per_b;
+  double s1 = 0.0, s2 = 0.0;
+  for (long i = threadIdx.x; i < total; i += STAT_THREADS) {
+    const size_t off = ((size_t)(i / per_b) * C + c) * L + (i % per_b) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(z + off);
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(dA + off);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float xh = (v[u] - mean) * r;
+      const float dy = (xh * g + bt > 0.f) ? d[u] : 0.f;
+      s1 += dy;
+      s2 += (double)dy * xh;
+    }
+  }
+  s1 = block_sum_f64(s1, s_buf);
+  s2 = block_sum_f64(s2, s_buf);
+  if (threadIdx.x == 0) dbeta[c] = (float)s1, dgamma[c] = (float)s2;
+  const float k1 = (float)(s1 / M), k2 = (float)(s2 / M), gr = g * r;
+  for (long i = threadIdx.x; i < total; i += STAT_THREADS) {
+    const size_t off = ((size_t)(i / per_b) * C + c) * L + (i % per_b) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4 *>(z + off);
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(dA + off);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float xh = (v[u] - mean) * r;
+      const float dy = (xh * g + bt > 0.f) ? d[u] : 0.f;
+      o[u] = gr * (dy - k1 - xh * k2);
+    }
+    *reinterpret_cast<f32x4 *>(dz + off) = o;
+  }
+}
+
+inline bool bn_small(int B, int C, long L) {
+  static const bool off = getenv("SPACAP_BN_THREE_PASS") != nullptr;
+  return !off && (L & 3) == 0 && C >= 64 && (double)B * (double)L <= 32768.0;
+}
+
 int pick_split(int C, double elems_per_channel) {
   int want = (int)(4096 / (C > 0 ? C : 1));
   if (want < 1) want = 1;
@@ -325,6 +413,24 @@ extern "C" int spacap_bn_stats_f32(const float *z, int B, int C, long L, float e
   return SPACAP_OK;
 }
 
+/* statistics + apply in one call (one launch for small tensors, else spacap_bn_stats_f32 + spacap_bn_relu_apply_f32) */
+extern "C" int spacap_bn_relu_train_f32(const float *z, int B, int C, long L, float eps, float momentum, float *running_mean,
+                                        float *running_var, const float *gamma, const float *beta, float *stats, float *out,
+                                        void *workspace, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 1 && C >= 1 && L >= 1 && (long)B * C <= 65535, "spacap_bn_relu_train_f32: bad sizes B=%d C=%d L=%ld", B, C, L);
+  SPACAP_REQUIRE(z && gamma && beta && stats && out && workspace, "spacap_bn_relu_train_f32: null pointer");
+  SPACAP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "spacap_bn_relu_train_f32: running stats");
+  if (bn_small(B, C, L)) {
+    hipLaunchKernelGGL(bn_relu_train_small_kernel, dim3(C), dim3(STAT_THREADS), 0, spacap::as_stream(stream), z, B, C, L,
+                       (double)B * (double)L, eps, momentum, running_mean, running_var, gamma, beta, stats, out);
+    SPACAP_CHECK_LAUNCH("spacap_bn_relu_train_f32");
+    return SPACAP_OK;
+  }
+  const int rc = spacap_bn_stats_f32(z, B, C, L, eps, momentum, running_mean, running_var, stats, workspace, stream);
+  if (rc != SPACAP_OK) return rc;
+  return spacap_bn_relu_apply_f32(z, stats, gamma, beta, B, C, L, out, stream);
+}
+
 extern "C" int spacap_bn_relu_apply_f32(const float *z, const float *stats, const float *gamma, const float *beta,
                                         int B, int C, long L, float *out, spacap_stream_t stream) {
   SPACAP_REQUIRE(B >= 1 && C >= 1 && L >= 1 && (long)B * C <= 65535, "spacap_bn_relu_apply_f32: bad sizes");
@@ -361,6 +467,12 @@ extern "C" int spacap_bn_relu_bwd_f32(const float *z, const float *stats, const 
   SPACAP_REQUIRE(z && stats && gamma && beta && dA && dz && dgamma && dbeta && workspace,
                  "spacap_bn_relu_bwd_f32: null pointer");
   hipStream_t s = spacap::as_stream(stream);
+  if (bn_small(B, C, L)) {
+    hipLaunchKernelGGL(bn_relu_bwd_small_kernel, dim3(C), dim3(STAT_THREADS), 0, s, z, dA, stats, gamma, beta, B, C, L,
+                       (double)B * (double)L, dz, dgamma, dbeta);
+    SPACAP_CHECK_LAUNCH("spacap_bn_relu_bwd_f32");
+    return SPACAP_OK;
+  }
   double *part = reinterpret_cast<double *>(workspace);
   float *coef = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + (size_t)C * 256 * 2 * sizeof(double));
   const double M = (double)B * (double)L;

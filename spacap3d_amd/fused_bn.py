@@ -27,9 +27,18 @@ class BNReLU(Function):
         with torch.cuda.device(dev):
             stats = torch.empty(C, 2, dtype=torch.float32, device=dev)
             ws = _ws(C, dev)
-            check(lib.spacap_bn_stats_f32(z.data_ptr(), B, C, L, float(eps), float(momentum),
-                                          running_mean.data_ptr() if running_mean is not None else None,
-                                          running_var.data_ptr() if running_var is not None else None,
+            rm = running_mean.data_ptr() if running_mean is not None else None
+            rv = running_var.data_ptr() if running_var is not None else None
+            if not pool_S:
+                # statistics + apply in one call (one launch when a channel has <= 32 768 elements)
+                out = torch.empty_like(z)
+                check(lib.spacap_bn_relu_train_f32(z.data_ptr(), B, C, L, float(eps), float(momentum), rm, rv, gamma.data_ptr(),
+                                                   beta.data_ptr(), stats.data_ptr(), out.data_ptr(), ws.data_ptr(), st),
+                      "spacap_bn_relu_train_f32")
+                ctx.save_for_backward(z, stats, gamma, beta)
+                ctx.pool_S = 0
+                return out
+            check(lib.spacap_bn_stats_f32(z.data_ptr(), B, C, L, float(eps), float(momentum), rm, rv,
                                           stats.data_ptr(), ws.data_ptr(), st), "spacap_bn_stats_f32")
             if pool_S:
                 S = int(pool_S)
