@@ -1321,7 +1321,18 @@ __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float *__res
   const int c4 = (int)(i % C4);
   f32x4 a = {0.f, 0.f, 0.f, 0.f};
   const int beg = off[k], end = off[k + 1];
-  for (int p = beg; p < end; ++p) a += ld4(dz + (size_t)order[p] * C + c4 * 4);
+  // (order[p] -> row is a dependent chain: four of them in flight per iteration; the sum keeps its order)
+  int p = beg;
+  for (; p + 3 < end; p += 4) {
+    const int o0 = order[p], o1 = order[p + 1], o2 = order[p + 2], o3 = order[p + 3];
+    const f32x4 r0 = ld4(dz + (size_t)o0 * C + c4 * 4), r1 = ld4(dz + (size_t)o1 * C + c4 * 4),
+                r2 = ld4(dz + (size_t)o2 * C + c4 * 4), r3 = ld4(dz + (size_t)o3 * C + c4 * 4);
+    a += r0;
+    a += r1;
+    a += r2;
+    a += r3;
+  }
+  for (; p < end; ++p) a += ld4(dz + (size_t)order[p] * C + c4 * 4);
   st4(out + (size_t)k * C + c4 * 4, a);
 }
 
