@@ -284,6 +284,10 @@ int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const float *W, 
    pooling candidates (cand_v f32, cand_i u8: [R / min(S,32)][Cout][2]); spacap_sa_pool_finalize_f32 turns them into
    (out, arg) once this layer's batch statistics are final, so that the pooling pass never reads z_out.
    gamma_out = BatchNorm weight of this layer's output.  _supported: 1 when there is a kernel for (Cin, Cout, S). */
+/* out[R][Cout] = x[R][Cin] W[Cout][Cin]^T (fp32 in / out / accumulate) on the streaming split-bf16 kernel: the relation
+   head's dhid1 = dz2 W2 (backward of models/transformer_captioner.py:319-326).  _supported: 1 when there is a kernel. */
+int spacap_gemm_rows_supported(int Cin, int Cout);
+int spacap_gemm_rows_f32(const float *x, const float *W, long R, int Cin, int Cout, float *out, spacap_stream_t stream);
 int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S);
 /* n CUs (0..64) are left free by the forward layer kernels' persistent grids: for callers that run other kernels (the next
    batch's sampling chain) beside the forward pass, whose workgroups would otherwise push the grid's last ones into a second

@@ -66,6 +66,8 @@ SIGNATURES = {
     "spacap_sa_bn_finalize_f32": (_i, [_p, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
     "spacap_sa_mid_fwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_pool_fwd_f32": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_gemm_rows_supported": (_i, [_i, _i]),
+    "spacap_gemm_rows_f32": (_i, [_p, _p, _l, _i, _i, _p, _p]),
     "spacap_sa_mid_fwd_pool_supported": (_i, [_i, _i, _i]),
     "spacap_sa_reserve_cus": (_i, [_i]),
     "spacap_sa_mid_fwd_pool_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),

@@ -1639,6 +1639,36 @@ extern "C" int spacap_lab_bf3s_trace(unsigned long long *out_host, unsigned long
 }
 
 /* 1 when spacap_sa_mid_fwd_pool_f32 has a kernel for this layer (the streaming split-bf16 kernel is the active one). */
+/* out[R][Cout] = x[R][Cin] W[Cout][Cin]^T, fp32 in / out / accumulate, on the streaming split-bf16 kernel (every fp32 product as
+   six bf16 matrix products): the relation head's dhid1 = dz2 W2 (models/transformer_captioner.py:319-326 backward), 524 288
+   rows.  _supported: 1 for Cin in {64, 128}, Cout a multiple of 128 (and the split kernels not switched off). */
+extern "C" int spacap_gemm_rows_supported(int Cin, int Cout) {
+  static const bool on = (getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2) == 2 && getenv("SPACAP_SA_LAB") == nullptr &&
+                         getenv("SPACAP_NO_GEMM_ROWS") == nullptr;
+  return on && (Cin == 64 || Cin == 128) && Cout % 128 == 0;
+}
+extern "C" int spacap_gemm_rows_f32(const float *x, const float *W, long R, int Cin, int Cout, float *out,
+                                    spacap_stream_t stream) {
+  const char *what = "spacap_gemm_rows_f32";
+  SPACAP_REQUIRE(x && W && out && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(spacap_gemm_rows_supported(Cin, Cout), "%s: (Cin=%d, Cout=%d) unsupported", what, Cin, Cout);
+  hipStream_t s = spacap::as_stream(stream);
+  const size_t ldss = bf3s_lds_bytes(Cin);
+  const long wtiles = (R + 31) / 32;
+  const int gy = Cout / 128;
+  long gx = device_cus() / gy;
+  gx = gx > NPART ? NPART : gx;
+  gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+  if (Cin == 64)
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 0, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
+                       (const float *)nullptr, W, Cout, R, out, (double *)nullptr, PoolArgs{});
+  else
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, 0, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
+                       (const float *)nullptr, W, Cout, R, out, (double *)nullptr, PoolArgs{});
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 /* n CUs are left free by the forward layer kernels' persistent grids (0 <= n <= 64): set by a caller that runs other work
    (the next batch's sampling chain) beside the forward pass. */
 extern "C" int spacap_sa_reserve_cus(int n) {

@@ -263,7 +263,17 @@ class RelationTail(Function):
                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_rel_tail_bwd_f32")
             s = sum_slabs(part, deferrable=True)
             dW3, db2, db3 = s[:NO * 128].view(NO, 128), s[NO * 128:NO * 128 + 128], s[NO * 128 + 128:NO * 128 + 128 + NO]
-            dh1 = (dz2 @ W2).view(ctx.shape) if ctx.needs_input_grad[0] else None
+            dh1 = None
+            if ctx.needs_input_grad[0]:
+                if R >= 49152 and lib.spacap_gemm_rows_supported(128, 128):
+                    # dz2 W2 on the streaming split-bf16 kernel (fp32-equivalent; 170 us in BLAS -> ~125 us at 524 288 rows)
+                    dh1 = torch.empty_like(hid2)
+                    W2t = W2.t().contiguous()
+                    check(lib.spacap_gemm_rows_f32(dz2.data_ptr(), W2t.data_ptr(), R, 128, 128, dh1.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream), "spacap_gemm_rows_f32")
+                    dh1 = dh1.view(ctx.shape)
+                else:
+                    dh1 = (dz2 @ W2).view(ctx.shape)
             S = RelationTail.SLABS
             if R % S == 0 and R >= 64 * S:
                 dW2 = sum_slabs(torch.bmm(dz2.view(S, R // S, 128).transpose(1, 2), h1.view(S, R // S, 128)).view(S, -1),

@@ -186,3 +186,23 @@ def test_fp32_mfma_data_gradient_kernel_meets_the_same_bar():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPACAP_SA_DGRAD_F32="1"), capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("R,ci,co", [(524288, 128, 128), (50000 + 13, 128, 256), (77, 64, 128)])
+def test_plain_row_product_matches_float64(R, ci, co):
+    """spacap_gemm_rows_f32 (out = x W^T on the streaming split-bf16 kernel, no BatchNorm / ReLU / statistics)."""
+    from spacap3d_amd._native import check, lib
+    if not lib.spacap_gemm_rows_supported(ci, co):
+        pytest.skip("the streaming split-bf16 kernels are switched off")
+    torch.manual_seed(R)
+    x = torch.randn(R, ci, device="cuda:0")
+    W = 0.1 * torch.randn(co, ci, device="cuda:0")
+    out = torch.full((R, co), float("nan"), device="cuda:0")
+    check(lib.spacap_gemm_rows_f32(x.data_ptr(), W.data_ptr(), R, ci, co, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "spacap_gemm_rows_f32")
+    torch.cuda.synchronize()
+    n = min(R, 16384)
+    sel = torch.cat([torch.arange(n // 2, device="cuda:0"), torch.arange(R - (n - n // 2), R, device="cuda:0")])
+    ref = x[sel].double() @ W.double().t()
+    assert not torch.isnan(out).any()
+    assert ((out[sel].double() - ref).abs().max() / ref.abs().max()).item() < TOL
