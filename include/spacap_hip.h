@@ -511,6 +511,71 @@ int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *target, const ui
 int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target, const uint8_t *good, const float *out, const float *gloss,
                             int B, int W, int V, int tstride, float *dlogits, spacap_stream_t stream);
 
+/* ---- fused Transformer sub-layers, d_model = 128 (replaces everything BETWEEN two attention() calls of
+ * models/transformer_captioner.py: SublayerConnection :115-127, LayerNorm :102-113, PositionwiseFeedForward :72-81, the
+ * output projection and the packed q|k|v projection of MultiHeadedAttention :52-70).  One argument block, read before the
+ * call returns; every tensor f32, dense, 16-byte aligned, rows of 128 unless stated.
+ *
+ *  mode 0 (forward), per row r:
+ *      acc   = a1[r, 0:k1] w1^T + bias1          w1 [128, k1], k1 a multiple of 128        (skipped when a1 == NULL)
+ *      x'    = res[r] + dropout(acc)             dropout(p, seed, seed_dev) as spacap_dropout_add_fwd_f32, element index
+ *                                                r*128 + c; x' = res[r] when a1 == NULL;  stored to x_out when non-NULL
+ *      n     = ln_a * (x' - mean) / (std_unbiased + eps) + ln_b      stored to n_out (nullable), (mean, 1/(std+eps)) to
+ *                                                stats [R,2] (nullable)
+ *      out2  = n w2^T + bias2                    w2 [n2, 128], n2 a multiple of 128, out2 [R, n2]   (skipped when n2 == 0)
+ *  mode 1 (backward), per row r:
+ *      dn    = a1[r, 0:k1] w1                    w1 [k1, 128]                              (dn = g[r] when a1 == NULL)
+ *      dx    = LayerNorm'(dn; x_ln[r], stats[r], ln_a) + res[r]      (res nullable: the gradient arriving along the
+ *                                                residual connection);  stored to x_out
+ *      part[workgroup] = (sum_rows dn * xhat, sum_rows dn)           f32 [spacap_tf_rows_parts(R), 256], to be added in order
+ *      dy    = dropout'(dx)                      the same mask as the forward call with the same (p, seed, seed_dev); stored
+ *                                                to n_out (nullable)
+ *      out2  = dy w2                             w2 [128, 128], n2 == 128, out2 [R,128]            (skipped when n2 == 0) */
+typedef struct {
+  int mode;
+  long R;
+  const float *a1;
+  const float *w1;
+  const float *bias1;
+  int k1;
+  float drop_p;
+  float eps;
+  uint64_t seed;
+  const uint64_t *seed_dev;
+  const float *res;
+  float *x_out;
+  const float *ln_a;
+  const float *ln_b;
+  float *n_out;
+  float *stats;
+  const float *x_ln;
+  const float *g;
+  float *part;
+  const float *w2;
+  const float *bias2;
+  float *out2;
+  int n2;
+  int nparts; /* > 0: a1 is [nparts][R][128], partial sums of the first product (spacap_tf_gemm_f32), added in order */
+} spacap_tf_rows_args;
+int spacap_tf_rows_f32(const spacap_tf_rows_args *args, spacap_stream_t stream);
+int spacap_tf_rows_parts(long R);
+/* h = dropout(relu(x W^T + bias)): x [R,128], W [N,128], N a multiple of 128, h [R,N]; dropout element index r*N + c
+ * (models/transformer_captioner.py:80).  The saved h is positive exactly where the unit was active and kept: the backward is
+ * spacap_linear_dgrad_mask_f32. */
+int spacap_tf_ffn1_f32(const float *x, const float *W, const float *bias, long R, int N, float drop_p, uint64_t seed,
+                       const uint64_t *seed_dev, float *h, spacap_stream_t stream);
+/* Split-K product for the skinny feed-forward products (K = d_ff, N = 128: w_2 forward, the data gradient through w_1):
+ * out[s][r][n] = sum_{k in slice s} a[r][k] Wop[k][n], Wop[k][n] = trans_w ? W[n][k] (W [N,K]) : W[k][n] (W [K,N]);
+ * a [R,K], K and N multiples of 128, nsplit a divisor of K / 128 (spacap_tf_gemm_splits suggests the one that fills the
+ * chip); out [nsplit][R][N] is consumed by spacap_tf_rows_f32 (nparts), which adds the slices in order. */
+int spacap_tf_gemm_splits(long R, int K, int N);
+int spacap_tf_gemm_f32(const float *a, const float *W, long R, int K, int N, int trans_w, int nsplit, float *out,
+                       spacap_stream_t stream);
+/* out[r][n] = y[r][n] > 0 ? scale * sum_k g[r][k] W[k][n] : 0 -- g [R,128], W [128,N], y, out [R,N]: the gradient of
+ * spacap_tf_ffn1_f32's pre-activation through the following Linear (y = its saved output). */
+int spacap_tf_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int K, int N, float *out,
+                             spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

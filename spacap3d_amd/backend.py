@@ -44,6 +44,8 @@ class HipBackend:
         self.ffn_tail = _lin.ffn_tail
         self.conv1x1 = _lin.conv1x1
         self.relation_tail = _lin.relation_tail
+        from . import tf_layer as _tf
+        self.tf_stack = _tf
         from . import sa_mlp as _sa
         self.sa_mlp_train = _sa.sa_mlp_train
         self.sa_mlp_eval = _sa.sa_mlp_eval

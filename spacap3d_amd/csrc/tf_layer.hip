@@ -1,0 +1,605 @@
+// Fused sub-layer kernels of the Transformer captioner (d_model = 128) for gfx950 (MI355X).
+//
+// Reference: models/transformer_captioner.py -- SublayerConnection :115-127 (x + dropout(sublayer(norm(x)))),
+// LayerNorm :102-113 (unbiased std, eps on std), PositionwiseFeedForward :72-81, MultiHeadedAttention's four
+// Linear(128,128) :39-70, EncoderLayer :180-191, DecoderLayer :209-225 (early guide: no cross-attention).
+//
+// One encoder / decoder layer is ~10 launches forward and ~14 backward as separate operators (LayerNorm, packed q|k|v
+// GEMM, attention, output projection, dropout-add, LayerNorm, w_1, relu-dropout, w_2, dropout-add and their
+// gradients), each a few microseconds on 1 MB tensors.  Rows (tokens) are independent everywhere except inside the
+// attention kernel, so everything between two attention calls is ONE row-tile kernel here:
+//
+//   tf_rows_kernel<FWD>:  acc = A1 W1^T + b1            (optional GEMM, K1 = 128 .. 2048: output projection or w_2)
+//                         x' = res + dropout(acc)       (stored: the residual stream)
+//                         n  = LayerNorm(x')            (stored for the weight gradients; statistics for the backward)
+//                         out2 = n W2^T + b2            (optional GEMM, N2 = 384: the NEXT attention's packed q|k|v)
+//   tf_rows_kernel<BWD>:  dn = A1 W1                    (optional GEMM: dqkv Wqkv, or dhid W_1 with K1 = 2048)
+//                         dx = LayerNorm'(dn) + addend  (stored; per-workgroup partials of the LayerNorm parameter sums)
+//                         dy = dropout'(dx)             (stored: gradient of the sub-layer output in front of the residual)
+//                         out2 = dy W2                  (optional GEMM, N2 = 128: through the output projection)
+//   tf_ffn1_kernel:       h = dropout(relu(n W_1^T + b_1))   [R, d_ff]   (weights stationary, 64 x 128 tiles)
+//
+// The feed-forward hidden layer's backward mask / data gradient is spacap_linear_dgrad_mask_f32 (sa_mlp.hip), the
+// weight gradients are the batched kernel of sa_mlp.hip (deferred to the end of the backward pass).
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: bit-for-bit an fp32 fma chain), computed transposed
+// (weights as the A operand) so that a lane ends up with consecutive columns of one row.  Operands reach the
+// registers as 16-byte loads through a permutation of k inside every group of 16: lane (l15, lg) loads
+// X[l15][16 q + 4 lg .. + 3] and the i-th MFMA of the group uses element i of both operands.
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int D = 128;        // d_model
+constexpr int BM = 16;        // rows per workgroup of the row kernel
+constexpr int LDT = D + 8;    // LDS row stride of a [rows][128] fp32 tile read with ds_read_b128 (conflict-free)
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ f32x2 ld2(const float *p) { return *reinterpret_cast<const f32x2 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+// ---- dropout keep mask: the counter hash of elementwise.hip (seed word per call + device-resident step counter) ----
+struct DropSeed {
+  unsigned lo, hi;
+};
+__device__ __forceinline__ DropSeed make_seed(unsigned long long seed, const unsigned long long *seed_dev) {
+  const unsigned long long s = seed + (seed_dev ? *seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+  return DropSeed{(unsigned)s, (unsigned)(s >> 32)};
+}
+__device__ __forceinline__ unsigned hash32(unsigned long long idx, DropSeed s) {
+  unsigned h = (unsigned)idx ^ s.lo;
+  h += ((unsigned)(idx >> 32) ^ s.hi) * 0x9E3779B1u;
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+
+struct TfRowsArgs {
+  long R;
+  const float *A1;       // [R][K1], or [nparts][R][128] partial sums of the first product when nparts > 0, or null
+  const float *W1;       // FWD: [128][K1];  BWD: [K1][128]
+  const float *bias1;    // FWD: [128] or null
+  int K1;
+  unsigned drop_thresh;  // 0: no dropout
+  float drop_scale;
+  float eps;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
+  const float *res;      // FWD: residual rows [R][128];  BWD: addend [R][128] or null
+  float *x_out;          // FWD: res + dropout(gemm1) or null;  BWD: dx
+  const float *ln_a, *ln_b;
+  float *n_out;          // FWD: LayerNorm output rows or null;  BWD: dy = dropout'(dx) or null
+  float *stats;          // FWD: out [R][2] (mean, 1 / (std + eps)) or null;  BWD: in
+  const float *x_ln;     // BWD: the rows the LayerNorm normalised
+  const float *G;        // BWD with A1 == null: gradient w.r.t. the LayerNorm output [R][128]
+  float *part;           // BWD: [gridDim.x][256] partial sums of (d ln_a, d ln_b)
+  const float *W2;       // FWD: [N2][128];  BWD: [128][N2 = 128]
+  const float *bias2;    // FWD: [N2] or null
+  float *out2;           // [R][N2]
+  int N2;                // 0: no second product
+  int nparts;            // > 0: A1 holds that many partial results of the first product (added in order), no GEMM here
+};
+
+// Row-tile kernel: see the file header.  256 threads = 4 waves; wave w owns columns [32 w, 32 w + 32) of the
+// 128-wide row through GEMM1 and the row epilogue, and N2 / 4 columns of the second product.
+template <bool BWD>
+__global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
+  __shared__ __attribute__((aligned(16))) float s_t[BM * LDT];
+  __shared__ float s_red[2][4][BM];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long row0 = (long)blockIdx.x * BM, row = row0 + l15;
+  const bool valid = row < P.R;
+  const long rowc = valid ? row : P.R - 1;
+
+  // ---- GEMM1 -> v[g][t]: the lane's 8 values of row l15, two groups of 4 consecutive columns cb[g] .. cb[g] + 3
+  float v[2][4];
+  int cb[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) cb[g] = BWD ? 32 * w + 8 * lg + 4 * g : 32 * w + 16 * g + 4 * lg;
+  if (P.nparts > 0) {
+    // the first product was formed by tf_gemm_kernel as partial sums over slices of k: add them in slice order
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 a = ld4(P.A1 + (size_t)rowc * D + cb[g]);
+      for (int sidx = 1; sidx < P.nparts; ++sidx) a += ld4(P.A1 + ((size_t)sidx * P.R + rowc) * D + cb[g]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[g][t] = a[t];
+    }
+  } else if (P.A1 != nullptr) {
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int K1 = P.K1;
+    const float *ap = P.A1 + (size_t)rowc * K1 + 4 * lg;
+    if (!BWD) {
+      // weights [128][K1]: tile j of the wave = output columns 32 w + 16 j + (0..15)
+      const float *wp0 = P.W1 + (size_t)(32 * w + l15) * K1 + 4 * lg, *wp1 = wp0 + (size_t)16 * K1;
+      // two register sets, loaded one chunk (128 of k) ahead of their use: no copies, so the loads of chunk c + 1 stay in
+      // flight under the MFMAs of chunk c
+      f32x4 a0[8], p0[8], q0[8], a1[8], p1[8], q1[8];
+      auto load = [&](f32x4 *a, f32x4 *x, f32x4 *y, int kc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = ld4(ap + kc + 16 * q), x[q] = ld4(wp0 + kc + 16 * q), y[q] = ld4(wp1 + kc + 16 * q);
+      };
+      auto mma = [&](const f32x4 *a, const f32x4 *x, const f32x4 *y) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0] = MFMA16(x[q][i], a[q][i], acc[0]);
+            acc[1] = MFMA16(y[q][i], a[q][i], acc[1]);
+          }
+      };
+      load(a0, p0, q0, 0);
+      for (int kc = 0; kc < K1; kc += 256) {
+        if (kc + 128 < K1) load(a1, p1, q1, kc + 128);
+        mma(a0, p0, q0);
+        if (kc + 128 < K1) {
+          if (kc + 256 < K1) load(a0, p0, q0, kc + 256);
+          mma(a1, p1, q1);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[g][u] = acc[g][u];
+    } else {
+      // weights [K1][128]: the wave's 32 columns as two interleaved tiles, tile i = columns 32 w + 2 n + i
+      const float *wp = P.W1 + (size_t)(4 * lg) * D + 32 * w + 2 * l15;
+      f32x4 a0[8], a1[8];
+      f32x2 x0[32], x1[32];
+      auto load = [&](f32x4 *a, f32x2 *x, int kc) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a[q] = ld4(ap + kc + 16 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[q * 4 + i] = ld2(wp + (size_t)(kc + 16 * q + i) * D);
+        }
+      };
+      auto mma = [&](const f32x4 *a, const f32x2 *x) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[0] = MFMA16(x[q * 4 + i][0], a[q][i], acc[0]);
+            acc[1] = MFMA16(x[q * 4 + i][1], a[q][i], acc[1]);
+          }
+      };
+      load(a0, x0, 0);
+      for (int kc = 0; kc < K1; kc += 256) {
+        if (kc + 128 < K1) load(a1, x1, kc + 128);
+        mma(a0, x0);
+        if (kc + 128 < K1) {
+          if (kc + 256 < K1) load(a0, x0, kc + 256);
+          mma(a1, x1);
+        }
+      }
+      // acc[i][u] is column 32 w + 2 (4 lg + u) + i = cb[u >> 1] + 2 (u & 1) + i
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u >> 1][2 * (u & 1) + i] = acc[i][u];
+    }
+  }
+
+  const DropSeed sd = make_seed(P.seed, P.seed_dev);
+  float t_out[2][4];   // what the second product consumes: FWD LayerNorm output, BWD dy
+
+  if (!BWD) {
+    // ---- x' = res + dropout(acc + b1);  n = LayerNorm(x') ----------------------------------------------------------
+    float xo[2][4], s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 r4 = ld4(P.res + (size_t)rowc * D + cb[g]);
+      if (P.A1 != nullptr) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (P.bias1) b4 = ld4(P.bias1 + cb[g]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float a = v[g][t] + b4[t];
+          if (P.drop_thresh != 0u) {
+            const bool keep = hash32((unsigned long long)row * D + cb[g] + t, sd) >= P.drop_thresh;
+            a = keep ? a * P.drop_scale : 0.f;
+          }
+          xo[g][t] = r4[t] + a;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xo[g][t] = r4[t];
+      }
+      if (P.x_out && valid) st4(P.x_out + (size_t)row * D + cb[g], f32x4{xo[g][0], xo[g][1], xo[g][2], xo[g][3]});
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s += xo[g][t];
+    }
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lg == 0) s_red[0][w][l15] = s;
+    __syncthreads();
+    const float mu = ((s_red[0][0][l15] + s_red[0][1][l15]) + (s_red[0][2][l15] + s_red[0][3][l15])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float c = xo[g][t] - mu;
+        q += c * c;
+      }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (lg == 0) s_red[1][w][l15] = q;
+    __syncthreads();
+    const float var = ((s_red[1][0][l15] + s_red[1][1][l15]) + (s_red[1][2][l15] + s_red[1][3][l15])) / (float)(D - 1);
+    const float r = 1.0f / (sqrtf(var) + P.eps);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 a4 = ld4(P.ln_a + cb[g]), b4 = ld4(P.ln_b + cb[g]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) t_out[g][t] = a4[t] * ((xo[g][t] - mu) * r) + b4[t];
+      if (P.n_out && valid)
+        st4(P.n_out + (size_t)row * D + cb[g], f32x4{t_out[g][0], t_out[g][1], t_out[g][2], t_out[g][3]});
+    }
+    if (P.stats && valid && w == 0 && lg == 0) {
+      P.stats[row * 2] = mu;
+      P.stats[row * 2 + 1] = r;
+    }
+  } else {
+    // ---- dx = LayerNorm'(dn) + addend;  partial sums of the LayerNorm parameter gradients;  dy = dropout'(dx) -----
+    const float mu = P.stats[rowc * 2], r = P.stats[rowc * 2 + 1];
+    float dn[2][4], xc[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      if (P.A1 == nullptr) {
+        const f32x4 g4 = ld4(P.G + (size_t)rowc * D + cb[g]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[g][t] = g4[t];
+      }
+      const f32x4 x4 = ld4(P.x_ln + (size_t)rowc * D + cb[g]), a4 = ld4(P.ln_a + cb[g]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dn[g][t] = valid ? v[g][t] : 0.f;
+        xc[g][t] = x4[t] - mu;
+        dxh[g][t] = dn[g][t] * a4[t];
+        s1 += dxh[g][t];
+        s2 += dxh[g][t] * xc[g][t];
+      }
+    }
+    s1 += __shfl_xor(s1, 16);
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    if (lg == 0) s_red[0][w][l15] = s1, s_red[1][w][l15] = s2;
+    __syncthreads();
+    s1 = (s_red[0][0][l15] + s_red[0][1][l15]) + (s_red[0][2][l15] + s_red[0][3][l15]);
+    s2 = (s_red[1][0][l15] + s_red[1][1][l15]) + (s_red[1][2][l15] + s_red[1][3][l15]);
+    const float sdv = 1.0f / r - P.eps;                            // the unbiased std
+    const float c2 = -(s2 * r * r) / (sdv * (float)(D - 1));      // 0/0 = NaN on a constant row, as autograd gives
+    const float c1 = r * s1 / (float)D;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+      if (P.res) ad = ld4(P.res + (size_t)rowc * D + cb[g]);
+      float dx[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        dx[t] = r * dxh[g][t] + c2 * xc[g][t] - c1 + ad[t];
+        float y = dx[t];
+        if (P.drop_thresh != 0u) {
+          const bool keep = hash32((unsigned long long)row * D + cb[g] + t, sd) >= P.drop_thresh;
+          y = keep ? y * P.drop_scale : 0.f;
+        }
+        t_out[g][t] = valid ? y : 0.f;
+      }
+      if (valid) {
+        st4(P.x_out + (size_t)row * D + cb[g], f32x4{dx[0], dx[1], dx[2], dx[3]});
+        if (P.n_out) st4(P.n_out + (size_t)row * D + cb[g], f32x4{t_out[g][0], t_out[g][1], t_out[g][2], t_out[g][3]});
+      }
+      // column sums over the 16 rows of the tile (lanes l15 = 0..15 of one lg), fixed tree order
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float pa = dn[g][t] * (xc[g][t] * r), pb = dn[g][t];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          pa += __shfl_xor(pa, o);
+          pb += __shfl_xor(pb, o);
+        }
+        if (l15 == 0) {
+          P.part[(size_t)blockIdx.x * 2 * D + cb[g] + t] = pa;
+          P.part[(size_t)blockIdx.x * 2 * D + D + cb[g] + t] = pb;
+        }
+      }
+    }
+  }
+
+  if (P.N2 == 0) return;   // (uniform: kernel argument)
+
+  // ---- second product on the rows just formed -------------------------------------------------------------------------
+#pragma unroll
+  for (int g = 0; g < 2; ++g) st4(&s_t[l15 * LDT + cb[g]], f32x4{t_out[g][0], t_out[g][1], t_out[g][2], t_out[g][3]});
+  __syncthreads();
+  f32x4 at[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) at[q] = ld4(&s_t[l15 * LDT + 16 * q + 4 * lg]);
+  if (!BWD) {
+    // W2 [N2][128], N2 a multiple of 128: the wave's N2 / 4 columns in pairs of 16-column tiles
+    const int N2 = P.N2, nw = N2 >> 2, n00 = w * nw;
+    const float *wp = P.W2 + (size_t)(n00 + l15) * D + 4 * lg;
+    f32x4 w0[8], w1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w0[q] = ld4(wp + 16 * q), w1[q] = ld4(wp + 16 * D + 16 * q);
+    for (int jt = 0; jt < nw; jt += 32) {
+      f32x4 w0n[8], w1n[8];
+      const bool more = jt + 32 < nw;
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          w0n[q] = ld4(wp + (size_t)(jt + 32) * D + 16 * q);
+          w1n[q] = ld4(wp + (size_t)(jt + 48) * D + 16 * q);
+        }
+      }
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc0 = MFMA16(w0[q][i], at[q][i], acc0);
+          acc1 = MFMA16(w1[q][i], at[q][i], acc1);
+        }
+      const int c0 = n00 + jt + 4 * lg;
+      if (P.bias2) acc0 += ld4(P.bias2 + c0), acc1 += ld4(P.bias2 + c0 + 16);
+      if (valid) {
+        st4(P.out2 + (size_t)row * N2 + c0, acc0);
+        st4(P.out2 + (size_t)row * N2 + c0 + 16, acc1);
+      }
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w0[q] = w0n[q], w1[q] = w1n[q];
+      }
+    }
+  } else {
+    // W2 [128][128] (N2 == 128): out2 = dy W2, the wave's 32 columns as two interleaved tiles
+    const float *wp = P.W2 + (size_t)(4 * lg) * D + 32 * w + 2 * l15;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 wv = ld2(wp + (size_t)(16 * q + i) * D);
+        acc[0] = MFMA16(wv[0], at[q][i], acc[0]);
+        acc[1] = MFMA16(wv[1], at[q][i], acc[1]);
+      }
+    if (valid) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        // columns cb[g] + e: e = 2 (u & 1) + i with u >> 1 == g
+        const f32x4 o = {acc[0][2 * g], acc[1][2 * g], acc[0][2 * g + 1], acc[1][2 * g + 1]};
+        st4(P.out2 + (size_t)row * D + cb[g], o);
+      }
+    }
+  }
+}
+
+// Tiled product with the weights stationary in registers and a choice of epilogue (fp32 MFMA, 64-row x 128-column tile
+// per workgroup, K walked in chunks of 128 through LDS; blockIdx.z = slice of K for the split products):
+//   EPI 0  out[z][r][n] = sum_{k in slice z} x[r][k] Wop[k][n]            partial sums, added in order by tf_rows_kernel
+//          (w_2 / the data gradient through w_1: K = d_ff = 2 048 and only 128 output columns -- a row-tile kernel alone would
+//          occupy R / 16 workgroups for 2 048 dependent k-steps each; split over K the product fills the chip)
+//   EPI 1  out[r][n] = dropout(relu(. + bias[n]))                          models/transformer_captioner.py:80 (w_1)
+//   EPI 2  out[r][n] = y[r][n] > 0 ? scale * . : 0                         backward of EPI 1 through w_2 (y = the saved EPI-1 output)
+// NN: Wop[k][n] = W[k][n] (W [K][ldw >= N]: data gradients), else Wop[k][n] = W[n][k] (W [N][ldw >= K]: forward products).
+constexpr int FM = 64;
+struct TfGemmArgs {
+  const float *x, *W, *bias, *y;
+  float *out;
+  long R;
+  int ldx, ldw, N, KS;
+  unsigned thresh;
+  float scale;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
+};
+template <int EPI, bool NN>
+__global__ __launch_bounds__(256) void tf_gemm_kernel(const TfGemmArgs P) {
+  __shared__ __attribute__((aligned(16))) float s_a[FM * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long row0 = (long)blockIdx.x * FM;
+  const int n0 = blockIdx.y * 128 + 32 * w;
+  const int k0 = blockIdx.z * P.KS;
+  const int c4 = tid & 31, r0 = tid >> 5;
+  f32x4 acc[FM / 16][2];
+#pragma unroll
+  for (int mt = 0; mt < FM / 16; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = k0; kc < k0 + P.KS; kc += 128) {
+    if (kc != k0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM / 8; ++i) {
+      const int rr = r0 + 8 * i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + rr < P.R) a = ld4(P.x + (size_t)(row0 + rr) * P.ldx + kc + c4 * 4);
+      st4(&s_a[rr * LDT + c4 * 4], a);
+    }
+    f32x4 w0[8], w1[8];   // NN: w0[q][i] / w1[q][i] = the two interleaved tiles' weights for k = kc + 16 q + 4 lg + i
+    if (!NN) {
+      const float *wp = P.W + (size_t)(n0 + l15) * P.ldw + kc + 4 * lg;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) w0[q] = ld4(wp + 16 * q), w1[q] = ld4(wp + (size_t)16 * P.ldw + 16 * q);
+    } else {
+      const float *wp = P.W + (size_t)(kc + 4 * lg) * P.ldw + n0 + 2 * l15;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x2 t = ld2(wp + (size_t)(16 * q + i) * P.ldw);
+          w0[q][i] = t[0], w1[q][i] = t[1];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < FM / 16; ++mt)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 a = ld4(&s_a[(mt * 16 + l15) * LDT + 16 * q + 4 * lg]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[mt][0] = MFMA16(w0[q][i], a[i], acc[mt][0]);
+          acc[mt][1] = MFMA16(w1[q][i], a[i], acc[mt][1]);
+        }
+      }
+  }
+  // the lane's columns of row (mt, l15): two runs of four, starting at c0 and c1
+  const int c0 = NN ? n0 + 8 * lg : n0 + 4 * lg, c1 = NN ? c0 + 4 : c0 + 16;
+  f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+  if (EPI == 1 && P.bias) b0 = ld4(P.bias + c0), b1 = ld4(P.bias + c1);
+  const DropSeed sd = make_seed(P.seed, P.seed_dev);
+  float *out = P.out + (EPI == 0 ? (size_t)blockIdx.z * P.R * P.N : (size_t)0);
+#pragma unroll
+  for (int mt = 0; mt < FM / 16; ++mt) {
+    const long row = row0 + mt * 16 + l15;
+    if (row >= P.R) continue;
+    f32x4 o0, o1;
+    if (NN) {
+      o0 = f32x4{acc[mt][0][0], acc[mt][1][0], acc[mt][0][1], acc[mt][1][1]};
+      o1 = f32x4{acc[mt][0][2], acc[mt][1][2], acc[mt][0][3], acc[mt][1][3]};
+    } else {
+      o0 = acc[mt][0], o1 = acc[mt][1];
+    }
+    if (EPI == 1) {
+      o0 += b0, o1 += b1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a0 = fmaxf(o0[u], 0.f), a1 = fmaxf(o1[u], 0.f);
+        if (P.thresh != 0u) {
+          const unsigned long long e = (unsigned long long)row * P.N;
+          a0 = hash32(e + c0 + u, sd) >= P.thresh ? a0 * P.scale : 0.f;
+          a1 = hash32(e + c1 + u, sd) >= P.thresh ? a1 * P.scale : 0.f;
+        }
+        o0[u] = a0, o1[u] = a1;
+      }
+    } else if (EPI == 2) {
+      const f32x4 y0 = ld4(P.y + (size_t)row * P.N + c0), y1 = ld4(P.y + (size_t)row * P.N + c1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o0[u] = y0[u] > 0.f ? o0[u] * P.scale : 0.f;
+        o1[u] = y1[u] > 0.f ? o1[u] * P.scale : 0.f;
+      }
+    }
+    st4(out + (size_t)row * P.N + c0, o0);
+    st4(out + (size_t)row * P.N + c1, o1);
+  }
+}
+
+inline bool drop_params(float p, unsigned &thresh, float &scale) {
+  if (!(p >= 0.f && p < 1.f)) return false;
+  thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  scale = 1.0f / (1.0f - p);
+  return true;
+}
+inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int spacap_tf_rows_f32(const spacap_tf_rows_args *a, spacap_stream_t stream) {
+  const char *what = "spacap_tf_rows_f32";
+  SPACAP_REQUIRE(a != nullptr, "%s: null argument block", what);
+  SPACAP_REQUIRE(a->R >= 0 && (a->mode == 0 || a->mode == 1), "%s: bad R / mode", what);
+  if (a->R == 0) return SPACAP_OK;
+  TfRowsArgs P;
+  P.R = a->R;
+  P.A1 = a->a1, P.W1 = a->w1, P.bias1 = a->bias1, P.K1 = a->k1;
+  SPACAP_REQUIRE(drop_params(a->drop_p, P.drop_thresh, P.drop_scale), "%s: bad dropout probability %f", what, (double)a->drop_p);
+  P.eps = a->eps, P.seed = a->seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(a->seed_dev);
+  P.res = a->res, P.x_out = a->x_out, P.ln_a = a->ln_a, P.ln_b = a->ln_b, P.n_out = a->n_out, P.stats = a->stats;
+  P.x_ln = a->x_ln, P.G = a->g, P.part = a->part, P.W2 = a->w2, P.bias2 = a->bias2, P.out2 = a->out2, P.N2 = a->n2;
+  P.nparts = a->nparts;
+  SPACAP_REQUIRE(P.nparts >= 0 && (P.nparts == 0 || P.A1), "%s: nparts = %d needs the partial sums in a1", what, P.nparts);
+  const bool bwd = a->mode == 1;
+  if (P.A1 && P.nparts == 0) SPACAP_REQUIRE(P.W1 && P.K1 >= 128 && P.K1 % 128 == 0, "%s: first product needs weights and K1 a multiple of 128 (K1=%d)", what, P.K1);
+  SPACAP_REQUIRE(P.ln_a && (bwd || P.ln_b), "%s: LayerNorm parameters missing", what);
+  if (!bwd) {
+    SPACAP_REQUIRE(P.res, "%s: forward needs the residual rows", what);
+    SPACAP_REQUIRE(P.N2 == 0 || (P.N2 % 128 == 0 && P.W2 && P.out2), "%s: N2=%d unsupported (multiple of 128) or null pointer", what, P.N2);
+  } else {
+    SPACAP_REQUIRE(P.A1 || P.G, "%s: backward needs a1 or g", what);
+    SPACAP_REQUIRE(P.x_ln && P.stats && P.x_out && P.part, "%s: backward needs x_ln, stats, x_out (dx) and part", what);
+    SPACAP_REQUIRE(P.N2 == 0 || (P.N2 == 128 && P.W2 && P.out2), "%s: backward N2 must be 0 or 128", what);
+  }
+  SPACAP_REQUIRE(al16(P.A1) && al16(P.W1) && al16(P.bias1) && al16(P.res) && al16(P.x_out) && al16(P.ln_a) && al16(P.ln_b) &&
+                     al16(P.n_out) && al16(P.x_ln) && al16(P.G) && al16(P.W2) && al16(P.bias2) && al16(P.out2),
+                 "%s: pointers must be 16-byte aligned", what);
+  const long tiles = (P.R + BM - 1) / BM;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  hipStream_t s = spacap::as_stream(stream);
+  if (bwd) hipLaunchKernelGGL((tf_rows_kernel<true>), dim3((unsigned)tiles), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((tf_rows_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, s, P);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_tf_rows_parts(long R) { return (int)((R + BM - 1) / BM); }
+
+namespace {
+template <int EPI>
+int launch_gemm(const char *what, const TfGemmArgs &P, bool nn, long R, int N, int nsplit, hipStream_t s) {
+  const long tiles = (R + FM - 1) / FM;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)tiles, N / 128, nsplit);
+  if (nn) hipLaunchKernelGGL((tf_gemm_kernel<EPI, true>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((tf_gemm_kernel<EPI, false>), grid, dim3(256), 0, s, P);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+}  // namespace
+
+extern "C" int spacap_tf_ffn1_f32(const float *x, const float *W, const float *bias, long R, int N, float drop_p, uint64_t seed,
+                                  const uint64_t *seed_dev, float *h, spacap_stream_t stream) {
+  const char *what = "spacap_tf_ffn1_f32";
+  TfGemmArgs P = {};
+  SPACAP_REQUIRE(R >= 0 && N >= 128 && N % 128 == 0 && drop_params(drop_p, P.thresh, P.scale), "%s: (R=%ld, N=%d, p=%f) unsupported",
+                 what, R, N, (double)drop_p);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(x && W && h && al16(x) && al16(W) && al16(bias) && al16(h), "%s: null or unaligned pointer", what);
+  P.x = x, P.W = W, P.bias = bias, P.out = h, P.R = R, P.ldx = D, P.ldw = D, P.N = N, P.KS = D;
+  P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
+  return launch_gemm<1>(what, P, false, R, N, 1, spacap::as_stream(stream));
+}
+
+// number of K slices that fills the chip with 64 x 128 tiles (a divisor of K / 128)
+extern "C" int spacap_tf_gemm_splits(long R, int K, int N) {
+  if (R < 1 || K < 128 || K % 128 || N < 128 || N % 128) return 0;
+  const long tiles = ((R + FM - 1) / FM) * (N / 128);
+  const int chunks = K / 128;
+  long want = 512 / tiles;
+  if (want < 1) want = 1;
+  int best = 1;
+  for (int sidx = 1; sidx <= chunks; ++sidx)
+    if (chunks % sidx == 0 && sidx <= want) best = sidx;
+  return best;
+}
+
+extern "C" int spacap_tf_gemm_f32(const float *a, const float *W, long R, int K, int N, int trans_w, int nsplit, float *out,
+                                  spacap_stream_t stream) {
+  const char *what = "spacap_tf_gemm_f32";
+  SPACAP_REQUIRE(R >= 0 && K >= 128 && K % 128 == 0 && N >= 128 && N % 128 == 0 && nsplit >= 1 && (K / 128) % nsplit == 0,
+                 "%s: (R=%ld, K=%d, N=%d, nsplit=%d) unsupported", what, R, K, N, nsplit);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(a && W && out && al16(a) && al16(W) && al16(out), "%s: null or unaligned pointer", what);
+  TfGemmArgs P = {};
+  P.x = a, P.W = W, P.out = out, P.R = R, P.ldx = K, P.ldw = trans_w ? K : N, P.N = N, P.KS = K / nsplit;
+  return launch_gemm<0>(what, P, !trans_w, R, N, nsplit, spacap::as_stream(stream));
+}
+
+extern "C" int spacap_tf_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int K, int N,
+                                        float *out, spacap_stream_t stream) {
+  const char *what = "spacap_tf_dgrad_mask_f32";
+  SPACAP_REQUIRE(R >= 0 && K == 128 && N >= 128 && N % 128 == 0, "%s: (R=%ld, K=%d, N=%d) unsupported", what, R, K, N);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(g && W && y && out && al16(g) && al16(W) && al16(y) && al16(out), "%s: null or unaligned pointer", what);
+  TfGemmArgs P = {};
+  P.x = g, P.W = W, P.y = y, P.out = out, P.R = R, P.ldx = K, P.ldw = N, P.N = N, P.KS = K, P.scale = scale;
+  return launch_gemm<2>(what, P, true, R, N, 1, spacap::as_stream(stream));
+}

@@ -1,0 +1,318 @@
+"""Fused Transformer sub-layers (csrc/tf_layer.hip) as autograd nodes -- everything BETWEEN two attention calls of an
+encoder / decoder stack is one launch (models/transformer_captioner.py: SublayerConnection :115-127, LayerNorm :102-113,
+PositionwiseFeedForward :72-81, the output / packed q|k|v projections of MultiHeadedAttention :52-70, EncoderLayer
+:180-191, DecoderLayer :209-225 in early-guide mode).
+
+Per layer, forward:   attention -> [out-proj + dropout-add + LayerNorm] -> [w_1 + relu + dropout] ->
+                      [w_2 + dropout-add + LayerNorm of the NEXT layer + its packed q|k|v projection]
+          backward:   [dqkv Wqkv + LayerNorm' + residual + dropout'] -> [(. W_2) * relu/dropout mask] ->
+                      [dhid W_1 + LayerNorm' + residual + dropout' + (. Wo)] -> attention backward (two launches)
+The weight / bias / LayerNorm-parameter gradients are queued on the step's deferred batch (``_native.deferred_slab_sums``).
+
+Node boundaries follow the BACKWARD kernels.  One private contract: the second output of ``AttnOutFfn1`` (the hidden
+activations h) is consumed only by ``Ffn2Ln``, whose backward hands back the gradient w.r.t. the hidden layer's
+PRE-activation (relu / dropout mask already applied, one fused launch); ``AttnOutFfn1.backward`` expects exactly that.
+"""
+import ctypes
+import os
+
+import torch
+from torch.autograd import Function
+
+from ._native import TfRowsArgs, check, grad_slot, lib, linear_wgrad_partials, sum_slabs
+
+D_MODEL = 128
+# tests / A-B measurements switch the fused stacks off here (the per-operator path of transformer_captioner.py then runs)
+ENABLED = os.environ.get("SPACAP_TF_FUSED", "1") != "0"   # (A/B runs of bench.py)
+
+
+def supported(d_model, d_ff):
+    return d_model == D_MODEL and d_ff >= 128 and d_ff % 128 == 0
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _rows(mode, R, dev, **kw):
+    """One launch of the row-tile kernel (include/spacap_hip.h: spacap_tf_rows_args); tensors by keyword."""
+    a = TfRowsArgs()
+    a.mode, a.R = mode, R
+    a.k1 = int(kw.pop("k1", 0))
+    a.n2 = int(kw.pop("n2", 0))
+    a.nparts = int(kw.pop("nparts", 0))
+    a.drop_p = float(kw.pop("drop_p", 0.0))
+    a.eps = float(kw.pop("eps", 1e-6))
+    a.seed = int(kw.pop("seed", 0))
+    a.seed_dev = None
+    if a.drop_p > 0.0:
+        from .attention import rng_state
+        a.seed_dev = rng_state(dev).data_ptr()
+    for k, v in kw.items():
+        setattr(a, k, _p(v))
+    check(lib.spacap_tf_rows_f32(ctypes.byref(a), torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_rows_f32")
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+def _parts(dev, R):
+    return _new(dev, int(lib.spacap_tf_rows_parts(R)), 2 * D_MODEL)
+
+
+def _split_product(a2, W, trans_w):
+    """Partial sums over slices of k of a2 W^T (trans_w, W [128, K]) or a2 W (W [K, 128]) for a2 (R, K), K > 128:
+    (parts (S, R, 128), S) -- the row kernel adds the slices in order (``nparts``).  The row kernel alone would run this
+    product on R / 16 workgroups with K / 4 dependent steps each; split over K it fills the chip."""
+    R, K = a2.shape
+    dev = a2.device
+    S = int(lib.spacap_tf_gemm_splits(R, K, D_MODEL))
+    parts = _new(dev, S, R, D_MODEL)
+    check(lib.spacap_tf_gemm_f32(a2.data_ptr(), W.data_ptr(), R, K, D_MODEL, 1 if trans_w else 0, S, parts.data_ptr(),
+                                 torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_gemm_f32")
+    return parts, S
+
+
+def _ln_param_grads(part):
+    s = sum_slabs(part, deferrable=True)
+    return s[:D_MODEL], s[D_MODEL:]
+
+
+def _linear_grads(g2, x2, weight):
+    """(dW, db) of y = x W^T + b from g2 (R, CK), x2 (R, CP): the batched weight-gradient kernel + one slab sum."""
+    CK, CP = g2.shape[1], x2.shape[1]
+    part = linear_wgrad_partials(g2, x2, True, deferrable=True)
+    if part is None:
+        return g2.t() @ x2, g2.sum(0)
+    s = sum_slabs(part, deferrable=True, out=grad_slot(weight, CK * CP + CK))
+    return s[:CK * CP].view(CK, CP), s[CK * CP:]
+
+
+def _route_qkv(dw, db, rows):
+    """gradients of the packed (3 d, d) weight / (3 d) bias as slices for the three nn.Linear parameters."""
+    a, b = rows[0], rows[0] + rows[1]
+    return (dw[:a], dw[a:b], dw[b:], db[:a], db[a:b], db[b:])
+
+
+class LnQkv(Function):
+    """(qkv, x) = (LayerNorm(x) Wqkv^T + bqkv, x): the FIRST layer's norm + packed projection.  The second output is x
+    itself, to be used as the residual operand, so that both gradient paths into x arrive here and the backward kernel
+    adds them while it writes dx.  ``routing`` = the three weights and three biases ``pw`` / ``pb`` are views over (so
+    that autograd hands them their slices), or nothing when ``pw`` / ``pb`` take the gradient themselves."""
+
+    @staticmethod
+    def forward(ctx, x, ln_a, ln_b, eps, pw, pb, *routing):
+        if not x.is_cuda:
+            raise RuntimeError("CPU not supported")
+        xc = x.contiguous()
+        R, dev = xc.numel() // D_MODEL, xc.device
+        N2 = pw.shape[0]
+        with torch.cuda.device(dev):
+            qkv, n, stats = _new(dev, *xc.shape[:-1], N2), _new(dev, R, D_MODEL), _new(dev, R, 2)
+            _rows(0, R, dev, res=xc, ln_a=ln_a, ln_b=ln_b, eps=eps, n_out=n, stats=stats, w2=pw, bias2=pb, n2=N2, out2=qkv)
+        ctx.save_for_backward(xc, ln_a, n, stats, pw)
+        ctx.eps = float(eps)
+        ctx.rows = [int(r.shape[0]) for r in routing[:3]]
+        ctx.set_materialize_grads(False)
+        return qkv, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, dqkv, dres):
+        xc, ln_a, n, stats, pw = ctx.saved_tensors
+        R, dev = xc.numel() // D_MODEL, xc.device
+        nrout = 6 if ctx.rows else 0
+        if dqkv is None:
+            return (dres,) + (None,) * (5 + nrout)
+        g2 = dqkv.reshape(R, -1).contiguous()
+        with torch.cuda.device(dev):
+            dx, part = _new(dev, *xc.shape), _parts(dev, R)
+            _rows(1, R, dev, a1=g2, w1=pw, k1=g2.shape[1], x_ln=xc, stats=stats, ln_a=ln_a, eps=ctx.eps,
+                  res=dres.contiguous() if dres is not None else None, x_out=dx, part=part)
+            da, db = _ln_param_grads(part)
+            dw, dbias = _linear_grads(g2, n, pw)
+        if ctx.rows:
+            return (dx, da, db, None, None, None) + _route_qkv(dw, dbias, ctx.rows)
+        return dx, da, db, None, dw, dbias
+
+
+class AttnOutFfn1(Function):
+    """(x1, h):  x1 = x + dropout(a Wo^T + bo);  h = dropout(relu(LayerNorm(x1) W1^T + b1)).
+    backward(g_x1, g_hpre): ``g_hpre`` is the gradient w.r.t. the hidden PRE-activation (see the module docstring)."""
+
+    @staticmethod
+    def forward(ctx, a, xres, Wo, bo, ln_a, ln_b, W1, b1, eps, p_sub, p_ffn, seed1, seed2):
+        if not a.is_cuda:
+            raise RuntimeError("CPU not supported")
+        ac, xr = a.contiguous(), xres.contiguous()
+        R, dev = xr.numel() // D_MODEL, xr.device
+        dff = W1.shape[0]
+        with torch.cuda.device(dev):
+            x1, n2, stats = _new(dev, *xr.shape), _new(dev, R, D_MODEL), _new(dev, R, 2)
+            _rows(0, R, dev, a1=ac, w1=Wo, bias1=bo, k1=D_MODEL, drop_p=p_sub, seed=seed1, res=xr, x_out=x1, ln_a=ln_a,
+                  ln_b=ln_b, eps=eps, n_out=n2, stats=stats)
+            h = _new(dev, *xr.shape[:-1], dff)
+            from .attention import rng_state
+            check(lib.spacap_tf_ffn1_f32(n2.data_ptr(), W1.data_ptr(), b1.data_ptr(), R, dff, float(p_ffn), int(seed2),
+                                         rng_state(dev).data_ptr() if p_ffn > 0.0 else None, h.data_ptr(),
+                                         torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_ffn1_f32")
+        ctx.save_for_backward(ac, x1, n2, stats, ln_a, Wo, W1)
+        ctx.meta = (float(eps), float(p_sub), int(seed1))
+        ctx.set_materialize_grads(False)
+        return x1, h
+
+    @staticmethod
+    def backward(ctx, g_x1, g_hpre):
+        ac, x1, n2, stats, ln_a, Wo, W1 = ctx.saved_tensors
+        eps, p_sub, seed1 = ctx.meta
+        R, dev = x1.numel() // D_MODEL, x1.device
+        dff = W1.shape[0]
+        with torch.cuda.device(dev):
+            dx1, dy1, da, part = _new(dev, *x1.shape), _new(dev, R, D_MODEL), _new(dev, *ac.shape), _parts(dev, R)
+            kw = dict(x_ln=x1, stats=stats, ln_a=ln_a, eps=eps, res=g_x1.contiguous() if g_x1 is not None else None,
+                      x_out=dx1, part=part, drop_p=p_sub, seed=seed1, n_out=dy1, w2=Wo, n2=D_MODEL, out2=da)
+            dW1 = db1 = None
+            if g_hpre is not None:
+                gh = g_hpre.reshape(R, dff).contiguous()
+                parts, S = _split_product(gh, W1, False)
+                _rows(1, R, dev, a1=parts, nparts=S, **kw)
+                dW1, db1 = _linear_grads(gh, n2, W1)
+            else:   # the hidden layer was not used downstream: only the residual path carries a gradient
+                _rows(1, R, dev, g=torch.zeros(R, D_MODEL, dtype=torch.float32, device=dev), **kw)
+            dln_a, dln_b = _ln_param_grads(part)
+            dWo, dbo = _linear_grads(dy1, ac.reshape(R, D_MODEL), Wo)
+        return da, dx1, dWo, dbo, dln_a, dln_b, dW1, db1, None, None, None, None, None
+
+
+class Ffn2Ln(Function):
+    """x2 = x1 + dropout(h W2^T + b2);  n = LayerNorm(x2) with the NEXT layer's (or the stack's final) norm;
+    returns (x2, n Wqkv^T + bqkv) -- or (n,) when ``pw`` is None (last layer: n is the stack's output).
+    The gradient returned for h is the one w.r.t. the hidden pre-activation (see the module docstring): ``p_ffn`` is the
+    hidden layer's dropout probability, whose scale that mask needs."""
+
+    @staticmethod
+    def forward(ctx, h, x1, W2, b2, ln_a, ln_b, eps, p_sub, p_ffn, seed3, pw, pb, *routing):
+        if not h.is_cuda:
+            raise RuntimeError("CPU not supported")
+        hc, xr = h.contiguous(), x1.contiguous()
+        R, dev = xr.numel() // D_MODEL, xr.device
+        dff = W2.shape[1]
+        last = pw is None
+        with torch.cuda.device(dev):
+            x2, n, stats = _new(dev, *xr.shape), _new(dev, *xr.shape), _new(dev, R, 2)
+            parts, S = _split_product(hc.reshape(R, dff), W2, True)
+            kw = dict(a1=parts, nparts=S, bias1=b2, drop_p=p_sub, seed=seed3, res=xr, x_out=x2, ln_a=ln_a, ln_b=ln_b, eps=eps,
+                      n_out=n, stats=stats)
+            qkv = None
+            if not last:
+                qkv = _new(dev, *xr.shape[:-1], pw.shape[0])
+                kw.update(w2=pw, bias2=pb, n2=pw.shape[0], out2=qkv)
+            _rows(0, R, dev, **kw)
+        ctx.save_for_backward(hc, x2, n, stats, ln_a, W2, pw)
+        ctx.meta = (float(eps), float(p_sub), float(p_ffn), int(seed3), last, [int(r.shape[0]) for r in routing[:3]])
+        ctx.set_materialize_grads(False)
+        return (n,) if last else (x2, qkv)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        hc, x2, n, stats, ln_a, W2, pw = ctx.saved_tensors
+        eps, p_sub, p_ffn, seed3, last, rows = ctx.meta
+        R, dev = x2.numel() // D_MODEL, x2.device
+        dff = W2.shape[1]
+        with torch.cuda.device(dev):
+            dx2, dy2, part = _new(dev, *x2.shape), _new(dev, R, D_MODEL), _parts(dev, R)
+            kw = dict(x_ln=x2, stats=stats, ln_a=ln_a, eps=eps, x_out=dx2, part=part, drop_p=p_sub, seed=seed3, n_out=dy2)
+            dw = dbias = None
+            if last:
+                g_mem = grads[0]
+                _rows(1, R, dev, g=g_mem.contiguous() if g_mem is not None else torch.zeros_like(x2), **kw)
+            else:
+                g_x2, dqkv = grads
+                gx = g_x2.contiguous() if g_x2 is not None else None
+                if dqkv is not None:
+                    g2 = dqkv.reshape(R, -1).contiguous()
+                    _rows(1, R, dev, a1=g2, w1=pw, k1=g2.shape[1], res=gx, **kw)
+                    dw, dbias = _linear_grads(g2, n.reshape(R, D_MODEL), pw)
+                else:
+                    _rows(1, R, dev, g=torch.zeros_like(x2), res=gx, **kw)
+            dln_a, dln_b = _ln_param_grads(part)
+            dh = _new(dev, *hc.shape)   # (dy2 W2) where the hidden unit was active and kept, scaled by the hidden dropout
+            check(lib.spacap_linear_dgrad_mask_f32(dy2.data_ptr(), W2.data_ptr(), hc.data_ptr(), 1.0 / (1.0 - p_ffn), R, D_MODEL,
+                                                   dff, dh.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_linear_dgrad_mask_f32")
+            dW2, db2 = _linear_grads(dy2, hc.reshape(R, dff), W2)
+        head = (dh, dx2, dW2, db2, dln_a, dln_b, None, None, None, None)
+        if last:
+            return head + (None, None)
+        if rows:
+            return head + (None, None) + _route_qkv(dw, dbias, rows)
+        return head + (dw, dbias)
+
+
+# ---- a whole stack ---------------------------------------------------------------------------------------------------
+
+def _packed(attn):
+    """(packed_w (3d, d), packed_b (3d), routing): views over the flat optimizer buffer when the Trainer laid the three
+    projections out back to back (spacap3d_amd/engine.py), else a concatenation that takes the gradient itself."""
+    pk = getattr(attn, "_packed_qkv", None)
+    lin = attn.linears
+    if pk is not None and pk[0].data_ptr() == lin[0].weight.data_ptr():
+        return pk[0], pk[1], tuple(l.weight for l in lin[:3]) + tuple(l.bias for l in lin[:3])
+    return torch.cat([l.weight for l in lin[:3]], 0), torch.cat([l.bias for l in lin[:3]], 0), ()
+
+
+def stack_supported(layers, x):
+    """True when ``run_stack`` can run these layers: float32 CUDA rows of width 128, feed-forward width a multiple of 128,
+    self-attention + feed-forward sub-layers only (encoder layers, or decoder layers in early-guide mode), contiguous
+    parameters."""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == D_MODEL and len(layers) > 0):
+        return False
+    for l in layers:
+        ff, sa = l.feed_forward, l.self_attn
+        if getattr(l, "early_guide", True) is not True or sa.h * sa.d_k != D_MODEL:
+            return False
+        if not supported(ff.w_1.in_features, ff.w_1.out_features) or ff.w_2.bias is None or ff.w_1.bias is None:
+            return False
+        if any(li.bias is None or not li.weight.is_contiguous() for li in sa.linears):
+            return False
+    return True
+
+
+def run_stack(layers, final_norm, x, mask):
+    """The N pre-norm layers (self-attention + feed-forward each) followed by ``final_norm``
+    (models/transformer_captioner.py: Encoder :166-178 / Decoder :193-207 in early-guide mode)."""
+    from .attention import _next_seed, self_attention_packed
+
+    def drop(m):
+        return float(m.p) if m.training else 0.0
+
+    def seed(p):
+        return _next_seed() if p > 0.0 else 0
+
+    sub = lambda l: (l.sublayer[0], l.sublayer[-1])
+    l0 = layers[0]
+    pw, pb, routing = _packed(l0.self_attn)
+    qkv, xres = LnQkv.apply(x, l0.sublayer[0].norm.a_2, l0.sublayer[0].norm.b_2, l0.sublayer[0].norm.eps, pw, pb, *routing)
+    out = None
+    for i, l in enumerate(layers):
+        sa, ff = l.self_attn, l.feed_forward
+        s_att, s_ffn = sub(l)
+        need_p = sa.keep_value if sa.store_attn is None else (sa.store_attn or sa.keep_value)
+        a, sa.attn = self_attention_packed(qkv, sa.h, mask=mask, dropout_p=sa.dropout.p, training=sa.dropout.training,
+                                           need_p=need_p)
+        if sa.keep_value:
+            hd = sa.h * sa.d_k
+            sa.value = qkv[..., 2 * hd:].view(qkv.shape[0], -1, sa.h, sa.d_k).transpose(1, 2)
+        p1, pf, p3 = drop(s_att.dropout), drop(ff.dropout), drop(s_ffn.dropout)
+        x1, h = AttnOutFfn1.apply(a, xres, sa.linears[-1].weight, sa.linears[-1].bias, s_ffn.norm.a_2, s_ffn.norm.b_2,
+                                  ff.w_1.weight, ff.w_1.bias, s_ffn.norm.eps, p1, pf, seed(p1), seed(pf))
+        if i + 1 < len(layers):
+            nxt = layers[i + 1]
+            nn_ = nxt.sublayer[0].norm
+            pw, pb, routing = _packed(nxt.self_attn)
+            xres, qkv = Ffn2Ln.apply(h, x1, ff.w_2.weight, ff.w_2.bias, nn_.a_2, nn_.b_2, nn_.eps, p3, pf, seed(p3), pw, pb,
+                                     *routing)
+        else:
+            (out,) = Ffn2Ln.apply(h, x1, ff.w_2.weight, ff.w_2.bias, final_norm.a_2, final_norm.b_2, final_norm.eps, p3, pf,
+                                  seed(p3), None, None)
+    return out

@@ -268,6 +268,9 @@ class Encoder(nn.Module):
         self.norm = LayerNorm(layer.size)
 
     def forward(self, x, mask):
+        st = getattr(ops(), "tf_stack", None)
+        if st is not None and st.stack_supported(self.layers, x):
+            return st.run_stack(self.layers, self.norm, x, mask)   # 4 launches per layer (spacap3d_amd/tf_layer.py)
         for layer in self.layers:
             x = layer(x, mask)
         return self.norm(x)
@@ -295,6 +298,9 @@ class Decoder(nn.Module):
     def forward(self, x, memory, src_mask, tgt_mask, obj_indicator=None):
         if obj_indicator is not None:
             x = torch.cat((obj_indicator, x), dim=1)
+        st = getattr(ops(), "tf_stack", None)
+        if st is not None and st.stack_supported(self.layers, x):   # early guide: self-attention + feed-forward only
+            return st.run_stack(self.layers, self.norm, x, tgt_mask)
         for layer in self.layers:
             x = layer(x, memory, src_mask, tgt_mask)
         return self.norm(x)
