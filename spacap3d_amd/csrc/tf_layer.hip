@@ -108,8 +108,16 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
     // the first product was formed by tf_gemm_kernel as partial sums over slices of k: add them in slice order
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      f32x4 a = ld4(P.A1 + (size_t)rowc * D + cb[g]);
-      for (int sidx = 1; sidx < P.nparts; ++sidx) a += ld4(P.A1 + ((size_t)sidx * P.R + rowc) * D + cb[g]);
+      const float *pp = P.A1 + (size_t)rowc * D + cb[g];
+      const size_t ps = (size_t)P.R * D;
+      f32x4 a = ld4(pp);
+      int sidx = 1;
+      for (; sidx + 3 < P.nparts; sidx += 4) {   // four loads in flight, added in slice order
+        const f32x4 t0 = ld4(pp + sidx * ps), t1 = ld4(pp + (sidx + 1) * ps), t2 = ld4(pp + (sidx + 2) * ps),
+                    t3 = ld4(pp + (sidx + 3) * ps);
+        a += t0, a += t1, a += t2, a += t3;
+      }
+      for (; sidx < P.nparts; ++sidx) a += ld4(pp + sidx * ps);
 #pragma unroll
       for (int t = 0; t < 4; ++t) v[g][t] = a[t];
     }
@@ -185,6 +193,24 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u >> 1][2 * (u & 1) + i] = acc[i][u];
+    }
+  }
+
+  // The second product's weights depend on nothing computed here: its first registers are requested NOW, so that their
+  // latency runs under the row epilogue (three barriers and a round of global loads) instead of after it.
+  f32x4 x0[8], y0[8];   // FWD: first pair of 16-column tiles of W2
+  f32x2 wv2[32];        // BWD: W2 [128][128], the wave's two interleaved tiles
+  const int nw2 = P.N2 >> 2, n00 = w * nw2;
+  const float *wp2 = BWD ? P.W2 + (size_t)(4 * lg) * D + 32 * w + 2 * l15 : P.W2 + (size_t)(n00 + l15) * D + 4 * lg;
+  if (P.N2 != 0) {
+    if (!BWD) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x0[q] = ld4(wp2 + 16 * q), y0[q] = ld4(wp2 + 16 * D + 16 * q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wv2[q * 4 + i] = ld2(wp2 + (size_t)(16 * q + i) * D);
     }
   }
 
@@ -327,28 +353,22 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
   for (int q = 0; q < 8; ++q) at[q] = ld4(&s_t[l15 * LDT + 16 * q + 4 * lg]);
   if (!BWD) {
     // W2 [N2][128], N2 a multiple of 128: the wave's N2 / 4 columns in pairs of 16-column tiles
-    const int N2 = P.N2, nw = N2 >> 2, n00 = w * nw;
-    const float *wp = P.W2 + (size_t)(n00 + l15) * D + 4 * lg;
-    f32x4 w0[8], w1[8];
+    const int N2 = P.N2, nw = nw2;
+    const float *wp = wp2;
+    // pairs of tiles, two register sets loaded one pair ahead (no copies: the loads stay in flight under the MFMAs)
+    f32x4 x1[8], y1[8];
+    auto load = [&](f32x4 *x, f32x4 *y, int jt) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) w0[q] = ld4(wp + 16 * q), w1[q] = ld4(wp + 16 * D + 16 * q);
-    for (int jt = 0; jt < nw; jt += 32) {
-      f32x4 w0n[8], w1n[8];
-      const bool more = jt + 32 < nw;
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          w0n[q] = ld4(wp + (size_t)(jt + 32) * D + 16 * q);
-          w1n[q] = ld4(wp + (size_t)(jt + 48) * D + 16 * q);
-        }
-      }
+      for (int q = 0; q < 8; ++q) x[q] = ld4(wp + (size_t)jt * D + 16 * q), y[q] = ld4(wp + (size_t)(jt + 16) * D + 16 * q);
+    };
+    auto pair = [&](const f32x4 *x, const f32x4 *y, int jt) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          acc0 = MFMA16(w0[q][i], at[q][i], acc0);
-          acc1 = MFMA16(w1[q][i], at[q][i], acc1);
+          acc0 = MFMA16(x[q][i], at[q][i], acc0);
+          acc1 = MFMA16(y[q][i], at[q][i], acc1);
         }
       const int c0 = n00 + jt + 4 * lg;
       if (P.bias2) acc0 += ld4(P.bias2 + c0), acc1 += ld4(P.bias2 + c0 + 16);
@@ -356,22 +376,24 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
         st4(P.out2 + (size_t)row * N2 + c0, acc0);
         st4(P.out2 + (size_t)row * N2 + c0 + 16, acc1);
       }
-      if (more) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) w0[q] = w0n[q], w1[q] = w1n[q];
+    };
+    for (int jt = 0; jt < nw; jt += 64) {   // (pair 0 was requested before the row epilogue)
+      if (jt + 32 < nw) load(x1, y1, jt + 32);
+      pair(x0, y0, jt);
+      if (jt + 32 < nw) {
+        if (jt + 64 < nw) load(x0, y0, jt + 64);
+        pair(x1, y1, jt + 32);
       }
     }
   } else {
     // W2 [128][128] (N2 == 128): out2 = dy W2, the wave's 32 columns as two interleaved tiles
-    const float *wp = P.W2 + (size_t)(4 * lg) * D + 32 * w + 2 * l15;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x2 wv = ld2(wp + (size_t)(16 * q + i) * D);
-        acc[0] = MFMA16(wv[0], at[q][i], acc[0]);
-        acc[1] = MFMA16(wv[1], at[q][i], acc[1]);
+        acc[0] = MFMA16(wv2[q * 4 + i][0], at[q][i], acc[0]);
+        acc[1] = MFMA16(wv2[q * 4 + i][1], at[q][i], acc[1]);
       }
     if (valid) {
 #pragma unroll
@@ -416,12 +438,17 @@ __global__ __launch_bounds__(256) void tf_gemm_kernel(const TfGemmArgs P) {
   for (int mt = 0; mt < FM / 16; ++mt) acc[mt][0] = acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int kc = k0; kc < k0 + P.KS; kc += 128) {
     if (kc != k0) __syncthreads();
+    {
+      // (rows past the end read the last row: branch-free, so the eight loads are in flight together; those rows of the
+      // tile are computed and never stored)
+      f32x4 stg[FM / 8];
 #pragma unroll
-    for (int i = 0; i < FM / 8; ++i) {
-      const int rr = r0 + 8 * i;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f};
-      if (row0 + rr < P.R) a = ld4(P.x + (size_t)(row0 + rr) * P.ldx + kc + c4 * 4);
-      st4(&s_a[rr * LDT + c4 * 4], a);
+      for (int i = 0; i < FM / 8; ++i) {
+        const long rr = min(row0 + r0 + 8 * i, P.R - 1);
+        stg[i] = ld4(P.x + (size_t)rr * P.ldx + kc + c4 * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < FM / 8; ++i) st4(&s_a[(r0 + 8 * i) * LDT + c4 * 4], stg[i]);
     }
     f32x4 w0[8], w1[8];   // NN: w0[q][i] / w1[q][i] = the two interleaved tiles' weights for k = kc + 16 q + 4 lg + i
     if (!NN) {
@@ -490,6 +517,144 @@ __global__ __launch_bounds__(256) void tf_gemm_kernel(const TfGemmArgs P) {
     }
     st4(out + (size_t)row * P.N + c0, o0);
     st4(out + (size_t)row * P.N + c1, o1);
+  }
+}
+
+// The feed-forward block as ONE launch per direction, chained through LDS (models/transformer_captioner.py:72-81):
+//   forward   h_c = dropout(relu(n W1_c^T + b1_c))   [64 rows x 128 hidden units c]   stored (the backward needs it)
+//             part[c] = h_c W2[:, c]^T                [64 x 128]   partial sum of w_2's output over this slice of d_ff
+//   backward  dhid_c = (dy W2[:, c]) * [h_c > 0] * scale            stored (the weight gradient of w_1 needs it)
+//             part[c] = dhid_c W1_c                   [64 x 128]   partial sum of the gradient w.r.t. the LayerNorm output
+// One workgroup per (64-row tile, 128-wide slice of d_ff): the hidden tile goes from the first product's accumulators
+// through the epilogue into LDS and is the second product's activation tile; both weight blocks are in registers
+// before the first MFMA (the second block's load latency hides under the first product).  tf_rows_kernel adds the
+// d_ff / 128 partial sums in slice order.
+struct TfFfnArgs {
+  const float *x, *Wa, *Wb, *bias, *y;
+  float *hid, *part;
+  long R;
+  int dff;
+  unsigned thresh;
+  float scale;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
+};
+template <bool BWD, int MT>   // MT row tiles of 16 per workgroup: 4, or 1 for the few hundred rows of the caption decoder
+__global__ __launch_bounds__(256) void tf_ffn_kernel(const TfFfnArgs P) {
+  constexpr int FM = 16 * MT, NST = FM >= 8 ? FM / 8 : 1;
+  __shared__ __attribute__((aligned(16))) float s_a[FM * LDT];
+  __shared__ __attribute__((aligned(16))) float s_h[FM * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long row0 = (long)blockIdx.x * FM;
+  const int c0 = blockIdx.y * 128, dff = P.dff;
+  const int c4 = tid & 31, r0 = tid >> 5;
+  f32x4 stg[NST];   // (rows past the end read the last row: branch-free, all loads in flight together; never stored)
+#pragma unroll
+  for (int i = 0; i < NST; ++i) stg[i] = ld4(P.x + (size_t)min(row0 + r0 + 8 * i, P.R - 1) * D + c4 * 4);
+  // element [q][i] of a weight register = Wop[k = 16 q + 4 lg + i][the wave's column l15 of tile 0 / 1]
+  f32x4 a0[8], a1[8], b0[8], b1[8];
+  if (!BWD) {
+    const float *wa = P.Wa + (size_t)(c0 + 32 * w + l15) * D + 4 * lg;          // W1 [dff][128]: rows = hidden units
+    const float *wb = P.Wb + (size_t)(32 * w + l15) * dff + c0 + 4 * lg;        // W2 [128][dff]: k = hidden units
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a0[q] = ld4(wa + 16 * q), a1[q] = ld4(wa + 16 * D + 16 * q);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b0[q] = ld4(wb + 16 * q), b1[q] = ld4(wb + (size_t)16 * dff + 16 * q);
+  } else {
+    const float *wa = P.Wa + (size_t)(4 * lg) * dff + c0 + 32 * w + 2 * l15;    // W2 [128][dff]: k = model channels
+    const float *wb = P.Wb + (size_t)(c0 + 4 * lg) * D + 32 * w + 2 * l15;      // W1 [dff][128]: k = hidden units
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 t = ld2(wa + (size_t)(16 * q + i) * dff);
+        a0[q][i] = t[0], a1[q][i] = t[1];
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 t = ld2(wb + (size_t)(16 * q + i) * D);
+        b0[q][i] = t[0], b1[q][i] = t[1];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < NST; ++i) st4(&s_a[(r0 + 8 * i) * LDT + c4 * 4], stg[i]);
+  // the lane's columns inside the 128-wide block: two runs of four starting at e0 and e1
+  const int e0 = BWD ? 32 * w + 8 * lg : 32 * w + 4 * lg, e1 = BWD ? e0 + 4 : e0 + 16;
+  f32x4 bb0 = {0.f, 0.f, 0.f, 0.f}, bb1 = {0.f, 0.f, 0.f, 0.f};
+  if (!BWD && P.bias) bb0 = ld4(P.bias + c0 + e0), bb1 = ld4(P.bias + c0 + e1);
+  const DropSeed sd = make_seed(P.seed, P.seed_dev);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < FM / 16; ++mt) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 a = ld4(&s_a[(mt * 16 + l15) * LDT + 16 * q + 4 * lg]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc0 = MFMA16(a0[q][i], a[i], acc0);
+        acc1 = MFMA16(a1[q][i], a[i], acc1);
+      }
+    }
+    const long row = row0 + mt * 16 + l15;
+    const bool valid = row < P.R;
+    f32x4 o0, o1;
+    if (BWD) {
+      o0 = f32x4{acc0[0], acc1[0], acc0[1], acc1[1]};
+      o1 = f32x4{acc0[2], acc1[2], acc0[3], acc1[3]};
+      f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+      if (valid) y0 = ld4(P.y + (size_t)row * dff + c0 + e0), y1 = ld4(P.y + (size_t)row * dff + c0 + e1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        o0[u] = y0[u] > 0.f ? o0[u] * P.scale : 0.f;
+        o1[u] = y1[u] > 0.f ? o1[u] * P.scale : 0.f;
+      }
+    } else {
+      o0 = acc0 + bb0, o1 = acc1 + bb1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v0 = fmaxf(o0[u], 0.f), v1 = fmaxf(o1[u], 0.f);
+        if (P.thresh != 0u) {
+          const unsigned long long e = (unsigned long long)row * dff + c0;
+          v0 = hash32(e + e0 + u, sd) >= P.thresh ? v0 * P.scale : 0.f;
+          v1 = hash32(e + e1 + u, sd) >= P.thresh ? v1 * P.scale : 0.f;
+        }
+        o0[u] = valid ? v0 : 0.f, o1[u] = valid ? v1 : 0.f;
+      }
+    }
+    if (valid) {
+      st4(P.hid + (size_t)row * dff + c0 + e0, o0);
+      st4(P.hid + (size_t)row * dff + c0 + e1, o1);
+    }
+    st4(&s_h[(mt * 16 + l15) * LDT + e0], o0);
+    st4(&s_h[(mt * 16 + l15) * LDT + e1], o1);
+  }
+  __syncthreads();
+  float *out = P.part + (size_t)blockIdx.y * P.R * D;
+#pragma unroll
+  for (int mt = 0; mt < FM / 16; ++mt) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 a = ld4(&s_h[(mt * 16 + l15) * LDT + 16 * q + 4 * lg]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc0 = MFMA16(b0[q][i], a[i], acc0);
+        acc1 = MFMA16(b1[q][i], a[i], acc1);
+      }
+    }
+    const long row = row0 + mt * 16 + l15;
+    if (row < P.R) {
+      if (BWD) {
+        st4(out + (size_t)row * D + e0, f32x4{acc0[0], acc1[0], acc0[1], acc1[1]});
+        st4(out + (size_t)row * D + e1, f32x4{acc0[2], acc1[2], acc0[3], acc1[3]});
+      } else {
+        st4(out + (size_t)row * D + e0, acc0);
+        st4(out + (size_t)row * D + e1, acc1);
+      }
+    }
   }
 }
 
@@ -566,6 +731,36 @@ extern "C" int spacap_tf_ffn1_f32(const float *x, const float *W, const float *b
   P.x = x, P.W = W, P.bias = bias, P.out = h, P.R = R, P.ldx = D, P.ldw = D, P.N = N, P.KS = D;
   P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   return launch_gemm<1>(what, P, false, R, N, 1, spacap::as_stream(stream));
+}
+
+// mode 0: hid = dropout(relu(x Wa^T + bias)) [R,dff] (Wa = w_1 [dff,128]), part[c] = hid[:, c] Wb[:, c]^T (Wb = w_2 [128,dff]);
+// mode 1: hid = (x Wa[:, c]) * [y > 0] / (1 - p) (Wa = w_2, y = the saved forward hid), part[c] = hid[:, c] Wb[c] (Wb = w_1).
+extern "C" int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, const float *Wb, const float *bias, const float *y, long R,
+                                 int dff, float drop_p, uint64_t seed, const uint64_t *seed_dev, float *hid, float *part,
+                                 spacap_stream_t stream) {
+  const char *what = "spacap_tf_ffn_f32";
+  TfFfnArgs P = {};
+  SPACAP_REQUIRE((mode == 0 || mode == 1) && R >= 0 && dff >= 128 && dff % 128 == 0 && drop_params(drop_p, P.thresh, P.scale),
+                 "%s: (mode=%d, R=%ld, dff=%d, p=%f) unsupported", what, mode, R, dff, (double)drop_p);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(x && Wa && Wb && hid && part && (mode == 0 || y) && al16(x) && al16(Wa) && al16(Wb) && al16(bias) && al16(y) &&
+                     al16(hid) && al16(part), "%s: null or unaligned pointer", what);
+  P.x = x, P.Wa = Wa, P.Wb = Wb, P.bias = bias, P.y = y, P.hid = hid, P.part = part, P.R = R, P.dff = dff;
+  P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
+  const bool small = R <= 512;   // few rows: 16-row tiles, so that the launch still has a few hundred workgroups
+  const long tiles = small ? (R + 15) / 16 : (R + 63) / 64;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)tiles, dff / 128);
+  hipStream_t s = spacap::as_stream(stream);
+  if (mode == 0) {
+    if (small) hipLaunchKernelGGL((tf_ffn_kernel<false, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((tf_ffn_kernel<false, 4>), grid, dim3(256), 0, s, P);
+  } else {
+    if (small) hipLaunchKernelGGL((tf_ffn_kernel<true, 1>), grid, dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((tf_ffn_kernel<true, 4>), grid, dim3(256), 0, s, P);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
 }
 
 // number of K slices that fills the chip with 64 x 128 tiles (a divisor of K / 128)

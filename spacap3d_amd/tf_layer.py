@@ -23,6 +23,7 @@ from ._native import TfRowsArgs, check, grad_slot, lib, linear_wgrad_partials, s
 
 D_MODEL = 128
 # tests / A-B measurements switch the fused stacks off here (the per-operator path of transformer_captioner.py then runs)
+SPLIT_MAX = int(os.environ.get("SPACAP_TF_SPLIT_MAX", "0"))   # lab knob: cap on the K slices of the split products
 ENABLED = os.environ.get("SPACAP_TF_FUSED", "1") != "0"   # (A/B runs of bench.py)
 
 
@@ -68,6 +69,8 @@ def _split_product(a2, W, trans_w):
     R, K = a2.shape
     dev = a2.device
     S = int(lib.spacap_tf_gemm_splits(R, K, D_MODEL))
+    if SPLIT_MAX:
+        S = max(d for d in range(1, min(S, SPLIT_MAX) + 1) if (K // 128) % d == 0)
     parts = _new(dev, S, R, D_MODEL)
     check(lib.spacap_tf_gemm_f32(a2.data_ptr(), W.data_ptr(), R, K, D_MODEL, 1 if trans_w else 0, S, parts.data_ptr(),
                                  torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_gemm_f32")
@@ -136,12 +139,25 @@ class LnQkv(Function):
         return dx, da, db, None, dw, dbias
 
 
+def _ffn(mode, x2, Wa, Wb, bias, y, dff, p, seed, dev):
+    """One launch of the chained feed-forward kernel: (hid (R, dff), parts (dff / 128, R, 128))."""
+    from .attention import rng_state
+    R = x2.shape[0]
+    hid, parts = _new(dev, R, dff), _new(dev, dff // 128, R, D_MODEL)
+    check(lib.spacap_tf_ffn_f32(mode, x2.data_ptr(), Wa.data_ptr(), Wb.data_ptr(), _p(bias), _p(y), R, dff, float(p), int(seed),
+                                rng_state(dev).data_ptr() if (p > 0.0 and mode == 0) else None, hid.data_ptr(), parts.data_ptr(),
+                                torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_ffn_f32")
+    return hid, parts
+
+
 class AttnOutFfn1(Function):
-    """(x1, h):  x1 = x + dropout(a Wo^T + bo);  h = dropout(relu(LayerNorm(x1) W1^T + b1)).
-    backward(g_x1, g_hpre): ``g_hpre`` is the gradient w.r.t. the hidden PRE-activation (see the module docstring)."""
+    """(x1, h, parts):  x1 = x + dropout(a Wo^T + bo);  h = dropout(relu(LayerNorm(x1) W1^T + b1));  parts = the partial sums
+    of h W2^T over the 128-wide slices of d_ff (same launch as h: the hidden tile never leaves the chip between the two
+    products).  backward(g_x1, g_hpre, g_parts): see the module docstring -- ``g_hpre`` is the gradient w.r.t. the hidden
+    PRE-activation and ``g_parts`` the partial sums of g_hpre W1, both produced by ``Ffn2Ln.backward`` in one launch."""
 
     @staticmethod
-    def forward(ctx, a, xres, Wo, bo, ln_a, ln_b, W1, b1, eps, p_sub, p_ffn, seed1, seed2):
+    def forward(ctx, a, xres, Wo, bo, ln_a, ln_b, W1, b1, W2, eps, p_sub, p_ffn, seed1, seed2):
         if not a.is_cuda:
             raise RuntimeError("CPU not supported")
         ac, xr = a.contiguous(), xres.contiguous()
@@ -151,18 +167,14 @@ class AttnOutFfn1(Function):
             x1, n2, stats = _new(dev, *xr.shape), _new(dev, R, D_MODEL), _new(dev, R, 2)
             _rows(0, R, dev, a1=ac, w1=Wo, bias1=bo, k1=D_MODEL, drop_p=p_sub, seed=seed1, res=xr, x_out=x1, ln_a=ln_a,
                   ln_b=ln_b, eps=eps, n_out=n2, stats=stats)
-            h = _new(dev, *xr.shape[:-1], dff)
-            from .attention import rng_state
-            check(lib.spacap_tf_ffn1_f32(n2.data_ptr(), W1.data_ptr(), b1.data_ptr(), R, dff, float(p_ffn), int(seed2),
-                                         rng_state(dev).data_ptr() if p_ffn > 0.0 else None, h.data_ptr(),
-                                         torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_ffn1_f32")
+            h, parts = _ffn(0, n2, W1, W2, b1, None, dff, p_ffn, seed2, dev)
         ctx.save_for_backward(ac, x1, n2, stats, ln_a, Wo, W1)
         ctx.meta = (float(eps), float(p_sub), int(seed1))
         ctx.set_materialize_grads(False)
-        return x1, h
+        return x1, h.view(*xr.shape[:-1], dff), parts
 
     @staticmethod
-    def backward(ctx, g_x1, g_hpre):
+    def backward(ctx, g_x1, g_hpre, g_parts):
         ac, x1, n2, stats, ln_a, Wo, W1 = ctx.saved_tensors
         eps, p_sub, seed1 = ctx.meta
         R, dev = x1.numel() // D_MODEL, x1.device
@@ -174,48 +186,50 @@ class AttnOutFfn1(Function):
             dW1 = db1 = None
             if g_hpre is not None:
                 gh = g_hpre.reshape(R, dff).contiguous()
-                parts, S = _split_product(gh, W1, False)
-                _rows(1, R, dev, a1=parts, nparts=S, **kw)
+                if g_parts is not None:
+                    gp = g_parts.contiguous()
+                    _rows(1, R, dev, a1=gp, nparts=gp.shape[0], **kw)
+                else:
+                    parts, S = _split_product(gh, W1, False)
+                    _rows(1, R, dev, a1=parts, nparts=S, **kw)
                 dW1, db1 = _linear_grads(gh, n2, W1)
             else:   # the hidden layer was not used downstream: only the residual path carries a gradient
                 _rows(1, R, dev, g=torch.zeros(R, D_MODEL, dtype=torch.float32, device=dev), **kw)
             dln_a, dln_b = _ln_param_grads(part)
             dWo, dbo = _linear_grads(dy1, ac.reshape(R, D_MODEL), Wo)
-        return da, dx1, dWo, dbo, dln_a, dln_b, dW1, db1, None, None, None, None, None
+        return da, dx1, dWo, dbo, dln_a, dln_b, dW1, db1, None, None, None, None, None, None
 
 
 class Ffn2Ln(Function):
-    """x2 = x1 + dropout(h W2^T + b2);  n = LayerNorm(x2) with the NEXT layer's (or the stack's final) norm;
-    returns (x2, n Wqkv^T + bqkv) -- or (n,) when ``pw`` is None (last layer: n is the stack's output).
-    The gradient returned for h is the one w.r.t. the hidden pre-activation (see the module docstring): ``p_ffn`` is the
-    hidden layer's dropout probability, whose scale that mask needs."""
+    """x2 = x1 + dropout(h W2^T + b2) -- ``parts`` = the partial sums of h W2^T from ``AttnOutFfn1`` --;
+    n = LayerNorm(x2) with the NEXT layer's (or the stack's final) norm;  returns (x2, n Wqkv^T + bqkv) -- or (n,) when ``pw``
+    is None (last layer: n is the stack's output).  The gradients returned for h / parts are the private pair described in
+    the module docstring; ``p_ffn`` is the hidden layer's dropout probability, whose scale that mask needs."""
 
     @staticmethod
-    def forward(ctx, h, x1, W2, b2, ln_a, ln_b, eps, p_sub, p_ffn, seed3, pw, pb, *routing):
+    def forward(ctx, h, parts, x1, W1, W2, b2, ln_a, ln_b, eps, p_sub, p_ffn, seed3, pw, pb, *routing):
         if not h.is_cuda:
             raise RuntimeError("CPU not supported")
-        hc, xr = h.contiguous(), x1.contiguous()
+        hc, xr, pc = h.contiguous(), x1.contiguous(), parts.contiguous()
         R, dev = xr.numel() // D_MODEL, xr.device
-        dff = W2.shape[1]
         last = pw is None
         with torch.cuda.device(dev):
             x2, n, stats = _new(dev, *xr.shape), _new(dev, *xr.shape), _new(dev, R, 2)
-            parts, S = _split_product(hc.reshape(R, dff), W2, True)
-            kw = dict(a1=parts, nparts=S, bias1=b2, drop_p=p_sub, seed=seed3, res=xr, x_out=x2, ln_a=ln_a, ln_b=ln_b, eps=eps,
-                      n_out=n, stats=stats)
+            kw = dict(a1=pc, nparts=pc.shape[0], bias1=b2, drop_p=p_sub, seed=seed3, res=xr, x_out=x2, ln_a=ln_a, ln_b=ln_b,
+                      eps=eps, n_out=n, stats=stats)
             qkv = None
             if not last:
                 qkv = _new(dev, *xr.shape[:-1], pw.shape[0])
                 kw.update(w2=pw, bias2=pb, n2=pw.shape[0], out2=qkv)
             _rows(0, R, dev, **kw)
-        ctx.save_for_backward(hc, x2, n, stats, ln_a, W2, pw)
+        ctx.save_for_backward(hc, x2, n, stats, ln_a, W1, W2, pw)
         ctx.meta = (float(eps), float(p_sub), float(p_ffn), int(seed3), last, [int(r.shape[0]) for r in routing[:3]])
         ctx.set_materialize_grads(False)
         return (n,) if last else (x2, qkv)
 
     @staticmethod
     def backward(ctx, *grads):
-        hc, x2, n, stats, ln_a, W2, pw = ctx.saved_tensors
+        hc, x2, n, stats, ln_a, W1, W2, pw = ctx.saved_tensors
         eps, p_sub, p_ffn, seed3, last, rows = ctx.meta
         R, dev = x2.numel() // D_MODEL, x2.device
         dff = W2.shape[1]
@@ -236,12 +250,12 @@ class Ffn2Ln(Function):
                 else:
                     _rows(1, R, dev, g=torch.zeros_like(x2), res=gx, **kw)
             dln_a, dln_b = _ln_param_grads(part)
-            dh = _new(dev, *hc.shape)   # (dy2 W2) where the hidden unit was active and kept, scaled by the hidden dropout
-            check(lib.spacap_linear_dgrad_mask_f32(dy2.data_ptr(), W2.data_ptr(), hc.data_ptr(), 1.0 / (1.0 - p_ffn), R, D_MODEL,
-                                                   dff, dh.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
-                  "spacap_linear_dgrad_mask_f32")
-            dW2, db2 = _linear_grads(dy2, hc.reshape(R, dff), W2)
-        head = (dh, dx2, dW2, db2, dln_a, dln_b, None, None, None, None)
+            # dhid = (dy2 W2) where the hidden unit was active and kept (scaled by the hidden dropout) AND the partial sums of
+            # dhid W1 over the slices of d_ff, in one launch
+            hflat = hc.reshape(R, dff)
+            dh, gparts = _ffn(1, dy2, W2, W1, None, hflat, dff, p_ffn, 0, dev)
+            dW2, db2 = _linear_grads(dy2, hflat, W2)
+        head = (dh.view_as(hc), gparts, dx2, None, dW2, db2, dln_a, dln_b, None, None, None, None)
         if last:
             return head + (None, None)
         if rows:
@@ -304,15 +318,15 @@ def run_stack(layers, final_norm, x, mask):
             hd = sa.h * sa.d_k
             sa.value = qkv[..., 2 * hd:].view(qkv.shape[0], -1, sa.h, sa.d_k).transpose(1, 2)
         p1, pf, p3 = drop(s_att.dropout), drop(ff.dropout), drop(s_ffn.dropout)
-        x1, h = AttnOutFfn1.apply(a, xres, sa.linears[-1].weight, sa.linears[-1].bias, s_ffn.norm.a_2, s_ffn.norm.b_2,
-                                  ff.w_1.weight, ff.w_1.bias, s_ffn.norm.eps, p1, pf, seed(p1), seed(pf))
+        x1, h, parts = AttnOutFfn1.apply(a, xres, sa.linears[-1].weight, sa.linears[-1].bias, s_ffn.norm.a_2, s_ffn.norm.b_2,
+                                         ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, s_ffn.norm.eps, p1, pf, seed(p1), seed(pf))
         if i + 1 < len(layers):
             nxt = layers[i + 1]
             nn_ = nxt.sublayer[0].norm
             pw, pb, routing = _packed(nxt.self_attn)
-            xres, qkv = Ffn2Ln.apply(h, x1, ff.w_2.weight, ff.w_2.bias, nn_.a_2, nn_.b_2, nn_.eps, p3, pf, seed(p3), pw, pb,
-                                     *routing)
+            xres, qkv = Ffn2Ln.apply(h, parts, x1, ff.w_1.weight, ff.w_2.weight, ff.w_2.bias, nn_.a_2, nn_.b_2, nn_.eps, p3, pf,
+                                     seed(p3), pw, pb, *routing)
         else:
-            (out,) = Ffn2Ln.apply(h, x1, ff.w_2.weight, ff.w_2.bias, final_norm.a_2, final_norm.b_2, final_norm.eps, p3, pf,
-                                  seed(p3), None, None)
+            (out,) = Ffn2Ln.apply(h, parts, x1, ff.w_1.weight, ff.w_2.weight, ff.w_2.bias, final_norm.a_2, final_norm.b_2,
+                                  final_norm.eps, p3, pf, seed(p3), None, None)
     return out

@@ -70,12 +70,12 @@ def test_attn_out_ffn1_and_ffn2_chain(tf, R, dff):
     for last in (False, True):
         for p in leaves:
             p.grad = None
-        x1, h = tf.AttnOutFfn1.apply(a_, x_, Wo, bo, l2a, l2b, W1, b1, 1e-6, 0.0, 0.0, 0, 0)
+        x1, h, parts = tf.AttnOutFfn1.apply(a_, x_, Wo, bo, l2a, l2b, W1, b1, W2, 1e-6, 0.0, 0.0, 0, 0)
         if last:
-            (mem,) = tf.Ffn2Ln.apply(h, x1, W2, b2, l3a, l3b, 1e-6, 0.0, 0.0, 0, None, None)
+            (mem,) = tf.Ffn2Ln.apply(h, parts, x1, W1, W2, b2, l3a, l3b, 1e-6, 0.0, 0.0, 0, None, None)
             (mem * g3).sum().backward()
         else:
-            x2, qkv = tf.Ffn2Ln.apply(h, x1, W2, b2, l3a, l3b, 1e-6, 0.0, 0.0, 0, pw, pb)
+            x2, qkv = tf.Ffn2Ln.apply(h, parts, x1, W1, W2, b2, l3a, l3b, 1e-6, 0.0, 0.0, 0, pw, pb)
             ((x2 * g1).sum() + (qkv * g2).sum()).backward()
         L = [p.detach().double().requires_grad_() for p in leaves]
         a6, x6, Wo6, bo6, l2a6, l2b6, W16, b16, W26, b26, l3a6, l3b6, pw6, pb6 = L
@@ -180,7 +180,7 @@ def test_split_product_and_masked_gradient(tf, R, K, N, trans, S):
 
 
 def test_fused_stack_launch_count(tf):
-    """5 kernels per layer forward (+1 for the first norm / projection): the point of the fusion."""
+    """4 kernels per layer forward (+1 for the first norm / projection): the point of the fusion."""
     m = _stack("enc", N=3).eval()
     x = _rand(2, 256, 128, seed=5)
     with torch.no_grad():
@@ -195,7 +195,7 @@ def test_fused_stack_launch_count(tf):
     ours = sum(e.count for e in ev if "tf_" in e.key or "mha_" in e.key)
     other = sum(e.count for e in ev) - ours
     # (outside a Trainer the three projection weights are not adjacent in memory: two concatenations per layer)
-    assert ours == 1 + 5 * 3 and other <= 2 * 3, [(e.key[:60], e.count) for e in ev]
+    assert ours == 1 + 4 * 3 and other <= 2 * 3, [(e.key[:60], e.count) for e in ev]
 
 
 @pytest.mark.parametrize("kind", ["enc", "dec"])
