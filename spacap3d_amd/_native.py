@@ -262,10 +262,28 @@ class deferred_slab_sums:
                       "spacap_sum_slabs_batched_f32")
 
 
-# weight.data_ptr() -> a view of the trainer's flat gradient bucket covering [dW | db] of that Linear layer (set by
-# engine.Trainer: the slab sums of the Linear-layer gradients then land directly where the all-reduce / optimizer read
-# them, and the per-step gradient pack has nothing left to copy for them)
+# weight.data_ptr() -> a view of a trainer's flat gradient bucket covering [dW | db] of that Linear layer: the slab sums
+# of the Linear-layer gradients then land directly where the all-reduce / optimizer read them, and the per-step gradient
+# pack has nothing left to copy for them.  The table is ACTIVE ONLY inside a ``grad_slots(table)`` block -- the engine
+# opens one around the backward of a step whose gradients autograd will ASSIGN (``p.grad is None`` everywhere).  Outside
+# it every weight gradient is an ordinary fresh tensor: a backward run with ``.grad`` already set (accumulation,
+# ``zero_grad(set_to_none=False)``, gradient checks) must never be handed a view of the buffer it accumulates into.
 GRAD_SLOTS = {}
+
+
+class grad_slots:
+    def __init__(self, table):
+        self.table = table or {}
+
+    def __enter__(self):
+        global GRAD_SLOTS
+        self._prev, GRAD_SLOTS = GRAD_SLOTS, self.table
+        return self
+
+    def __exit__(self, *exc):
+        global GRAD_SLOTS
+        GRAD_SLOTS = self._prev
+        return False
 
 
 def grad_slot(weight, numel):

@@ -36,6 +36,7 @@ class Trainer:
         self._capture_stream = None
         self.last_losses = {}
         self._bn_counters = None
+        self._grad_slots = {}
         self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
@@ -194,17 +195,18 @@ class Trainer:
         return rest + [p for g in groups for p in g]
 
     def _register_grad_slots(self):
-        """[dW | db] of every Linear layer whose weight is directly followed by its bias in the flat bucket (and of the
-        packed q | k | v groups: three weights, then three biases) -> the matching slice of the flat gradient buffer
-        (_native.GRAD_SLOTS): the deferred slab sums write there, the gradient pack skips them."""
-        from . import _native
-        _native.GRAD_SLOTS.clear()
+        """[dW | db] of every nn.Linear whose OWN bias directly follows its weight in the flat bucket (matched by module,
+        not by shape), and of the packed q | k | v groups (three weights, then their three biases) -> the matching slice of
+        the flat gradient buffer.  The table belongs to this Trainer and is only active around its backward
+        (_native.grad_slots in _core): the deferred slab sums then write there and the gradient pack skips them."""
+        self._grad_slots = {}
         ps, flat, offs = self.bucket.params, self.bucket.flat, self.bucket.offsets
         pos = {id(p): i for i, p in enumerate(ps)}
-        for i, p in enumerate(ps[:-1]):
-            b = ps[i + 1]
-            if p.dim() == 2 and b.dim() == 1 and b.shape[0] == p.shape[0] and offs[i + 1] == offs[i] + p.numel():
-                _native.GRAD_SLOTS[p.data_ptr()] = flat[offs[i]:offs[i] + p.numel() + b.numel()]
+        for m in self.model.modules():
+            if isinstance(m, torch.nn.Linear) and m.bias is not None:
+                iw, ib = pos.get(id(m.weight)), pos.get(id(m.bias))
+                if iw is not None and ib == iw + 1 and offs[ib] == offs[iw] + m.weight.numel():
+                    self._grad_slots[m.weight.data_ptr()] = flat[offs[iw]:offs[iw] + m.weight.numel() + m.bias.numel()]
         for m in self._attention_modules():
             pk = getattr(m, "_packed_qkv", None)
             ws, bs = [l.weight for l in m.linears[:3]], [l.bias for l in m.linears[:3]]
@@ -213,7 +215,7 @@ class Trainer:
             i0 = pos[id(ws[0])]
             n = sum(t.numel() for t in ws + bs)
             if [pos[id(t)] for t in ws + bs] == list(range(i0, i0 + 6)) and offs[i0 + 5] + bs[2].numel() == offs[i0] + n:
-                _native.GRAD_SLOTS[pk[0].data_ptr()] = flat[offs[i0]:offs[i0] + n]
+                self._grad_slots[pk[0].data_ptr()] = flat[offs[i0]:offs[i0] + n]
 
     def _attach_packed_qkv(self):
         from .linear import packed_views
@@ -235,17 +237,29 @@ class Trainer:
         if pc.is_cuda:
             # the ~70 weight-gradient slab sums of the backward are only read by the optimizer: queue them and run them
             # as ONE launch when the backward is over (spacap3d_amd/_native.py: deferred_slab_sums)
-            from ._native import deferred_slab_sums
-            # (only when autograd will ASSIGN the gradients: accumulating into an existing .grad reads them at once)
+            from ._native import deferred_slab_sums, grad_slots
+            # (only when autograd will ASSIGN the gradients: accumulating into an existing .grad reads them at once -- and
+            # must not be handed views of the flat bucket either, so the slot table is only active in this branch)
             if all(p.grad is None for p in self.bucket.params):
-                with deferred_slab_sums() as dq:
+                with grad_slots(getattr(self, "_grad_slots", None)), deferred_slab_sums() as dq:
                     d["loss"].backward()
                     if self._eager_checks > 0:
-                        # A queued sum is unfilled until the flush: it must have reached a parameter's .grad untouched
-                        # (a parameter consumed by two autograd nodes, or an AccumulateGrad that clones, would have read it)
+                        # A queued sum is unfilled until the flush: every byte of it must have reached parameters' .grad
+                        # untouched (a parameter consumed by two autograd nodes, or an AccumulateGrad that clones, would
+                        # have read it).  Compared by address RANGE: a storage pointer would match any view of the bucket.
                         self._eager_checks -= 1
-                        leaf = {p.grad.untyped_storage().data_ptr() for p in self.model.parameters() if p.grad is not None}
-                        lost = [tuple(o.shape) for o in dq.outputs() if o.untyped_storage().data_ptr() not in leaf]
+                        spans = sorted((g.data_ptr(), g.data_ptr() + g.numel() * g.element_size())
+                                       for g in (p.grad for p in self.model.parameters()) if g is not None)
+                        merged = []
+                        for lo, hi in spans:
+                            if merged and lo <= merged[-1][1]:
+                                merged[-1][1] = max(merged[-1][1], hi)
+                            else:
+                                merged.append([lo, hi])
+                        def covered(o):
+                            lo, hi = o.data_ptr(), o.data_ptr() + o.numel() * o.element_size()
+                            return any(a <= lo and hi <= b for a, b in merged)
+                        lost = [tuple(o.shape) for o in dq.outputs() if not covered(o)]
                         if lost:
                             raise RuntimeError(f"deferred weight-gradient sums did not land in a leaf .grad: {lost}")
             else:

@@ -378,3 +378,35 @@ def test_fused_relation_loss_matches_the_torch_composition():
     d0 = dict(d, objectness_label=torch.zeros_like(d["objectness_label"]), relation_pred=pa.detach().clone().requires_grad_(True))
     r0 = relation_losses(d0)
     assert float(r0["x_loss"]) == 0.0 and float(r0["z_acc"]) == 0.0
+
+
+def test_gradient_slots_are_scoped_to_the_step_and_accumulation_outside_it_is_plain():
+    """The [dW | db] slots of the flat bucket (_native.GRAD_SLOTS) are only active around the backward inside
+    Trainer._core.  A backward run OUTSIDE it with .grad still set (manual accumulation) must see ordinary gradients: two
+    identical accumulated passes give exactly twice one pass (a slot view aliasing .grad would give four times)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spacap3d_amd import _native
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    model = _make()
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6)
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    tr.step(data)
+    tr.step(data)
+    assert _native.GRAD_SLOTS == {} and tr._grad_slots, "slot table must be inactive outside the step"
+    some = next(iter(m for m in model.modules() if isinstance(m, torch.nn.Linear) and m.weight.data_ptr() in tr._grad_slots))
+    assert _native.grad_slot(some.weight, some.weight.numel() + some.bias.numel()) is None
+    # a second Trainer does not disturb the first one's table
+    other = Trainer(_make(1), S.mean_size_arr().numpy(), lr=1e-6)
+    other.step(data)
+    assert tr._grad_slots and all(k in tr._grad_slots for k in [some.weight.data_ptr()])
+    # manual accumulation outside the step (dropout is off and train-mode BatchNorm uses batch statistics: both passes
+    # evaluate the same function)
+    params = [p for p in tr.bucket.params]
+    for p in params:
+        p.grad = None
+    tr.loss(dict(data))["loss"].backward()
+    g1 = [p.grad.clone() for p in params]
+    tr.loss(dict(data))["loss"].backward()      # accumulates into the existing .grad
+    for p, a in zip(params, g1):
+        assert torch.allclose(p.grad, 2 * a, rtol=1e-4, atol=1e-6 * float(a.abs().max() + 1e-12))

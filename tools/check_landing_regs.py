@@ -9,7 +9,9 @@ script compiles sa_mlp.hip to assembly and checks, per kernel, in layout order:
   * no compiler-generated instruction READS one between a load block that targets it and the wait block that names it
     (state carried round the loop: a register counts as in flight from the top of the function until its first wait).
 
-    python tools/check_landing_regs.py        (needs hipcc; no GPU)
+    python tools/check_landing_regs.py                  compiles sa_mlp.hip itself (needs hipcc; no GPU)
+    python tools/check_landing_regs.py --asm FILE.s     checks the assembly the build kept (csrc/Makefile runs this right
+                                                        after compiling sa_mlp.o and deletes the object when it fails)
 """
 import os
 import re
@@ -82,6 +84,13 @@ def check(asm_text):
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--asm":
+        seen, bad = check(open(sys.argv[2]).read())
+        ver = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+        print(f"{seen} streaming kernels checked, {len(bad)} unsafe uses of landing registers  [{ver.strip()}]")
+        for name, n, what in bad[:20]:
+            print("  ", name[:60], n, what)
+        return 1 if bad or not seen else 0
     with tempfile.TemporaryDirectory() as tmp:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-ffp-contract=fast", "-save-temps", "-c", os.path.join(CSRC, "sa_mlp.hip"), "-o", os.path.join(tmp, "sa.o"),
