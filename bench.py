@@ -160,6 +160,101 @@ def cpu_baseline(cfg, omp_batch, steps, threads=8):
                     "what": "oracle FPS N -> 2048 and ball query 2048 x N (r 0.2, 64 samples), one call each"}}
 
 
+
+def quick_config(name, rank, dev, steps=5, warmup=5):
+    """A short pipelined run of another BASELINE configuration (driver-visible sub-record of the bench line): same step as
+    the headline (prefetch on the side stream, hipGraph replay), `steps` timed steps after `warmup`."""
+    cfg = CFG[name]
+    torch.manual_seed(0)
+    model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"],
+                          **cfg["transformer"]).to(dev)
+    model.train()
+    tr = Trainer(model, S.mean_size_arr().numpy())
+    data = synthetic_batch(cfg["batch"], cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
+    tr.step(data, next_data=data)
+    graphed = tr.enable_graph(data)
+    for _ in range(warmup):
+        tr.step(data, next_data=data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(data, next_data=data)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rec = {"value": cfg["batch"] / dt, "unit": "scenes/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": warmup,
+           "scenes_per_gpu": cfg["batch"], "points": cfg["n_points"], "proposals": cfg["proposals"],
+           "extra_channels": S.num_extra_channels(**cfg["feats"]), "hip_graph": bool(graphed), "final_loss": float(loss),
+           "n_gpus": 1, "note": "per-GPU shard of the configuration on ONE GPU (BASELINE.json quotes it on 4 - 8 GPUs)"}
+    if cfg["transformer"]:
+        rec["transformer"] = dict(cfg["transformer"], deviation="Linear(128, d_model) token projection, SURVEY.md section 5")
+    del tr, model, data
+    torch.cuda.empty_cache()
+    return rec
+
+
+def eval_record(model, data, iters=3):
+    """Inference forward: detector + encoder once + greedy decoding of B*K captions for 31 steps
+    (models/transformer_captioner.py:402-453), no gradients; model.eval()."""
+    was = model.training
+    model.eval()
+    d = {k: v for k, v in data.items() if k != "_fps_prefetch"}
+    with torch.no_grad():
+        out = model(dict(d), is_eval=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            out = model(dict(d), is_eval=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    model.train(was)
+    B, K = out["lang_cap"].shape[:2]
+    return {"ms_per_forward": dt * 1e3, "scenes_per_s": B / dt, "captions_per_s": B * K / dt, "scenes": B, "captions": B * K,
+            "decode_steps": int(out["lang_cap"].shape[2]), "iters": iters,
+            "what": "SpaCapNet eval forward: detector + 6-layer encoder once + greedy decoding of B*K captions "
+                    "(key / value cache, fused decode step), host-timed incl. launches"}
+
+
+class InStepTimer:
+    """Brackets the calls of ONE C entry point that match `select(args)` with HIP events on the stream they are launched on
+    (the step's own stream): the duration the roofline kernel has INSIDE a training step, beside the side-stream sampling
+    chain -- measured over a few EAGER steps after the timed region (inside the replayed hipGraph events cannot bracket a
+    kernel; the kernels and what runs beside them are the same)."""
+
+    def __init__(self, mod, name, select):
+        self.mod, self.name, self.select, self.events = mod, name, select, []
+        self.fn = getattr(mod.lib, name)
+
+    def __enter__(self):
+        timer = self
+
+        class _Lib:
+            def __getattr__(self_, k):
+                f = getattr(timer.mod_lib, k)
+                if k != timer.name:
+                    return f
+
+                def wrapped(*a):
+                    if not timer.select(a):
+                        return f(*a)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rc = f(*a)
+                    e1.record()
+                    timer.events.append((e0, e1))
+                    return rc
+                return wrapped
+        self.mod_lib = self.mod.lib
+        self.mod.lib = _Lib()
+        return self
+
+    def __exit__(self, *exc):
+        self.mod.lib = self.mod_lib
+        return False
+
+    def mean_us(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) * 1e3 / max(1, len(self.events))
+
+
 def step_flops(cfg, B):
     """Algorithmic flops of one training step (SURVEY.md section 8d formulas): dense layers 2*cin*cout*rows forward, x3 for
     forward + data gradient + weight gradient (first layers of SA1 / the embedding have no data gradient: < 1 %)."""
@@ -193,6 +288,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads of the multi-core CPU baseline (8 is the fastest on the box's host)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up at size)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the extra unpipelined (drop-in caller) measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short cfg3 / cfg4 / cfg5 sub-records and the eval record")
     args = ap.parse_args()
 
     rank, local_rank, world = init_from_env()
@@ -256,6 +352,25 @@ def main():
     loss_val = float(loss)
     n_params, allreduce_bytes = sum(p.numel() for p in model.parameters()), trainer.bucket.nbytes
 
+    # -- the roofline kernel's duration INSIDE a step (beside the side-stream sampling chain, with the step's grid) ----------
+    in_step = None
+    if world == 1 and nxt is not None and not args.ablate and (per_gpu, cfg["n_points"]) == (8, 40000):
+        import spacap3d_amd.sa_mlp as sam
+        R2_ = per_gpu * 1024 * 32
+        keep_graph, trainer.graph = trainer.graph, None     # a few EAGER steps: same kernels, events can bracket them
+        with InStepTimer(sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)) as ist:
+            for _ in range(8):
+                trainer.step(data, next_data=nxt)
+            torch.cuda.synchronize()
+        if ist.events:
+            in_step = {"us": ist.mean_us(), "launches": len(ist.events)}
+        trainer.graph = keep_graph
+
+    # -- inference forward (greedy decoding) -------------------------------------------------------------------------------
+    eval_rec = None
+    if world == 1 and rank == 0 and not args.no_configs and not args.ablate:
+        eval_rec = eval_record(model, data)
+
     # -- drop-in caller: the model invoked unchanged, everything (sampling, grouping, neighbour search) inside the step --
     drop_in = None
     if world == 1 and nxt is not None and not args.no_drop_in and not args.ablate:
@@ -294,14 +409,23 @@ def main():
         # ones with `reserved_cus` CUs left to the sampling chain: that launch is timed as well
         KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
         c_mfma = KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3")
-        roof = KC.roofline_entry(c_mfma, KC.time_case(c_mfma), pmc)
+        iso_us = KC.time_case(c_mfma)
+        # `roofline` = the kernel function with the largest summed duration on the step's own stream (window table under
+        # profiles/: sa_mid_fwd_bf3s_kernel<128, .., pooled>, four launches per step), at its largest launch (SA2 layer 3),
+        # priced with the duration it has INSIDE the step and against the roof that binds the implemented arithmetic
+        roof = KC.roofline_entry(c_mfma, in_step["us"] if in_step else iso_us, pmc)
+        roof["launch_us_isolated_full_grid"] = iso_us
+        if in_step:
+            roof["in_step_launches_timed"] = in_step["launches"]
         if reserved_cus:
             KC.check(KC.lib.spacap_sa_reserve_cus(reserved_cus), "spacap_sa_reserve_cus")
-            roof["launch_us_with_the_steps_grid"] = KC.time_case(c_mfma)
+            roof["launch_us_isolated_with_the_steps_grid"] = KC.time_case(c_mfma)
             KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
-        roof["launches_timed"] = 20
-        roof["how"] = ("20 back-to-back launches through the C ABI between two HIP events on the launch stream, right after the "
-                       "timed steps (full grid; launch_us_with_the_steps_grid: " + str(reserved_cus) + " CUs left to the side stream's sampling chain, as the step launches it); traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+        roof["how"] = ("launch_us = mean duration of this launch INSIDE " + (str(in_step["launches"]) if in_step else "0") + " eager training steps run right "
+                       "after the timed region (HIP events on the step's stream around the C-ABI call; the sampling chain of the next "
+                       "batch runs beside it on the side stream and the forward grid leaves " + str(reserved_cus) + " CUs to it, as in the "
+                       "replayed step -- compare the kernel's row in profiles/*_step_timeline.txt); launch_us_isolated_*: 20 back-to-back "
+                       "launches with nothing beside them; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
         del c_mfma
         c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
         roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)
@@ -309,6 +433,9 @@ def main():
         c_dg = KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3")
         roof_dg = KC.roofline_entry(c_dg, KC.time_case(c_dg), pmc)
         del c_dg
+        c_ffn = KC.tf_ffn(B * 256, 2048, 0, dev)
+        roof_ffn = KC.roofline_entry(c_ffn, KC.time_case(c_ffn), pmc)
+        del c_ffn
         c_fps = KC.fps(B, N, m, dev)
         t_fps_us = KC.time_case(c_fps, iters=5, warm=1)
         roof_fps = KC.roofline_entry(c_fps, t_fps_us, pmc)
@@ -347,13 +474,19 @@ def main():
                        "sa_forward_gemm": {"0": "fp32 MFMA (v_mfma_f32_16x16x4_f32)", "1": "split-bf16 x3, LDS-staged activations"}.get(
                            os.environ.get("SPACAP_SA_BF16X3", "2"), "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
-            "roofline": roof, "roofline_more": [roof_dg, roof_hbm, roof_fps],
+            "roofline": roof, "roofline_more": [roof_dg, roof_hbm, roof_ffn, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
                      "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
             "ops": ops, "final_loss": loss_val,
         }
         if drop_in is not None:
             line["drop_in"] = drop_in
+        if eval_rec is not None:
+            line["eval"] = eval_rec
+        if world == 1 and args.config == "cfg2" and not args.no_configs and not args.ablate:
+            del model, data
+            torch.cuda.empty_cache()
+            line["configs"] = {name: quick_config(name, rank, dev) for name in ("cfg3", "cfg4", "cfg5")}
         if args.ablate:
             line["metric"] += f" [ABLATION {args.ablate}: not the headline metric]"
         if world == 1 and not args.no_cpu_baseline:
