@@ -566,12 +566,18 @@ int spacap_tf_ffn1_f32(const float *x, const float *W, const float *bias, long R
                        const uint64_t *seed_dev, float *h, spacap_stream_t stream);
 /* The feed-forward block as one launch per direction, chained through LDS (64-row x 128-hidden-unit tile per workgroup):
  *  mode 0: hid = dropout(relu(x Wa^T + bias)) [R,dff], Wa = w_1 [dff,128] (dropout element index r*dff + c);
- *          part[c][r][:] = hid[r, 128c:128c+128] Wb[:, 128c:128c+128]^T, Wb = w_2 [128,dff]
+ *          part[c][r][:] = hid[r, 128c:128c+128] Wb[:, 128c:128c+128]^T, Wb = w_2 [128,dff]; hid may be NULL (inference)
  *  mode 1: hid = (x Wa) * [y > 0] / (1 - drop_p), Wa = w_2 [128,dff], y = the forward hid;
  *          part[c][r][:] = hid[r, 128c:128c+128] Wb[128c:128c+128, :], Wb = w_1 [dff,128]
  * x [R,128]; part f32 [dff/128][R][128] is consumed by spacap_tf_rows_f32 (nparts = dff/128), which adds the slices in order. */
 int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, const float *Wb, const float *bias, const float *y, long R, int dff,
                       float drop_p, uint64_t seed, const uint64_t *seed_dev, float *hid, float *part, spacap_stream_t stream);
+/* One greedy-decoding step of self-attention over a key / value cache (replaces the prefix recomputation of
+ * models/transformer_captioner.py:435-438): qkv f32 [R, 3*128] = the packed projection of the NEW token of every sequence;
+ * its k, v are appended at position t of kcache / vcache f32 [R, T, 128] (T <= 32) and its q attends over positions 0..t;
+ * out f32 [R, 128] (heads concatenated).  h = 8, d_k = 16. */
+int spacap_decode_attn_f32(const float *qkv, float *kcache, float *vcache, long R, int h, int d_k, int T, int t, float scale,
+                           float *out, spacap_stream_t stream);
 /* Split-K product for the skinny feed-forward products (K = d_ff, N = 128: w_2 forward, the data gradient through w_1):
  * out[s][r][n] = sum_{k in slice s} a[r][k] Wop[k][n], Wop[k][n] = trans_w ? W[n][k] (W [N,K]) : W[k][n] (W [K,N]);
  * a [R,K], K and N multiples of 128, nsplit a divisor of K / 128 (spacap_tf_gemm_splits suggests the one that fills the

@@ -26,6 +26,8 @@
 // (weights as the A operand) so that a lane ends up with consecutive columns of one row.  Operands reach the
 // registers as 16-byte loads through a permutation of k inside every group of 16: lane (l15, lg) loads
 // X[l15][16 q + 4 lg .. + 3] and the i-th MFMA of the group uses element i of both operands.
+#include <math.h>
+
 #include "common.hpp"
 
 namespace {
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(const TfFfnArgs P) {
         o0[u] = valid ? v0 : 0.f, o1[u] = valid ? v1 : 0.f;
       }
     }
-    if (valid) {
+    if (valid && P.hid) {   // (inference passes no buffer: nothing is kept for a backward)
       st4(P.hid + (size_t)row * dff + c0 + e0, o0);
       st4(P.hid + (size_t)row * dff + c0 + e1, o1);
     }
@@ -656,6 +658,53 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(const TfFfnArgs P) {
       }
     }
   }
+}
+
+// One greedy-decoding step of self-attention over a key / value cache (models/transformer_captioner.py:402-453: the
+// reference re-runs the whole decoder prefix for every new word; with pre-norm layers and a causal mask the newest row of
+// that recomputation equals this incremental step).  One workgroup per sequence: the new token's k, v (from its packed
+// q|k|v row) are appended at position t of the caches [R][T][h*16], thread (head, key) forms one logit, a 32-lane softmax
+// per head, then thread (head, d) accumulates sum_key p[key] v[key][d] over coalesced 64-byte reads.  h = 8, d_k = 16, T <= 32.
+__global__ __launch_bounds__(256) void decode_attn_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+                                                          float *__restrict__ vc, int T, int t, float scale,
+                                                          float *__restrict__ out) {
+  constexpr int HD = 128;
+  __shared__ float s_p[8][32];
+  const int tid = threadIdx.x, hh = tid >> 5, tk = tid & 31;
+  const size_t row = blockIdx.x;
+  const float *me = qkv + row * 3 * HD;
+  float *kr = kc + row * (size_t)T * HD, *vr = vc + row * (size_t)T * HD;
+  if (tid < 32) st4(kr + (size_t)t * HD + tid * 4, ld4(me + HD + tid * 4));
+  else if (tid < 64) st4(vr + (size_t)t * HD + (tid - 32) * 4, ld4(me + 2 * HD + (tid - 32) * 4));
+  float logit = -INFINITY;
+  if (tk <= t) {
+    const float *kp = tk == t ? me + HD + hh * 16 : kr + (size_t)tk * HD + hh * 16;   // (position t: straight from the row)
+    float a = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 kv = ld4(kp + 4 * q), qv = ld4(me + hh * 16 + 4 * q);
+      a += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+    }
+    logit = a * scale;
+  }
+  float mx = logit;
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  const float e = tk <= t ? __expf(logit - mx) : 0.f;
+  float sum = e;
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  s_p[hh][tk] = e / sum;
+  __syncthreads();
+  // thread (head, half, d): keys of its parity
+  const int d = tk & 15, par = tk >> 4;
+  float acc = 0.f;
+  for (int k2 = par; k2 <= t; k2 += 2) {
+    const float v = k2 == t ? me[2 * HD + hh * 16 + d] : vr[(size_t)k2 * HD + hh * 16 + d];
+    acc += s_p[hh][k2] * v;
+  }
+  acc += __shfl_xor(acc, 16);
+  if (par == 0) out[row * HD + hh * 16 + d] = acc;
 }
 
 inline bool drop_params(float p, unsigned &thresh, float &scale) {
@@ -743,7 +792,7 @@ extern "C" int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, cons
   SPACAP_REQUIRE((mode == 0 || mode == 1) && R >= 0 && dff >= 128 && dff % 128 == 0 && drop_params(drop_p, P.thresh, P.scale),
                  "%s: (mode=%d, R=%ld, dff=%d, p=%f) unsupported", what, mode, R, dff, (double)drop_p);
   if (R == 0) return SPACAP_OK;
-  SPACAP_REQUIRE(x && Wa && Wb && hid && part && (mode == 0 || y) && al16(x) && al16(Wa) && al16(Wb) && al16(bias) && al16(y) &&
+  SPACAP_REQUIRE(x && Wa && Wb && (hid || mode == 0) && part && (mode == 0 || y) && al16(x) && al16(Wa) && al16(Wb) && al16(bias) && al16(y) &&
                      al16(hid) && al16(part), "%s: null or unaligned pointer", what);
   P.x = x, P.Wa = Wa, P.Wb = Wb, P.bias = bias, P.y = y, P.hid = hid, P.part = part, P.R = R, P.dff = dff;
   P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
@@ -759,6 +808,19 @@ extern "C" int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, cons
     if (small) hipLaunchKernelGGL((tf_ffn_kernel<true, 1>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((tf_ffn_kernel<true, 4>), grid, dim3(256), 0, s, P);
   }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_decode_attn_f32(const float *qkv, float *kcache, float *vcache, long R, int h, int d_k, int T, int t, float scale,
+                                      float *out, spacap_stream_t stream) {
+  const char *what = "spacap_decode_attn_f32";
+  SPACAP_REQUIRE(R >= 0 && h == 8 && d_k == 16 && T >= 1 && T <= 32 && t >= 0 && t < T, "%s: (R=%ld, h=%d, d_k=%d, T=%d, t=%d) unsupported",
+                 what, R, h, d_k, T, t);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(qkv && kcache && vcache && out && al16(qkv) && al16(kcache) && al16(vcache) && al16(out), "%s: null or unaligned pointer", what);
+  SPACAP_REQUIRE(R <= 2147483647L, "%s: too many sequences", what);
+  hipLaunchKernelGGL(decode_attn_kernel, dim3((unsigned)R), dim3(256), 0, spacap::as_stream(stream), qkv, kcache, vcache, T, t, scale, out);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -330,3 +330,60 @@ def run_stack(layers, final_norm, x, mask):
             (out,) = Ffn2Ln.apply(h, parts, x1, ff.w_1.weight, ff.w_2.weight, ff.w_2.bias, final_norm.a_2, final_norm.b_2,
                                   final_norm.eps, p3, pf, seed(p3), None, None)
     return out
+
+
+@torch.no_grad()
+def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
+    """Greedy decoding of R sequences through the early-guide decoder stack ``dec`` with pre-allocated key / value caches
+    (models/transformer_captioner.py:402-453; the reference re-runs encoder and decoder prefix for every word).  Position 0
+    is the object indicator token (R, 128), position 1 the start symbol, then every chosen word is fed back; one token per
+    sequence per step, four launches per layer and step (the training kernels with dropout off + spacap_decode_attn_f32).
+    Returns the (R, n_words) int64 word ids."""
+    import math
+    import torch.nn.functional as F
+    layers = list(dec.layers)
+    R, dev = indicator.shape[0], indicator.device
+    T = n_words + 1
+    st = torch.cuda.current_stream(dev).cuda_stream
+    packs = [_packed(l.self_attn)[:2] for l in layers]
+    h, dk = layers[0].self_attn.h, layers[0].self_attn.d_k
+    dff = layers[0].feed_forward.w_1.out_features
+    S = dff // 128
+    scale = 1.0 / math.sqrt(dk)
+    with torch.cuda.device(dev):
+        kc = [_new(dev, R, T, D_MODEL) for _ in layers]
+        vc = [_new(dev, R, T, D_MODEL) for _ in layers]
+        qkv, a, x1, x2, n2, n = _new(dev, R, 3 * D_MODEL), _new(dev, R, D_MODEL), _new(dev, R, D_MODEL), _new(dev, R, D_MODEL), \
+            _new(dev, R, D_MODEL), _new(dev, R, D_MODEL)
+        parts = _new(dev, S, R, D_MODEL)
+        ys = torch.empty(R, n_words, dtype=torch.long, device=dev)
+        sqrt_d = math.sqrt(embed.d_model)
+        x = indicator.contiguous()
+        word = torch.full((R,), int(sos), dtype=torch.long, device=dev)
+        for t in range(T):
+            if t >= 1:
+                x = embed.lut(word) * sqrt_d + pe[0, t - 1]
+            n0 = layers[0].sublayer[0].norm
+            _rows(0, R, dev, res=x, ln_a=n0.a_2, ln_b=n0.b_2, eps=n0.eps, w2=packs[0][0], bias2=packs[0][1], n2=3 * D_MODEL, out2=qkv)
+            xres = x
+            for i, l in enumerate(layers):
+                sa, ff, nf = l.self_attn, l.feed_forward, l.sublayer[-1].norm
+                check(lib.spacap_decode_attn_f32(qkv.data_ptr(), kc[i].data_ptr(), vc[i].data_ptr(), R, h, dk, T, t, scale, a.data_ptr(),
+                                                 st), "spacap_decode_attn_f32")
+                _rows(0, R, dev, a1=a, w1=sa.linears[-1].weight, bias1=sa.linears[-1].bias, k1=D_MODEL, res=xres, x_out=x1,
+                      ln_a=nf.a_2, ln_b=nf.b_2, eps=nf.eps, n_out=n2)
+                check(lib.spacap_tf_ffn_f32(0, n2.data_ptr(), ff.w_1.weight.data_ptr(), ff.w_2.weight.data_ptr(),
+                                            ff.w_1.bias.data_ptr(), None, R, dff, 0.0, 0, None, None, parts.data_ptr(), st),
+                      "spacap_tf_ffn_f32")
+                if i + 1 < len(layers):
+                    nn_ = layers[i + 1].sublayer[0].norm
+                    _rows(0, R, dev, a1=parts, nparts=S, bias1=ff.w_2.bias, res=x1, x_out=x2, ln_a=nn_.a_2, ln_b=nn_.b_2, eps=nn_.eps,
+                          w2=packs[i + 1][0], bias2=packs[i + 1][1], n2=3 * D_MODEL, out2=qkv)
+                    xres = x2
+                else:
+                    _rows(0, R, dev, a1=parts, nparts=S, bias1=ff.w_2.bias, res=x1, ln_a=dec.norm.a_2, ln_b=dec.norm.b_2,
+                          eps=dec.norm.eps, n_out=n)
+            if t >= 1:
+                word = F.linear(n, generator.proj.weight, generator.proj.bias).argmax(dim=-1)
+                ys[:, t - 1] = word
+    return ys

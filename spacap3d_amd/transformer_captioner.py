@@ -553,6 +553,13 @@ class TransformerDecoderModel(nn.Module):
         else:
             indicator, dec_memory = obj_flat.unsqueeze(1), memory
         embed, pos = self.model.tgt_embed[0], self.model.tgt_embed[1]
+        st = getattr(ops(), "tf_stack", None)
+        if self.early_guide and not self.training and st is not None and st.stack_supported(dec.layers, indicator.squeeze(1)):
+            # pre-allocated key / value caches, one token per sequence and step, four launches per layer (tf_layer.greedy_decode)
+            words = st.greedy_decode(dec, self.model.generator, embed, pos.pe, indicator.squeeze(1), self.word_to_idx["sos"],
+                                     MAX_DES_LEN + 1)
+            ep["lang_cap"] = words.view(B, K, -1)
+            return ep
         if self.early_guide:
             # positions: 0 = object indicator, 1.. = words (sinusoid added to the words only, as tgt_embed does)
             x_new = torch.cat((indicator, pos.dropout(embed(ys) + pos.pe[:, :1])), dim=1)

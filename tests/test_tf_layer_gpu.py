@@ -241,3 +241,26 @@ def test_dropout_masks_agree_between_forward_and_backward(tf, kind):
         assert abs(rate - (1 - p)) < 0.02, rate
         assert rel(h1[kept], h0[kept] / (1 - p)) < 1e-6
         assert rel(h0, torch.relu(n2.double() @ W1.double().t() + b1.double())) < 2e-6
+
+
+def test_decode_attention_step_over_the_cache(tf):
+    """spacap_decode_attn_f32: appending the new token's k, v and attending over positions 0..t equals the last row of causal
+    attention over the whole prefix (what the reference recomputes at every word, models/transformer_captioner.py:435-438)."""
+    from spacap3d_amd._native import check, lib
+    R, T, h, dk = 37, 32, 8, 16
+    kc, vc = torch.zeros(R, T, 128, device=DEV), torch.zeros(R, T, 128, device=DEV)
+    out = torch.empty(R, 128, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+    for t in range(T):
+        qkv = _rand(R, 384, seed=100 + t)
+        rows.append(qkv)
+        check(lib.spacap_decode_attn_f32(qkv.data_ptr(), kc.data_ptr(), vc.data_ptr(), R, h, dk, T, t, 0.25, out.data_ptr(), st), "dec")
+        allr = torch.stack(rows, 1).double()                                   # (R, t+1, 384)
+        q = allr[:, -1, :128].view(R, h, 1, dk)
+        k = allr[:, :, 128:256].view(R, t + 1, h, dk).transpose(1, 2)
+        v = allr[:, :, 256:].view(R, t + 1, h, dk).transpose(1, 2)
+        p = torch.softmax(q @ k.transpose(-1, -2) * 0.25, -1)
+        want = (p @ v).transpose(1, 2).reshape(R, 128)
+        assert rel(out, want) < 3e-6, t
+        assert torch.equal(kc[:, t], qkv[:, 128:256]) and torch.equal(vc[:, t], qkv[:, 256:])
