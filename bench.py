@@ -15,7 +15,7 @@ Extra objects on the line (tier contract):
   roofline      the dominant kernel of the step's critical path: the largest shared-MLP GEMM (SA2 layer 3, 262 144 rows,
                 128 -> 256 channels; that kernel family is the largest block of main-stream time).  Default implementation:
                 `sa_mid_fwd_bf3s_kernel` -- fp32 results from bf16 matrix instructions, every fp32 product as 6 exact
-                bf16 products with fp32 accumulation (SPACAP_SA_BF16X3=0 selects the fp32-MFMA
+                bf16 products with fp32 accumulation (SPACAP_SA_F32MFMA=1 selects the fp32-MFMA
                 kernel, whose line is kept under profiles/ as well).
                 achieved = algorithmic flops 2*cin*cout*R / its average launch duration, measured live with HIP
                 events around back-to-back launches through the C ABI on the launch stream right after the timed steps
@@ -471,8 +471,8 @@ def main():
                        "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None,
                        "prefetch_as_graph": bool(graphed and nxt is not None and trainer_prefetch_graph), "reserved_cus_forward": reserved_cus, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
                        "side_stream_branches": bool(args.streams),
-                       "sa_forward_gemm": {"0": "fp32 MFMA (v_mfma_f32_16x16x4_f32)", "1": "split-bf16 x3, LDS-staged activations"}.get(
-                           os.environ.get("SPACAP_SA_BF16X3", "2"), "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
+                       "sa_forward_gemm": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if os.environ.get("SPACAP_SA_F32MFMA", "0") not in ("", "0") else
+                                           "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
             "roofline": roof, "roofline_more": [roof_dg, roof_hbm, roof_ffn, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,

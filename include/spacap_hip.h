@@ -186,6 +186,9 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
  *  lib/pointnet2/pointnet2_modules.py:253-259, forward and backward).  z f32 [B,C,L] dense (L = npoint*nsample).
  * `workspace`: spacap_bn_workspace_bytes(C) bytes, shared by the forward-statistics and backward calls. */
 size_t spacap_bn_workspace_bytes(int C);
+/* process-wide: 1 (default) = small tensors (<= 32 768 elements per channel) take the one-launch kernels, 0 = always the
+ * partial / final / apply form (identical results; for tests). */
+int spacap_bn_set_single_launch(int enabled);
 /* stats f32 [C,2] = (batch mean, 1/sqrt(biased var + eps)); running_mean/var (nullable pair) are updated with
  * `momentum` and the unbiased variance, as torch.nn.BatchNorm does. */
 int spacap_bn_stats_f32(const float *z, int B, int C, long L, float eps, float momentum, float *running_mean,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "spacap_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_grad_pm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_bn_workspace_bytes": (ctypes.c_size_t, [_i]),
+    "spacap_bn_set_single_launch": (_i, [_i]),
     "spacap_bn_stats_f32": (_i, [_p, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p]),
     "spacap_bn_relu_apply_f32": (_i, [_p, _p, _p, _p, _i, _i, _l, _p, _p]),
     "spacap_bn_relu_train_f32": (_i, [_p, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p]),

@@ -18,6 +18,8 @@
 // Everything is deterministic (fixed partial-sum order, no atomics).
 #include <math.h>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace {
@@ -366,9 +368,9 @@ __global__ __launch_bounds__(STAT_THREADS) void bn_relu_bwd_small_kernel(
   }
 }
 
+static std::atomic<int> g_single_launch{1};   // spacap_bn_set_single_launch (tests compare the two forms bit for bit)
 inline bool bn_small(int B, int C, long L) {
-  static const bool off = getenv("SPACAP_BN_THREE_PASS") != nullptr;
-  return !off && (L & 3) == 0 && C >= 64 && (double)B * (double)L <= 32768.0;
+  return g_single_launch.load(std::memory_order_relaxed) != 0 && (L & 3) == 0 && C >= 64 && (double)B * (double)L <= 32768.0;
 }
 
 int pick_split(int C, double elems_per_channel) {
@@ -505,5 +507,12 @@ extern "C" int spacap_bn_relu_max_bwd_f32(const float *z, const float *stats, co
   hipLaunchKernelGGL((bn_bwd_dz_kernel<true>), dim3(grid_x(L), B * C), dim3(256), 0, s, z, dP, arg, stats, gamma, beta,
                      coef, C, L, S, dz);
   SPACAP_CHECK_LAUNCH("spacap_bn_relu_max_bwd_f32");
+  return SPACAP_OK;
+}
+
+/* 1 (default): tensors with <= 32 768 elements per channel take the one-launch kernels; 0: always the partial / final / apply
+   form (same fp32 expressions and fp64 sums: tests compare the two bit for bit). */
+extern "C" int spacap_bn_set_single_launch(int enabled) {
+  g_single_launch.store(enabled ? 1 : 0, std::memory_order_relaxed);
   return SPACAP_OK;
 }

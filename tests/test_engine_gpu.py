@@ -408,5 +408,11 @@ def test_gradient_slots_are_scoped_to_the_step_and_accumulation_outside_it_is_pl
     tr.loss(dict(data))["loss"].backward()
     g1 = [p.grad.clone() for p in params]
     tr.loss(dict(data))["loss"].backward()      # accumulates into the existing .grad
-    for p, a in zip(params, g1):
-        assert torch.allclose(p.grad, 2 * a, rtol=1e-4, atol=1e-6 * float(a.abs().max() + 1e-12))
+    names = {id(p): n for n, p in model.named_parameters()}
+    bad = []
+    gmax = max(float(a.abs().max()) for a in g1)
+    for p, a in zip(params, g1):   # (an aliased slot would give 4x: the bar only has to separate 2x from that; biases in
+        err = float((p.grad - 2 * a).abs().max())   # front of a BatchNorm have an analytically zero gradient: noise only)
+        if err > 1e-3 * max(float(2 * a.abs().max()), 1e-3 * gmax):
+            bad.append((names[id(p)], err, float(a.abs().max()), float((p.grad / (a + 1e-30)).median())))
+    assert not bad, bad[:8]

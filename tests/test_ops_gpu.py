@@ -369,31 +369,29 @@ def test_fused_bn_relu_max_matches_torch(hip_ext, B, C, P, Sn, pool):
 @pytest.mark.gpu
 def test_single_launch_bn_equals_the_three_pass_form(hip_ext):
     """Small tensors take one launch per direction (csrc/bn_relu.hip: bn_relu_train_small_kernel / bn_relu_bwd_small_kernel):
-    outputs, gradients and running statistics must equal the partial / final / apply form (SPACAP_BN_THREE_PASS=1, child
-    process) bit for bit -- same fp32 expressions, fp64 sums."""
-    import subprocess
-    import tempfile
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-from spacap3d_amd.fused_bn import bn_relu_train
-torch.manual_seed(5)
-outs = []
-for (B, C, L) in ((8, 256, 1024), (8, 128, 256), (2, 64, 16384)):
-    z = torch.randn(B, C, L, device="cuda:0", requires_grad=True)
-    bn = torch.nn.BatchNorm1d(C).cuda().train()
-    with torch.no_grad():
-        bn.weight.uniform_(-1.0, 1.5); bn.bias.normal_()
-    y = bn_relu_train(z, bn)
-    (y * torch.randn_like(y)).sum().backward()
-    outs += [y.detach().cpu(), z.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), bn.running_mean.cpu(), bn.running_var.cpu()]
-torch.save(outs, sys.argv[1])
-''' % ROOT
-    with tempfile.TemporaryDirectory() as tmp:
-        a, b = os.path.join(tmp, "a.pt"), os.path.join(tmp, "b.pt")
-        for path, env in ((a, {}), (b, {"SPACAP_BN_THREE_PASS": "1"})):
-            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
-            assert r.returncode == 0, r.stderr[-2000:]
-        A, Bq = torch.load(a), torch.load(b)
+    outputs, gradients and running statistics must equal the partial / final / apply form (spacap_bn_set_single_launch(0))
+    bit for bit -- same fp32 expressions, fp64 sums."""
+    from spacap3d_amd._native import lib
+    from spacap3d_amd.fused_bn import bn_relu_train
+
+    def run():
+        torch.manual_seed(5)
+        outs = []
+        for (B, C, L) in ((8, 256, 1024), (8, 128, 256), (2, 64, 16384)):
+            z = torch.randn(B, C, L, device="cuda:0", requires_grad=True)
+            bn = torch.nn.BatchNorm1d(C).cuda().train()
+            with torch.no_grad():
+                bn.weight.uniform_(-1.0, 1.5)
+                bn.bias.normal_()
+            y = bn_relu_train(z, bn)
+            (y * torch.randn_like(y)).sum().backward()
+            outs += [y.detach().cpu(), z.grad.cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), bn.running_mean.cpu(), bn.running_var.cpu()]
+        return outs
+    A = run()
+    try:
+        assert lib.spacap_bn_set_single_launch(0) == 0
+        Bq = run()
+    finally:
+        lib.spacap_bn_set_single_launch(1)
     for i, (x, y) in enumerate(zip(A, Bq)):
         assert torch.equal(x, y), (i, (x - y).abs().max().item())

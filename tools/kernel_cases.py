@@ -48,7 +48,7 @@ def sa_mid_fwd(R, cin, cout, dev, label):
         check(lib.spacap_sa_mid_fwd_f32(zin.data_ptr(), st.data_ptr(), W.data_ptr(), R, cin, cout, zout.data_ptr(),
                                         part.data_ptr(), _st(dev)), "sa_mid_fwd")
     import os
-    split = os.environ.get("SPACAP_SA_BF16X3", "2") != "0" and cout % 128 == 0   # the library's default for these shapes
+    split = os.environ.get("SPACAP_SA_F32MFMA", "0") in ("", "0") and cout % 128 == 0   # the library's default for these shapes
     return dict(name=f"sa_mid_fwd {cin}->{cout} R={R} ({label})", kernel="sa_mid_fwd", run=run, bf16_products=6 if split else 0,
                 flops=2.0 * cin * cout * R, bytes=4.0 * R * (cin + cout), keep=(zin, st, W, zout, part),
                 what=f"{label}: z_out = relu(bn(z_in)) W^T + batch statistics of z_out, {R} rows, {cin} -> {cout} channels")
@@ -69,7 +69,7 @@ def sa_dgrad(R, ck, cp, pooled, S, dev, label):
     # reads: z_k (dense dz is rebuilt from it), z_prev (ReLU mask), dy (dense) or the pooled gradient; writes dy_prev
     byts = 4.0 * R * (ck + 2 * cp) + (4.0 * G * ck + G * ck if pooled else 4.0 * R * ck)
     import os
-    split = (os.environ.get("SPACAP_SA_BF16X3", "2") == "2" and not os.environ.get("SPACAP_SA_DGRAD_F32") and ck in (128, 256)
+    split = (os.environ.get("SPACAP_SA_F32MFMA", "0") in ("", "0") and ck in (128, 256)
              and cp % 64 == 0 and R >= 49152)   # the library's default for these shapes (csrc/sa_bf3_dgrad.inc)
     return dict(name=f"sa_dgrad {ck}->{cp} R={R} {'pooled' if pooled else 'dense'} ({label})", kernel="sa_dgrad", run=run,
                 bf16_products=6 if split else 0, flops=2.0 * ck * cp * R, bytes=byts, keep=(dy, arg, zk, zp, coef, stp, W, dyp, part),

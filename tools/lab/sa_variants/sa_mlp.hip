@@ -202,7 +202,11 @@ struct TailArgs {
   float *pred;         // [R][NO3]
   int NO3;             // <= 16
 };
-template <int CIN, int NT, bool TAIL = false, int TMT = 64>
+// LAB != 0: timing experiments only (tools/lab/mid_variants.py; results are wrong on purpose):
+//   1 = no MFMA (loads, staging, epilogue, stores only)   2 = no global stores   3 = no global loads after the first tile
+//   4 = MFMA B operand from registers (INVALID: the compiler merges the then identical accumulators)
+//   5 = MFMA loop + LDS operand reads only (no global traffic, no staging, no barriers, no epilogue)
+template <int CIN, int NT, bool TAIL = false, int LAB = 0, int TMT = 64>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
                                                          float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
   auto tile = [&](long t, auto full, bool stores_pending) {
     constexpr bool FULL = decltype(full)::value;
     const long row0 = t * TMT;
-    {
+    if (LAB != 5) {
       wait_prefetch(stores_pending);
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -284,14 +288,14 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
         st4(&s_a[row * LD + c4 * 4], a);
       }
       __syncthreads();
-      if (FULL) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
+      if (FULL && LAB != 3) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
     }
     f32x4 acc[TMT / 16][NT];
 #pragma unroll
     for (int mt = 0; mt < TMT / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
+    if (LAB != 1) {
       // B operand by ds_read_b128, software-pipelined in chunks of (16 rows x half of K): two register buffers; the
       // reads of chunk c + 2 are issued right after the MFMAs of chunk c, i.e. one chunk of MFMA time (16 * NT
       // instructions) before their first use.  sched_barriers pin that order (the scheduler otherwise sinks every
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       auto bload = [&](int c) {
         const int mt = c / (KQ / KH), h = c % (KQ / KH);
 #pragma unroll
-        for (int q = 0; q < KH; ++q) bq[c & 1][q] = ld4(bsrc + mt * 16 * LD + (h * KH + q) * 8);
+        for (int q = 0; q < KH; ++q) bq[c & 1][q] = LAB == 4 ? f32x4{mean[0], sc[1], be[2], mean[3]} : ld4(bsrc + mt * 16 * LD + (h * KH + q) * 8);
       };
       bload(0);
       if (NCH > 1) bload(1);
@@ -320,6 +324,13 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
         __builtin_amdgcn_sched_barrier(0);
         if (c + 2 < NCH) bload(c + 2);
       }
+    }
+    if (LAB == 5) {   // MFMA + LDS operand reads only: keep the accumulators alive, skip the epilogue
+#pragma unroll
+      for (int mt = 0; mt < TMT / 16; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ssum[j] += acc[mt][j];
+      return;
     }
 #pragma unroll
     for (int mt = 0; mt < TMT / 16; ++mt)
@@ -342,7 +353,9 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
       const int row = or0 + i * OSTEP;
-      if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
+      if (LAB == 2) {
+        if (row0 + row == R + 12345) st4(zout, ld4(&s_o[row * LDO + o4 * 4]));   // never true: keeps the LDS reads alive
+      } else if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
     }
     if (TAIL) {   // wave w: rows 16 w .. 16 w + 15 of the tile times the padded output weights
       f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
@@ -389,16 +402,244 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     }
 }
 
-// ---- the same layer on the bf16 matrix cores with fp32-equivalent accuracy ("bf16 x 3") ---------------------------------
-// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950, which makes these 128-wide layers matrix-core bound.  Every fp32
-// operand is split exactly into three bf16 pieces, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2):
-// 3 x 8 = 24 significant bits), and the product a*w is evaluated as the six bf16 products with weight >= 2^-16
-//     a1 w1 + a1 w2 + a2 w1 + a2 w2 + a1 w3 + a3 w1        (dropped: a2 w3, a3 w2, a3 w3 <= 2^-24 |a w|)
-// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: 6/16 of the fp32-MFMA time for the same fp32-level result.
-// The kernels are in sa_bf3.inc (forward layers) and sa_bf3_dgrad.inc (data gradient).  Earlier variants of this layer (a
-// 32x32x2 fp32-MFMA kernel, an LDS-staged split-bf16 kernel, a streaming fp32 kernel, timing builds) live in
-// tools/lab/sa_variants/ and are not part of the library.
+// ---- the same layer on v_mfma_f32_32x32x2_f32 ------------------------------------------------------------------
+// Measured on MI355X (tools/lab/mfma_rate2.hip): from registers the 32x32x2 fp32 MFMA sustains 140 - 147 TFLOP/s with
+// any number of accumulators and waves per SIMD, the 16x16x4 form 94 - 144 depending on the accumulator rotation
+// (113 - 124 with the 8 accumulators the kernel above cycles through).  Same tile pipeline as sa_mid_fwd_kernel; only
+// the operand mapping differs:
+//   A = weights: lane (c = lane % 32, kk = lane / 32) holds W[cb + c][kperm(s, kk)] for step s (CIN / 2 registers);
+//   B = activations from LDS: lane (r = lane % 32, kk) reads row rb * 32 + r, words kk * CIN / 2 + 4 q .. + 3 with one
+//       ds_read_b128 per 4 steps -- kperm(s, kk) = kk * CIN / 2 + s; with LD = CIN + 4 (== 4 mod 64 words) the 16 rows of
+//       every ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32) tile the 64 banks exactly once;
+//   D: lane (r, kk), register v = channel cb + 8 (v / 4) + 4 kk + v % 4 of row r: four 16-byte chunks per row block.
+// A workgroup covers COB = 64 NT output channels in NCB = 2 NT blocks of 32; with NT = 1 two waves share a channel
+// block and split the tile's two 32-row blocks.  B reads are software-pipelined in chunks of 16 steps (two register
+// buffers, reads of chunk c + 2 issued right after the MFMAs of chunk c; sched_barriers pin the order).
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 using f32x16 = float __attribute__((ext_vector_type(16)));
+template <int CIN, int NT, bool TAIL = false, int LAB = 0>
+__global__ __launch_bounds__(256) void sa_mid_fwd32_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
+                                                           const float *__restrict__ W, int Cout, long R,
+                                                           float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
+  constexpr int LD = CIN + 4, KS2 = CIN / 2, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
+  constexpr int NCB = COB / 32, WPC = 4 / NCB, RB = (TM / 32) / WPC;   // channel blocks, waves per block, row blocks per wave
+  constexpr int CHS = 16, NCHB = KS2 / CHS, NCH = RB * NCHB;            // steps per chunk, chunks per row block, per tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_a = smem;             // [TM][LD]   activations (MFMA B operand)
+  float *s_o = smem + TM * LD;   // [TM][LDO]  output tile, row-major
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int l15 = lane & 15, lg = lane >> 4;   // (TAIL: the 9-column product keeps the 16x16x4 form)
+  const int cw = w % NCB, rw = w / NCB;         // this wave's channel block and (NT = 1) row half
+  const int cbb = blockIdx.y * COB, wc = cw * 32, cb = cbb + wc;
+  float wf[KS2];
+#pragma unroll
+  for (int q = 0; q < KS2 / 4; ++q) {
+    const f32x4 w4 = ld4(W + (size_t)(cb + l31) * CIN + kk * KS2 + q * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wf[q * 4 + u] = w4[u];
+  }
+  const int c4 = tid % C4, r0 = tid / C4, o4 = tid % O4, or0 = tid / O4;
+  f32x4 mean = {0.f, 0.f, 0.f, 0.f}, sc = mean, be = mean;
+  if (!TAIL) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+      mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+    }
+  }
+  float wf3[TAIL ? COB / 4 : 1];
+  f32x4 bv[4];
+  if (TAIL) {
+#pragma unroll
+    for (int ks = 0; ks < COB / 4; ++ks) wf3[TAIL ? ks : 0] = l15 < ta.NO3 ? ta.W3[(size_t)l15 * Cout + ks * 4 + lg] : 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) bv[b] = ld4(ta.bias + cb + 8 * b + 4 * kk);
+  }
+  f32x4 ssum[4], ssq[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ssum[b] = ssq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TM - 1) / TM;
+  f32x4 pre[NV];
+  auto fetch = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
+    }
+  };
+  auto wait_prefetch = [&](bool stores_pending) {
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));  // uses of pre[] stay below the wait
+  };
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
+    const long row0 = t * TM;
+    if (LAB != 5) {
+      wait_prefetch(stores_pending);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int row = r0 + i * RSTEP;
+        f32x4 a;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
+        st4(&s_a[row * LD + c4 * 4], a);
+      }
+      __syncthreads();
+      if (FULL && LAB != 3) fetch(t + gridDim.x);  // (the ragged tile is the last one: nothing to prefetch)
+    }
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[rb][v] = 0.f;
+    if (LAB != 1) {
+      const float *bsrc = s_a + (rw * RB * 32 + l31) * LD + kk * KS2;
+      f32x4 bq[2][CHS / 4];
+      auto bload = [&](int c) {
+        const int rb = c / NCHB, h = c % NCHB;
+#pragma unroll
+        for (int q = 0; q < CHS / 4; ++q) bq[c & 1][q] = LAB == 4 ? f32x4{mean[0], sc[1], be[2], mean[3]} : ld4(bsrc + rb * 32 * LD + h * CHS + q * 4);
+      };
+      bload(0);
+      if (NCH > 1) bload(1);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int rb = c / NCHB, h = c % NCHB;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CHS / 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[rb] = MFMA32(wf[h * CHS + q * 4 + u], bq[c & 1][q][u], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) bload(c + 2);
+      }
+    }
+    if (LAB == 5) {   // MFMA + LDS operand reads only: keep the accumulators alive, skip the epilogue
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) ssum[b] += f32x4{acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+      return;
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int trow = (rw * RB + rb) * 32 + l31;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 v = {acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+        if (TAIL) {
+          v += bv[b];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        } else if (FULL || row0 + trow < R) {
+          ssum[b] += v;
+          ssq[b] += v * v;
+        }
+        st4(&s_o[trow * LDO + wc + 8 * b + 4 * kk], v);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NO; ++i) {
+      const int row = or0 + i * OSTEP;
+      if (LAB == 2) {
+        if (row0 + row == R + 12345) st4(zout, ld4(&s_o[row * LDO + o4 * 4]));   // never true: keeps the LDS reads alive
+      } else if (FULL || row0 + row < R) st4(zout + (size_t)(row0 + row) * Cout + cbb + o4 * 4, ld4(&s_o[row * LDO + o4 * 4]));
+    }
+    if (TAIL) {   // wave w: rows 16 w .. 16 w + 15 of the tile times the padded output weights
+      f32x4 a3 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < COB / 4; ++ks) a3 = MFMA16(wf3[TAIL ? ks : 0], s_o[(w * 16 + l15) * LDO + ks * 4 + lg], a3);
+      const long row = row0 + w * 16 + l15;
+      if (FULL || row < R) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (4 * lg + u < ta.NO3) ta.pred[(size_t)row * ta.NO3 + 4 * lg + u] = a3[u] + ta.b3[4 * lg + u];
+      }
+    }
+  };
+  const long nfull = R / TM;
+  bool pending = false;
+  if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(pre[i]));
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    fetch(nfull);
+    tile(nfull, std::false_type{}, false);
+  }
+  if (TAIL) return;
+  // per-lane sums -> per-wave sums over the 32 rows a lane group holds (lanes with l31 == 0 keep them)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = ssum[b][u], q = ssq[b][u];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      ssum[b][u] = a, ssq[b][u] = q;
+    }
+  if (WPC > 1) {   // two waves share a channel block: add the second wave's sums through LDS
+    __syncthreads();
+    float *s_red = smem;   // [NCB][2][32]
+    if (rw == 1 && l31 == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s_red[(cw * 2 + 0) * 32 + 8 * b + 4 * kk + u] = ssum[b][u];
+          s_red[(cw * 2 + 1) * 32 + 8 * b + 4 * kk + u] = ssq[b][u];
+        }
+    }
+    __syncthreads();
+    if (rw == 0 && l31 == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ssum[b][u] += s_red[(cw * 2 + 0) * 32 + 8 * b + 4 * kk + u];
+          ssq[b][u] += s_red[(cw * 2 + 1) * 32 + 8 * b + 4 * kk + u];
+        }
+    }
+  }
+  if (rw == 0 && l31 == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = cb + 8 * b + 4 * kk + u;
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)ssum[b][u];
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)ssq[b][u];
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
+      }
+  }
+}
+
+// ---- the same layer on the bf16 matrix cores with fp32-equivalent accuracy ("bf16 x 3") ---------------------------------
+// fp32 MFMA runs at 1/16 of the bf16 MFMA rate on gfx950, which makes these 128-wide layers matrix-core bound.  Here every
+// fp32 operand is split exactly into three bf16 pieces, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 -
+// x2): 3 x 8 = 24 significant bits), and the product a*w is evaluated as the six bf16 products with weight >= 2^-16
+//     a1 w1 + a1 w2 + a2 w1 + a2 w2 + a1 w3 + a3 w1        (dropped: a2 w3, a3 w2, a3 w3 <= 2^-24 |a w|)
+// each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: 6/16 of the fp32-MFMA time for the same fp32-level result
+// (the dropped terms are of the size of ONE fp32 rounding of the product; the summation order differs from the fp32 kernel
+// as it does between any two GEMM implementations).  The kernel is then HBM bound.
+//   weights: split once per workgroup into registers (lane (c = lane % 32, g = lane / 32): 8 consecutive k of channel cb + c
+//            per MFMA step and piece);
+//   activations: BN + ReLU as before while staging, then split; three bf16 images [TM][CIN + 8] in LDS (row stride == 4
+//            words mod 64: conflict-free ds_read_b128 of the B operand, 8 consecutive k of row r per lane);
+//   accumulators are stored straight from registers (16-byte pieces, 32 bytes per row and instruction, 4 instructions per
+//            128-byte line back to back): no output tile in LDS.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
@@ -408,8 +649,157 @@ __device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l)
   m = (__bf16)r;
   l = (__bf16)(r - (float)m);
 }
+template <int CIN, int LAB = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void sa_mid_fwd_bf3_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
+                                                             const float *__restrict__ W, int Cout, long R,
+                                                             float *__restrict__ zout, double *__restrict__ part) {
+  constexpr int LDB = CIN + 8, KS = CIN / 16, IMG = TM * LDB, C4 = CIN / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
+  constexpr int COB = 128, RB = TM / 32, NCH = RB * KS;
+  extern __shared__ __attribute__((aligned(16))) __bf16 simg[];   // [3][TM][LDB]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int cbb = blockIdx.y * COB, cb = cbb + 32 * w;
+  bf16x8 wsp[3][KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const float *src = W + (size_t)(cb + l31) * CIN + 16 * s + 8 * kk;
+    const f32x4 lo = ld4(src), hi = ld4(src + 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __bf16 a, b, c;
+      split3(i < 4 ? lo[i] : hi[i - 4], a, b, c);
+      wsp[0][s][i] = a, wsp[1][s][i] = b, wsp[2][s][i] = c;
+    }
+  }
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 mean, sc, be;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *s = st_in + (size_t)(c4 * 4 + u) * 4;
+    mean[u] = s[0], sc[u] = s[2], be[u] = s[3];
+  }
+  f32x4 ssum[4], ssq[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) ssum[b] = ssq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ntiles = (R + TM - 1) / TM;
+  f32x4 pre[NV];
+  auto fetch = [&](long t) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      long grow = t * TM + r0 + i * RSTEP;
+      grow = grow < R ? grow : R - 1;
+      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
+    }
+  };
+  constexpr int NST = RB * 4;   // global stores per lane and tile
+  auto wait_prefetch = [&](bool stores_pending) {
+    if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) asm volatile("" : "+v"(pre[i]));
+  };
+  auto tile = [&](long t, auto full, bool stores_pending) {
+    constexpr bool FULL = decltype(full)::value;
+    const long row0 = t * TM;
+    wait_prefetch(stores_pending);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      bf16x4 p0, p1, p2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float a = fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        if (!FULL && row0 + row >= R) a = 0.f;
+        __bf16 h, m, l;
+        split3(a, h, m, l);
+        p0[u] = h, p1[u] = m, p2[u] = l;
+      }
+      __bf16 *dst = simg + row * LDB + c4 * 4;
+      *reinterpret_cast<bf16x4 *>(dst) = p0;
+      *reinterpret_cast<bf16x4 *>(dst + IMG) = p1;
+      *reinterpret_cast<bf16x4 *>(dst + 2 * IMG) = p2;
+    }
+    __syncthreads();
+    if (FULL && LAB != 3) fetch(t + gridDim.x);
+    f32x16 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[rb][v] = 0.f;
+    {
+      const __bf16 *bsrc = simg + l31 * LDB + 8 * kk;
+      bf16x8 bq[2][3];
+      auto bload = [&](int c) {
+        const int rb = c / KS, s = c % KS;
+#pragma unroll
+        for (int pz = 0; pz < 3; ++pz)
+          bq[c & 1][pz] = *reinterpret_cast<const bf16x8 *>(bsrc + pz * IMG + rb * 32 * LDB + 16 * s);
+      };
+      bload(0);
+      bload(1);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int rb = c / KS, s = c % KS;
+        __builtin_amdgcn_sched_barrier(0);
+        // smallest terms first
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][2], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[2][s], bq[c & 1][0], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[1][s], bq[c & 1][1], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][1], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[1][s], bq[c & 1][0], acc[rb]);
+        acc[rb] = MFMA_BF16(wsp[0][s], bq[c & 1][0], acc[rb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 2 < NCH) bload(c + 2);
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const long grow = row0 + rb * 32 + l31;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const f32x4 v = {acc[rb][4 * b], acc[rb][4 * b + 1], acc[rb][4 * b + 2], acc[rb][4 * b + 3]};
+        if (FULL || grow < R) {
+          ssum[b] += v;
+          ssq[b] += v * v;
+          if (LAB != 2) st4(zout + (size_t)grow * Cout + cb + 8 * b + 4 * kk, v);
+        }
+      }
+    }
+    __syncthreads();   // every wave is done with the images before the next tile is staged over them
+  };
+  const long nfull = R / TM;
+  bool pending = false;
+  if ((long)blockIdx.x < nfull) fetch(blockIdx.x);
+  for (long t = blockIdx.x; t < nfull; t += gridDim.x) {
+    tile(t, std::true_type{}, pending);
+    pending = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("" ::"v"(pre[i]));
+  if (nfull < ntiles && (long)blockIdx.x == nfull % gridDim.x) {  // ragged last tile
+    fetch(nfull);
+    tile(nfull, std::false_type{}, false);
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float a = ssum[b][u], q = ssq[b][u];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) a += __shfl_xor(a, o), q += __shfl_xor(q, o);
+      if (l31 == 0) {
+        const int c = cb + 8 * b + 4 * kk + u;
+        part[((size_t)blockIdx.x * 2 + 0) * Cout + c] = (double)a;
+        part[((size_t)blockIdx.x * 2 + 1) * Cout + c] = (double)q;
+        for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x)  // partial rows without a workgroup
+          part[((size_t)pr * 2 + 0) * Cout + c] = 0.0, part[((size_t)pr * 2 + 1) * Cout + c] = 0.0;
+      }
+    }
+}
 
 #include "sa_bf3.inc"
+#include "sa_stream.inc"
 #include "sa_bf3_dgrad.inc"
 
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
@@ -523,6 +913,7 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
                                                        const float *__restrict__ st_p, long R, float *__restrict__ dyp,
                                                        double *__restrict__ part, const L1Args L = L1Args{}) {
+  constexpr int LAB = 0;  // (the MFMA loop below is shared text with sa_mid_fwd_kernel, which has timing variants)
   constexpr int LD = CK + 4, KS = CK / 4, C4 = CK / 4, NV = TM * C4 / 256, RSTEP = 256 / C4;
   constexpr int COB = 64 * NT, LDO = COB + 4, O4 = COB / 4, NO = TM * O4 / 256, OSTEP = 256 / O4;
   constexpr bool DENSE_PF = PREFETCH && !POOLED;
@@ -624,7 +1015,7 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     for (int mt = 0; mt < TM / 16; ++mt)
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[mt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
+    if (LAB != 1) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -983,13 +1374,6 @@ bool rows_layout(int B, int Np, long E, RowsLayout &L) {
 // and the kernel takes 1.3 - 2.1x as long (tools/lab/fps_interference.py; the side-stream work cost the main stream 0.86 ms
 // per step, tools/lab/step_without_side_stream.py).  A grid of (CUs - 8) workgroups costs one more tile round in nine
 // when nothing runs beside it.
-// The library's one environment switch: SPACAP_SA_F32MFMA=1 keeps every shared-MLP product (forward layers, data gradient,
-// plain row products, pooling candidates from the epilogue) on the fp32-MFMA kernels instead of the split-bf16 streaming ones
-// -- the reference implementation the split kernels are gated against (tests/test_sa_gemm_kernels_gpu.py).
-inline bool f32_mfma_only() {
-  static const bool on = getenv("SPACAP_SA_F32MFMA") != nullptr && atoi(getenv("SPACAP_SA_F32MFMA")) != 0;
-  return on;
-}
 static std::atomic<int> g_reserved_cus{0};
 inline int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
 template <typename K>
@@ -1110,9 +1494,58 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   SPACAP_REQUIRE(zin && st_in && W && zout && part && R >= 1, "%s: bad arguments", what);
   hipStream_t s = spacap::as_stream(stream);
   const int nt = (Cin == 64 && Cout == 64) ? 1 : 2;
-  // default: the streaming split-bf16 kernel (fp32-equivalent products); SPACAP_SA_F32MFMA=1 (the
-  // library's one switch) keeps every shared-MLP product on the fp32-MFMA kernels
-  if (!f32_mfma_only() && (Cin == 64 || Cin == 128) && Cout % 128 == 0) {
+  static const int lab = getenv("SPACAP_SA_LAB") ? atoi(getenv("SPACAP_SA_LAB")) : 0;   // timing experiments (tools/lab)
+  static const bool m16 = getenv("SPACAP_SA_MFMA32") == nullptr;   // default: 16x16x4 form; SPACAP_SA_MFMA32=1: the 32x32x2 variant
+  static const bool tm32 = getenv("SPACAP_SA_TM32") != nullptr;    // 32-row tiles (lab: more resident workgroups)
+  const size_t lds = (size_t)TM * ((Cin + (m16 ? 8 : 4)) + (64 * nt + 4)) * sizeof(float);
+  const long tiles = (R + TM - 1) / TM;
+#define MFL(CI, NTV, GY, LABV)                                                                                       \
+  {                                                                                                                  \
+    if (m16 && tm32) {                                                                                               \
+      const size_t lds32 = (size_t)32 * ((CI + 8) + (64 * NTV + 4)) * sizeof(float);                                 \
+      const long tiles32 = (R + 31) / 32;                                                                            \
+      static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>, lds32);                    \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV, 32>), dim3(grid_rows(res, GY, tiles32), GY),       \
+                         dim3(256), lds32, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                       \
+    } else if (m16) {                                                                                                \
+      static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false, LABV>, lds);                          \
+      hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY), dim3(256),  \
+                         lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                                    \
+    } else {                                                                                                         \
+      static const int res = resident_blocks(sa_mid_fwd32_kernel<CI, NTV, false, LABV>, lds);                        \
+      hipLaunchKernelGGL((sa_mid_fwd32_kernel<CI, NTV, false, LABV>), dim3(grid_rows(res, GY, tiles), GY),           \
+                         dim3(256), lds, s, zin, st_in, W, Cout, R, zout, part, TailArgs{});                         \
+    }                                                                                                                \
+  }
+#define MF(CI, NTV, GY)                                                                                              \
+  {                                                                                                                  \
+    if (lab == 1) MFL(CI, NTV, GY, 1) else if (lab == 2) MFL(CI, NTV, GY, 2) else if (lab == 3) MFL(CI, NTV, GY, 3)  \
+    else if (lab == 4) MFL(CI, NTV, GY, 4) else if (lab == 5) MFL(CI, NTV, GY, 5) else MFL(CI, NTV, GY, 0)           \
+  }
+  static const bool streaming = getenv("SPACAP_SA_STREAM") != nullptr;   // the wave-streaming fp32 kernel (sa_stream.inc)
+  if (streaming && ((Cin == 64 && Cout == 64) || ((Cin == 64 || Cin == 128) && Cout % 128 == 0))) {
+    static const int cus = resident_blocks(sa_mid_fwd_s_kernel<128, 4>, 100 * 1024);   // = CUs: one workgroup per CU
+    const int cob = Cout == 64 ? 64 : 128, gy = Cout / cob;
+    const size_t ldss = sa_stream_lds_bytes(Cin, cob);
+    const long wtiles = (R + 31) / 32;
+    long gx = cus / gy;
+    gx = gx > NPART ? NPART : gx;
+    gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
+#define MS(CI, NCQV, LABV)                                                                                            \
+  hipLaunchKernelGGL((sa_mid_fwd_s_kernel<CI, NCQV, LABV>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, \
+                     R, zout, part)
+    if (lab == 1) { if (Cin == 64 && cob == 64) MS(64, 2, 1); else if (Cin == 64) MS(64, 4, 1); else MS(128, 4, 1); }
+    else if (lab == 2) { if (Cin == 64 && cob == 64) MS(64, 2, 2); else if (Cin == 64) MS(64, 4, 2); else MS(128, 4, 2); }
+    else { if (Cin == 64 && cob == 64) MS(64, 2, 0); else if (Cin == 64) MS(64, 4, 0); else MS(128, 4, 0); }
+#undef MS
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
+  }
+  // default: the streaming split-bf16 kernel (fp32-equivalent products); SPACAP_SA_BF16X3=0 selects the
+  // fp32-MFMA kernels, =1 the first split-bf16 kernel (activations staged through LDS)
+  static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
+  static const bool bf3 = bf3v != 0;   // split-bf16 matrix-core path (1: sa_mid_fwd_bf3_kernel, 2: the streaming kernel)
+  if (bf3v == 2 && (Cin == 64 || Cin == 128) && Cout % 128 == 0) {
     static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
     const size_t ldss = bf3s_lds_bytes(Cin);
     const long wtiles = (R + 31) / 32;
@@ -1120,22 +1553,31 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
     long gx = (cus - reserved_cus()) / gy;
     gx = gx > NPART ? NPART : gx;
     gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
-    if (Cin == 64)
-      hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, R, zout,
-                         part, PoolArgs{});
-    else
-      hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, R, zout,
-                         part, PoolArgs{});
+#define MS(CI, KSP, LABV)                                                                                             \
+  hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<CI, KSP, LABV>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout, R, \
+                     zout, part)
+    if (lab == 1) { if (Cin == 64) MS(64, 1, 1); else MS(128, 1, 1); }
+    else if (lab == 2) { if (Cin == 64) MS(64, 1, 2); else MS(128, 1, 2); }
+    else if (lab == 9) { if (Cin == 64) MS(64, 1, 9); else MS(128, 1, 9); }
+    else if (Cin == 64) MS(64, 1, 0);
+    else MS(128, 1, 0);
+#undef MS
     SPACAP_CHECK_LAUNCH(what);
     return SPACAP_OK;
   }
-  const size_t lds = (size_t)TM * ((Cin + 8) + (64 * nt + 4)) * sizeof(float);
-  const long tiles = (R + TM - 1) / TM;
-#define MF(CI, NTV, GY)                                                                                              \
+  if (bf3 && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && lab != 1 && lab != 4 && lab != 5) {
+    const size_t lds3 = (size_t)3 * TM * (Cin + 8) * sizeof(__bf16);
+#define MB(CI, LABV)                                                                                                 \
   {                                                                                                                  \
-    static const int res = resident_blocks(sa_mid_fwd_kernel<CI, NTV, false>, lds);                                  \
-    hipLaunchKernelGGL((sa_mid_fwd_kernel<CI, NTV, false>), dim3(grid_rows(res, GY, tiles), GY), dim3(256), lds, s,  \
-                       zin, st_in, W, Cout, R, zout, part, TailArgs{});                                              \
+    static const int res = resident_blocks(sa_mid_fwd_bf3_kernel<CI, LABV>, lds3);                                   \
+    hipLaunchKernelGGL((sa_mid_fwd_bf3_kernel<CI, LABV>), dim3(grid_rows(res, Cout / 128, tiles), Cout / 128),        \
+                       dim3(256), lds3, s, zin, st_in, W, Cout, R, zout, part);                                      \
+  }
+    if (Cin == 64) { if (lab == 2) MB(64, 2) else if (lab == 3) MB(64, 3) else MB(64, 0) }
+    else { if (lab == 2) MB(128, 2) else if (lab == 3) MB(128, 3) else MB(128, 0) }
+#undef MB
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
   }
   if (Cin == 64 && Cout == 64) MF(64, 1, 1)
   else if (Cin == 64 && Cout % 128 == 0) MF(64, 2, Cout / 128)
@@ -1143,6 +1585,7 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
   else
     SPACAP_REQUIRE(false, "%s: (Cin=%d, Cout=%d) unsupported", what, Cin, Cout);
 #undef MF
+#undef MFL
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -1189,12 +1632,20 @@ __global__ __launch_bounds__(256) void sa_pool_finalize_kernel(const float *__re
   arg[i] = (uint8_t)a;
 }
 
+// lab only: the cycle stamps written by the LAB == 9 build of the streaming kernel ([4 workgroups][8 waves][32 phases][5])
+extern "C" int spacap_lab_bf3s_trace(unsigned long long *out_host, unsigned long long *io_host) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bf3s_dbg), sizeof(bf3s_dbg)) != hipSuccess) return SPACAP_E_LAUNCH;
+  return hipMemcpyFromSymbol(io_host, HIP_SYMBOL(bf3s_dbg_io), sizeof(bf3s_dbg_io)) == hipSuccess ? SPACAP_OK : SPACAP_E_LAUNCH;
+}
+
 /* 1 when spacap_sa_mid_fwd_pool_f32 has a kernel for this layer (the streaming split-bf16 kernel is the active one). */
 /* out[R][Cout] = x[R][Cin] W[Cout][Cin]^T, fp32 in / out / accumulate, on the streaming split-bf16 kernel (every fp32 product as
    six bf16 matrix products): the relation head's dhid1 = dz2 W2 (models/transformer_captioner.py:319-326 backward), 524 288
    rows.  _supported: 1 for Cin in {64, 128}, Cout a multiple of 128 (and the split kernels not switched off). */
 extern "C" int spacap_gemm_rows_supported(int Cin, int Cout) {
-  return !f32_mfma_only() && (Cin == 64 || Cin == 128) && Cout % 128 == 0;
+  static const bool on = (getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2) == 2 && getenv("SPACAP_SA_LAB") == nullptr &&
+                         getenv("SPACAP_NO_GEMM_ROWS") == nullptr;
+  return on && (Cin == 64 || Cin == 128) && Cout % 128 == 0;
 }
 extern "C" int spacap_gemm_rows_f32(const float *x, const float *W, long R, int Cin, int Cout, float *out,
                                     spacap_stream_t stream) {
@@ -1209,10 +1660,10 @@ extern "C" int spacap_gemm_rows_f32(const float *x, const float *W, long R, int 
   gx = gx > NPART ? NPART : gx;
   gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
   if (Cin == 64)
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 0, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
                        (const float *)nullptr, W, Cout, R, out, (double *)nullptr, PoolArgs{});
   else
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, 0, false, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, x,
                        (const float *)nullptr, W, Cout, R, out, (double *)nullptr, PoolArgs{});
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -1227,7 +1678,10 @@ extern "C" int spacap_sa_reserve_cus(int n) {
 }
 
 extern "C" int spacap_sa_mid_fwd_pool_supported(int Cin, int Cout, int S) {
-  return !f32_mfma_only() && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && (S == 16 || S == 32 || S == 64);
+  static const int bf3v = getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2;
+  static const bool off = getenv("SPACAP_SA_LAB") != nullptr || getenv("SPACAP_SA_STREAM") != nullptr ||
+                          getenv("SPACAP_SA_NO_POOL_FUSION") != nullptr;
+  return bf3v == 2 && !off && (Cin == 64 || Cin == 128) && Cout % 128 == 0 && (S == 16 || S == 32 || S == 64);
 }
 
 /* spacap_sa_mid_fwd_f32 for the LAST layer of a shared MLP whose output is max-pooled over groups of S consecutive rows:
@@ -1250,10 +1704,10 @@ extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, 
   gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
   const PoolArgs pa{gamma_out, S, cand_v, cand_i};
   if (Cin == 64)
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<64, 1, 0, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
                        R, zout, part, pa);
   else
-    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
+    hipLaunchKernelGGL((sa_mid_fwd_bf3s_kernel<128, 1, 0, true>), dim3((unsigned)gx, gy), dim3(512), ldss, s, zin, st_in, W, Cout,
                        R, zout, part, pa);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -1301,8 +1755,10 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
   SPACAP_REQUIRE(dy && zk && coef && Wk && zp && st_p && dyp && part && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(!arg || (S >= 1 && R % S == 0), "%s: bad S", what);
   hipStream_t s = spacap::as_stream(stream);
-  // default: the streaming split-bf16 kernel (sa_bf3_dgrad.inc); SPACAP_SA_F32MFMA=1: the fp32-MFMA kernels
-  if (!f32_mfma_only() && (CK == 128 || CK == 256) && CP % 64 == 0 && R >= 49152) {   // (below: too few tiles per wave to pay for the weight staging)
+  // default: the streaming split-bf16 kernel (sa_bf3_dgrad.inc); SPACAP_SA_BF16X3=0 / SPACAP_SA_DGRAD_F32=1: the fp32-MFMA kernels
+  static const bool split = (getenv("SPACAP_SA_BF16X3") ? atoi(getenv("SPACAP_SA_BF16X3")) : 2) == 2 &&
+                            getenv("SPACAP_SA_DGRAD_F32") == nullptr && getenv("SPACAP_SA_LAB") == nullptr;
+  if (split && (CK == 128 || CK == 256) && CP % 64 == 0 && R >= 49152) {   // (below: too few tiles per wave to pay for the weight staging)
     static const int cus = resident_blocks(sa_mid_fwd_bf3s_kernel<128, 1>, 100 * 1024);   // = CUs: one workgroup per CU
     const size_t ldsd = bf3s_dgrad_lds_bytes(CK);
     const long wtiles = (R + 31) / 32;
@@ -1971,12 +2427,20 @@ extern "C" int spacap_rel_tail_fwd_f32(const float *hid1, const float *W2, const
                                        long R, float *hid2, float *pred, spacap_stream_t stream) {
   const char *what = "spacap_rel_tail_fwd_f32";
   SPACAP_REQUIRE(hid1 && W2 && b2 && W3 && b3 && hid2 && pred && R >= 1, "%s: bad arguments", what);
-  const size_t lds = (size_t)TM * ((128 + 8) + (128 + 4)) * sizeof(float);
+  static const bool m16 = getenv("SPACAP_SA_MFMA32") == nullptr;   // default: 16x16x4 form; SPACAP_SA_MFMA32=1: the 32x32x2 variant
+  const size_t lds = (size_t)TM * ((128 + (m16 ? 8 : 4)) + (128 + 4)) * sizeof(float);
   const long tiles = (R + TM - 1) / TM;
-  static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
-  hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(fwd_resident(res), 1, tiles), 1), dim3(256), lds,
-                     spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
-                     TailArgs{b2, W3, b3, pred, RT_NO});
+  if (m16) {
+    static const int res = resident_blocks(sa_mid_fwd_kernel<128, 2, true>, lds);
+    hipLaunchKernelGGL((sa_mid_fwd_kernel<128, 2, true>), dim3(grid_rows(fwd_resident(res), 1, tiles), 1), dim3(256), lds,
+                       spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
+                       TailArgs{b2, W3, b3, pred, RT_NO});
+  } else {
+    static const int res = resident_blocks(sa_mid_fwd32_kernel<128, 2, true>, lds);
+    hipLaunchKernelGGL((sa_mid_fwd32_kernel<128, 2, true>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds,
+                       spacap::as_stream(stream), hid1, (const float *)nullptr, W2, 128, R, hid2, (double *)nullptr,
+                       TailArgs{b2, W3, b3, pred, RT_NO});
+  }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
