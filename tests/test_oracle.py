@@ -27,6 +27,23 @@ def test_fps_c_matches_literal_simulation(oracle_ext, n, m, kind):
     assert np.array_equal(got, L.fps_literal(pts, m))
 
 
+@pytest.mark.parametrize("n,m,grid", [(4096, 48, 6), (5000, 40, 5), (8192, 24, 8)])
+def test_fps_c_matches_literal_simulation_at_the_models_block_size(oracle_ext, n, m, grid):
+    """The regime the model runs in: block size 512 (every call of the model has n >= 512), several
+    strided points per simulated thread, lattice coordinates so that most rounds end in exact ties that only the tree
+    order (smallest bitrev9(k mod 512), then smallest k) resolves, plus exact duplicates and points inside the skip radius."""
+    rng = np.random.default_rng(n + m)
+    pts = rng.integers(0, grid, size=(n, 3)).astype(np.float32) * np.float32(0.25)
+    pts[rng.integers(0, n, size=40)] = pts[rng.integers(0, n, size=40)]        # duplicates
+    pts[rng.integers(1, n, size=9)] = np.float32(0.01)                          # |p|^2 <= 1e-3: never selected
+    assert oracle_ext.opt_n_threads(n) == 512 == L.opt_n_threads(n)
+    got = oracle_ext.furthest_point_sampling(torch.from_numpy(pts)[None], m)[0].numpy()
+    want = L.fps_literal(pts, m)
+    assert np.array_equal(got, want)
+    # the case is only meaningful if ties actually occurred: the running minimum takes few distinct values on a lattice
+    assert len(set(np.round(((pts[want[1:]] - pts[want[:-1]]) ** 2).sum(1), 6))) < m - 1
+
+
 def test_fps_semantics_by_hand(oracle_ext):
     # 4 collinear points: start at 0, then the farthest (3), then the one maximising the min distance
     pts = torch.tensor([[[1.0, 0, 0], [2.0, 0, 0], [4.0, 0, 0], [8.0, 0, 0]]])
