@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+from .layout import ChannelMajorOf, point_major_of
 
 
 SA_NPOINTS = (2048, 1024, 512, 256)  # backbone_module.py:29,38,47,56
@@ -215,8 +216,7 @@ class VotingModule(nn.Module):
         if self.training and pm.is_cuda:
             # (B, C, num_vote) as a transposed VIEW carrying the point-major tensor (the fused SA op of the proposal
             # module reads that one): no transposed copy here nor of its gradient
-            vote_features = pm.transpose(2, 1)
-            vote_features._point_major = pm
+            vote_features = ChannelMajorOf.wrap(pm)
         else:
             vote_features = pm.transpose(2, 1).contiguous()
         return vote_xyz, vote_features
@@ -263,7 +263,7 @@ class ProposalModule(nn.Module):
         # continuous part of the step.
         xyz, features, fps_inds = self.vote_aggregation(xyz, features, data_dict.get("proposal_inds"))
         data_dict["aggregated_vote_xyz"] = xyz
-        pm = getattr(features, "_point_major", None)   # the fused SA op's own (B,K,128) result
+        pm = point_major_of(features)   # the fused SA op's own (B,K,128) result
         data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
         net = features.contiguous() if self.training else features

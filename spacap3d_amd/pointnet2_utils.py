@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from .layout import ChannelMajorOf, point_major_of
 from .backend import ops
 
 
@@ -104,7 +105,7 @@ def three_interpolate_train(features, idx, weight):
     """Training-path interpolation: point-major gradient gather when the backend has it (same values)."""
     if getattr(ops(), "three_interpolate_grad_pm", None) is None or not features.is_cuda:
         return three_interpolate(features.contiguous(), idx, weight)
-    pm = getattr(features, "_point_major", None)
+    pm = point_major_of(features)
     if pm is not None:
         return ThreeInterpolatePM.apply(pm, idx, weight, True)
     return ThreeInterpolatePM.apply(features, idx, weight, False)

@@ -9,6 +9,7 @@ the per-operator path (``QueryAndGroup`` + ``SharedMLP``), which is also HIP.
 import torch
 from torch.autograd import Function
 
+from .layout import ChannelMajorOf, point_major_of
 from ._native import check, lib, sum_slabs
 
 
@@ -247,7 +248,7 @@ def rows_index(idx, Np):
 
 
 def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True, rows_idx=None):
-    """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N) [a view of the point-major (B,N,C3) result, also attached as ``._point_major``].  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
+    """xyz (B,Np,3), new_xyz (B,N,3), features (B,Cf,Np) or None, idx (B,N,S) -> (B,C3,N) [a ``layout.ChannelMajorOf``: the transposed view of the point-major (B,N,C3) result].  ``mlp_module``: the SharedMLP whose parameters / BatchNorm statistics are used and
     updated.  Returns None when this MLP has no fused kernels (the caller then uses the per-operator path)."""
     if not use_xyz or not xyz.is_cuda or not supported(mlp_module, idx.shape[2]):
         return None
@@ -261,7 +262,7 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True, ro
             feat = features.reshape(features.shape[0], -1)                   # inline: no (B,Np,C1) product needed
         else:
             # the first layer commutes with the gather: multiply once per source point (inside the op)
-            pm = getattr(features, "_point_major", None)   # (B,Np,Cf) form of a previous module's output, if any
+            pm = point_major_of(features)   # (B,Np,Cf) form of a previous module's output, if any
             pm = pm if pm is not None else features.transpose(1, 2)
     else:
         assert Cf == 0
@@ -269,11 +270,9 @@ def sa_mlp_train(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True, ro
     out = _SAMLP.apply(xyz, new_xyz, idx, feat, pm, W1, l2.conv.weight.view(l2.conv.out_channels, -1),
                        l3.conv.weight.view(l3.conv.out_channels, -1), bns[0].weight, bns[0].bias, bns[1].weight,
                        bns[1].bias, bns[2].weight, bns[2].bias, bns, rdiv, rows_idx)
-    # (B,C3,N) as a transposed VIEW of the point-major result: the next SA module and the proposal head read the
-    # point-major tensor itself (``_point_major``), so no transposed copy is made unless a consumer asks for one
-    res = out.transpose(1, 2)
-    res._point_major = out
-    return res
+    # (B,C3,N) as a transposed VIEW of the point-major result, typed (layout.ChannelMajorOf): the next SA module and the
+    # proposal head ask for the point-major tensor itself, so no transposed copy is made unless a consumer needs one
+    return ChannelMajorOf.wrap(out)
 
 
 def _running_stats_rows(bn):
@@ -308,7 +307,7 @@ def sa_mlp_eval(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
         if Cf == 1:
             feat, W1a = features.reshape(B, -1).contiguous(), W1.contiguous()
         else:
-            pm = getattr(features, "_point_major", None)
+            pm = point_major_of(features)
             Y = torch.matmul(pm if pm is not None else features.transpose(1, 2), W1[:, 3:].t()).contiguous()
             W1a = W1[:, :3].contiguous()
     else:
@@ -336,6 +335,4 @@ def sa_mlp_eval(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
         arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
         check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(), st),
               "spacap_sa_pool_fwd_f32")
-    res = out.transpose(1, 2)
-    res._point_major = out
-    return res
+    return ChannelMajorOf.wrap(out)

@@ -4,6 +4,7 @@ import torch
 import torch.nn as nn
 
 from .detector import Pointnet2Backbone, ProposalModule, VotingModule
+from .layout import ChannelMajorOf, point_major_of
 from .transformer_captioner import TransformerDecoderModel
 
 
@@ -43,13 +44,12 @@ class SpaCapNet(nn.Module):
         data_dict["seed_xyz"] = xyz
         data_dict["seed_features"] = features
         xyz, features = self.vgen(xyz, features)
-        pm = getattr(features, "_point_major", None)
+        pm = point_major_of(features)
         if pm is not None:   # same L2 normalisation over the channels, on the point-major tensor
             from .backend import ops
             f = getattr(ops(), "l2norm_rows", None) if (pm.is_cuda and pm.shape[-1] % 4 == 0) else None
             pm = f(pm) if f is not None else pm.div(torch.norm(pm, p=2, dim=2).unsqueeze(2))
-            features = pm.transpose(1, 2)
-            features._point_major = pm
+            features = ChannelMajorOf.wrap(pm)
         else:
             features = features.div(torch.norm(features, p=2, dim=1).unsqueeze(1))  # SpaCapNet.py:66-67 (no eps)
         data_dict["vote_xyz"] = xyz

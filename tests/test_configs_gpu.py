@@ -15,6 +15,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+from spacap3d_amd.layout import point_major_of
 
 from spacap3d_amd import backend, synthetic as S
 
@@ -111,7 +112,7 @@ def _sa1_vs_float64(C, seed):
     sa = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[C, 64, 64, 128], use_xyz=True,
                                normalize_xyz=True).to(DEV).train()
     new_xyz, out, inds = sa(xyz, feats)
-    assert getattr(out, "_point_major", None) is not None, "the fused shared-MLP path did not run"
+    assert point_major_of(out) is not None, "the fused shared-MLP path did not run"
     node = _fused_node(out)
     saved = node.saved_tensors
     zs, sts, arg = saved[7:10], saved[10:13], saved[14]

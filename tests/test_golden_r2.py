@@ -16,6 +16,7 @@ import sys
 import numpy as np
 import pytest
 import torch
+from spacap3d_amd.layout import point_major_of
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
@@ -98,7 +99,7 @@ def test_sa_module_at_fused_shapes_matches_reference(kind, name):
         if kind == "hip":
             from spacap3d_amd import sa_mlp
             assert sa_mlp.supported(sa.mlp_module, ns), "this shape must have fused kernels"
-            assert getattr(new_feats, "_point_major", None) is not None, "the fused shared-MLP path did not run"
+            assert point_major_of(new_feats) is not None, "the fused shared-MLP path did not run"
         (new_feats * wout).sum().backward()
     (o_linf, o_l2), (g_linf, g_l2), (f_linf, f_l2) = SA_TOL[device]
     assert np.array_equal(_np(inds), fx[name + "_inds"])

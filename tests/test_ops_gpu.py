@@ -130,10 +130,9 @@ def test_three_interpolate_point_major_gradient_is_the_same_gather(hip_ext, orac
     for layout in ("channel", "point"):
         f = feats.to(DEV).requires_grad_(True)
         if layout == "point":
+            from spacap3d_amd.layout import ChannelMajorOf
             pm = f.transpose(1, 2).contiguous()
-            view = pm.transpose(1, 2)
-            view._point_major = pm
-            out = pu.three_interpolate_train(view, idx.to(DEV), w.to(DEV))
+            out = pu.three_interpolate_train(ChannelMajorOf.wrap(pm), idx.to(DEV), w.to(DEV))
         else:
             out = pu.three_interpolate_train(f, idx.to(DEV), w.to(DEV))
         assert torch.equal(out.detach().cpu(), oracle_ext.three_interpolate(feats, idx, w))

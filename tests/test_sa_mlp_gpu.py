@@ -8,6 +8,7 @@ import copy
 import numpy as np
 import pytest
 import torch
+from spacap3d_amd.layout import point_major_of
 import torch.nn.functional as F
 
 from spacap3d_amd import backend
@@ -73,7 +74,7 @@ def test_fused_sa_mlp_matches_float64_reference(name, Np, N, Sn, Cf, mlp, radius
     feats_in = feats.clone().requires_grad_(Cf > 1)
     rm0 = [l.bn.bn.running_mean.clone() for l in sa.mlp_module.children()]
     new_xyz, out, inds = sa(xyz_in, feats_in)
-    assert out.shape == (B, mlp[-1], N) and out._point_major.is_contiguous()
+    assert out.shape == (B, mlp[-1], N) and point_major_of(out).is_contiguous()
     dout = torch.randn_like(out)
     (out * dout).sum().backward()
     idx = PU.ball_query(radius, Sn, xyz, new_xyz.detach())
@@ -194,7 +195,7 @@ def test_eval_mode_fused_path_folds_the_running_statistics(mlp, Cf, Sn):
     hip = backend.ops()
     with torch.no_grad():
         _, fused, inds = sa(xyz, feats)
-        assert getattr(fused, "_point_major", None) is not None, "the fused inference path did not run"
+        assert point_major_of(fused) is not None, "the fused inference path did not run"
         saved = hip.sa_mlp_eval
         hip.sa_mlp_eval = None
         try:
@@ -202,6 +203,6 @@ def test_eval_mode_fused_path_folds_the_running_statistics(mlp, Cf, Sn):
         finally:
             hip.sa_mlp_eval = saved
     assert torch.equal(inds, inds2)
-    assert getattr(plain, "_point_major", None) is None
+    assert point_major_of(plain) is None
     err = float((fused - plain).abs().max() / plain.abs().max())
     assert err < 2e-5, err
