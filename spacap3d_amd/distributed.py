@@ -103,15 +103,25 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self, sources=None, force_pack=False):
-        """The step's single collective.  No-op in a single process (unless ``force_pack``, used by tests to
-        exercise the multi-rank code path on one GPU)."""
+    def all_reduce(self, sources=None, force_pack=False, average=True):
+        """The step's single collective: SUM of the flat bucket over the ranks.  Returns the factor that turns the result into
+        the mean (1 / world): with ``average=True`` it has already been applied to the bucket (one more pass over it) and 1.0
+        is returned; with ``average=False`` the caller folds it into its own pass (FlatAdam's ``grad_scale``).  No-op in a
+        single process (unless ``force_pack``, used by tests to exercise the multi-rank code path on one GPU)."""
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi or force_pack:
             self.pack(sources)
-        if multi:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(dist.get_world_size())
+        if not multi:
+            return 1.0
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        world = dist.get_world_size()
+        if average:
+            self.flat.div_(world)
+            return 1.0
+        return 1.0 / world
+
+    def all_reduce_mean(self, sources=None, force_pack=False):
+        self.all_reduce(sources=sources, force_pack=force_pack, average=True)
 
 
 def used_parameters(module: torch.nn.Module, loss: torch.Tensor):

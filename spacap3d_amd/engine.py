@@ -37,6 +37,7 @@ class Trainer:
         self.last_losses = {}
         self._bn_counters = None
         self._grad_slots = {}
+        self.grad_scale = 1.0
         self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
@@ -278,10 +279,15 @@ class Trainer:
         return d["loss"].detach()
 
     def _optimizer_step(self, sources):
-        """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket."""
+        """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket and takes the
+        1 / world of the mean as its gradient scale: no separate division pass over the 36 MB bucket."""
         flat = not isinstance(self.optimizer, torch.optim.Optimizer)
-        self.bucket.all_reduce_mean(sources=sources, force_pack=self.split_optimizer or flat)
-        self.optimizer.step()
+        scale = self.bucket.all_reduce(sources=sources, force_pack=self.split_optimizer or flat, average=not flat)
+        self.grad_scale = scale            # bucket.flat * grad_scale = the mean gradient the optimizer applied
+        if flat:
+            self.optimizer.step(grad_scale=scale)
+        else:
+            self.optimizer.step()
 
     # -- hipGraph mode ------------------------------------------------------------------------------------------
     # One training step is ~800 kernel launches (1 900 before the fused operators), most of them microseconds long; eager

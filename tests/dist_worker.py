@@ -57,7 +57,7 @@ def main():
                 dist.all_gather(gathered, local)
                 tr._optimizer_step(None)                     # pack (no-op now) + all-reduce mean + Adam
                 want = torch.stack(gathered).sum(0) / world
-                got = tr.bucket.flat
+                got = tr.bucket.flat * tr.grad_scale      # (FlatAdam folds 1 / world into its own pass: the bucket holds the sum)
                 assert torch.allclose(got, want, rtol=1e-6, atol=1e-9), float((got - want).abs().max())
                 red = [torch.empty_like(got) for _ in range(world)]
                 dist.all_gather(red, got.clone())
