@@ -288,6 +288,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=8, help="torch threads of the multi-core CPU baseline (8 is the fastest on the box's host)")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-baseline steps (after one warm-up at size)")
     ap.add_argument("--no-drop-in", action="store_true", help="skip the extra unpipelined (drop-in caller) measurement")
+    ap.add_argument("--no-in-step", action="store_true", help="skip the eager steps that time the roofline kernel inside a step "
+                                                              "(for rocprofv3 runs: tools/prof_window.py takes the LAST steps of the trace)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short cfg3 / cfg4 / cfg5 sub-records and the eval record")
     args = ap.parse_args()
 
@@ -354,7 +356,7 @@ def main():
 
     # -- the roofline kernel's duration INSIDE a step (beside the side-stream sampling chain, with the step's grid) ----------
     in_step = None
-    if world == 1 and nxt is not None and not args.ablate and (per_gpu, cfg["n_points"]) == (8, 40000):
+    if world == 1 and nxt is not None and not args.ablate and not args.no_in_step and (per_gpu, cfg["n_points"]) == (8, 40000):
         import spacap3d_amd.sa_mlp as sam
         R2_ = per_gpu * 1024 * 32
         keep_graph, trainer.graph = trainer.graph, None     # a few EAGER steps: same kernels, events can bracket them

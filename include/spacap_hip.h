@@ -514,6 +514,15 @@ int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *target, const ui
 int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target, const uint8_t *good, const float *out, const float *gloss,
                             int B, int W, int V, int tstride, float *dlogits, spacap_stream_t stream);
 
+/* ---- tail of get_scene_cap_loss (lib/loss_helper.py:340-383): det f32 [8] = (vote, objectness, center, heading_cls, heading_reg,
+ * size_cls, size_reg, sem_cls), cap f32 [4] (cap[0] = caption loss), rel f32 [7] or NULL (rel[0..2] = x, y, z loss);
+ * obj_label i64 [n], obj_mask f32 [n], bbox_mask i64 [n] -> out f32 [8] = (box_loss, det_loss, relation_loss, loss, pos_ratio,
+ * neg_ratio, obj_acc, 0) and loss f32 [1] (= out[3], the differentiable output).  Backward: g_loss f32 [1] -> g_det [8],
+ * g_cap [4], g_rel [7] (NULL when rel was). */
+int spacap_loss_tail_fwd_f32(const float *det, const float *cap, const float *rel, const int64_t *obj_label, const float *obj_mask,
+                             const int64_t *bbox_mask, int n, float *out, float *loss, spacap_stream_t stream);
+int spacap_loss_tail_bwd_f32(const float *g_loss, float *g_det, float *g_cap, float *g_rel, spacap_stream_t stream);
+
 /* ---- fused Transformer sub-layers, d_model = 128 (replaces everything BETWEEN two attention() calls of
  * models/transformer_captioner.py: SublayerConnection :115-127, LayerNorm :102-113, PositionwiseFeedForward :72-81, the
  * output projection and the packed q|k|v projection of MultiHeadedAttention :52-70).  One argument block, read before the

@@ -35,6 +35,7 @@ class HipBackend:
         self.detection_losses = _fl.detection_losses
         self.relation_losses = _fl.relation_losses
         self.caption_head_loss = _fl.caption_head_loss
+        self.loss_tail = _fl.loss_tail
         self.l2norm_rows = _fl.l2norm_rows
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout

@@ -499,7 +499,8 @@ __global__ __launch_bounds__(CAP_T) void cap_rows_kernel(const float *__restrict
   for (int v = tid; v < V; v += CAP_T) logp[(size_t)r * V + v] = x[v] - lse;
   if (tid == 0) {
     const int b = r / W, wd = r % W;
-    const int64_t t = target[(size_t)b * tstride + wd];
+    int64_t t = target[(size_t)b * tstride + wd];
+    if ((uint64_t)t >= (uint64_t)V) t = 0;                         // out-of-range id: ignored like the pad id (never read out of bounds)
     const float gd = good[b] ? 1.f : 0.f;
     const float lt = (t != 0) ? -(x[t] - lse) : 0.f;              // ignore_index = 0
     rowstat[r * 4 + 0] = lt * gd;
@@ -509,9 +510,11 @@ __global__ __launch_bounds__(CAP_T) void cap_rows_kernel(const float *__restrict
   }
 }
 __global__ __launch_bounds__(64) void cap_final_kernel(const float *__restrict__ rowstat, int rows, float *__restrict__ out) {
-  if (threadIdx.x != 0) return;
+  // one wavefront: lane l adds rows l, l + 64, ... in order, then a fixed shuffle tree (bitwise reproducible)
   float a = 0.f, g = 0.f, h = 0.f, v = 0.f;
-  for (int r = 0; r < rows; ++r) a += rowstat[r * 4], g += rowstat[r * 4 + 1], h += rowstat[r * 4 + 2], v += rowstat[r * 4 + 3];
+  for (int r = threadIdx.x; r < rows; r += 64) a += rowstat[r * 4], g += rowstat[r * 4 + 1], h += rowstat[r * 4 + 2], v += rowstat[r * 4 + 3];
+  a = spacap::wave_sum_f32(a), g = spacap::wave_sum_f32(g), h = spacap::wave_sum_f32(h), v = spacap::wave_sum_f32(v);
+  if (threadIdx.x != 0) return;
   const float inv = 1.0f / (g + 1e-6f);
   out[0] = a * inv;
   out[1] = h / fmaxf(v, 1.0f);
@@ -524,7 +527,8 @@ __global__ __launch_bounds__(CAP_T) void cap_bwd_kernel(const float *__restrict_
                                                        float *__restrict__ dlogits) {
   const int r = blockIdx.x, tid = threadIdx.x;
   const int b = r / W, wd = r % W;
-  const int64_t t = target[(size_t)b * tstride + wd];
+  int64_t t = target[(size_t)b * tstride + wd];
+  if ((uint64_t)t >= (uint64_t)V) t = 0;
   const float w = (good[b] && t != 0) ? gloss[0] * out[2] : 0.f;
   for (int v = tid; v < V; v += CAP_T) {
     const float p = expf(logp[(size_t)r * V + v]);
@@ -537,7 +541,10 @@ extern "C" int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *targe
                                        int tstride, float *logp, float *rowstat, float *out, spacap_stream_t stream) {
   const char *what = "spacap_cap_loss_fwd_f32";
   SPACAP_REQUIRE(B >= 0 && W >= 1 && V >= 2 && tstride >= W, "%s: bad sizes", what);
-  if (B == 0) return SPACAP_OK;
+  if (B == 0) {   // no rows: loss 0, accuracy 0, 1 / (0 + 1e-6), 0 good boxes
+    if (out) SPACAP_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(float), spacap::as_stream(stream)), what);
+    return SPACAP_OK;
+  }
   SPACAP_REQUIRE(logits && target && good && logp && rowstat && out, "%s: null pointer", what);
   hipStream_t s = spacap::as_stream(stream);
   hipLaunchKernelGGL(cap_rows_kernel, dim3(B * W), dim3(CAP_T), 0, s, logits, target, good, W, V, tstride, logp, rowstat);
@@ -554,6 +561,71 @@ extern "C" int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target,
   SPACAP_REQUIRE(logp && target && good && out && gloss && dlogits, "%s: null pointer", what);
   hipLaunchKernelGGL(cap_bwd_kernel, dim3(B * W), dim3(CAP_T), 0, spacap::as_stream(stream), logp, target, good, out, gloss, W, V,
                      tstride, dlogits);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// ---- the tail of get_scene_cap_loss (lib/loss_helper.py:340-383): every derived scalar of a training step in ONE launch ----
+//   det  f32 [8]  = (vote, objectness, center, heading_cls, heading_reg, size_cls, size_reg, sem_cls) loss
+//   cap  f32 [4]  = (cap_loss, cap_acc, ., .)          rel f32 [7] = (x, y, z loss, x, y, z acc, .) or NULL (no relation head)
+//   out  f32 [8]  = (box_loss, det_loss, relation_loss, loss, pos_ratio, neg_ratio, obj_acc, 0)
+//       box = center + 0.1 heading_cls + heading_reg + 0.1 size_cls + size_reg;  det = vote + 0.5 objectness + box + 0.1 sem_cls;
+//       relation = x + y + z;  loss = 10 det + cap + 0.1 relation   (:373-383);  the three ratios as :355-362.
+// PyTorch composes these from ~25 scalar kernels forward and as many backward (stack / unbind / gemv / fill / add on 0-d tensors).
+namespace {
+__global__ __launch_bounds__(256) void loss_tail_fwd_kernel(const float *__restrict__ det, const float *__restrict__ cap,
+                                                            const float *__restrict__ rel, const int64_t *__restrict__ obj_label,
+                                                            const float *__restrict__ obj_mask, const int64_t *__restrict__ bbox_mask,
+                                                            int n, float *__restrict__ out, float *__restrict__ loss) {
+  __shared__ float s_red[4];
+  float pos = 0.f, msk = 0.f, hit = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float m = obj_mask[i];
+    pos += (float)obj_label[i];
+    msk += m;
+    hit += (bbox_mask[i] == obj_label[i]) ? m : 0.f;
+  }
+  pos = block_sum(pos, s_red), msk = block_sum(msk, s_red), hit = block_sum(hit, s_red);
+  if (threadIdx.x == 0) {
+    const float box = det[2] + 0.1f * det[3] + det[4] + 0.1f * det[5] + det[6];
+    const float dl = det[0] + 0.5f * det[1] + box + 0.1f * det[7];
+    const float rl = rel ? (rel[0] + rel[1]) + rel[2] : 0.f;
+    out[0] = box, out[1] = dl, out[2] = rl, out[3] = 10.f * dl + cap[0] + 0.1f * rl;
+    out[4] = pos / (float)n, out[5] = msk / (float)n - pos / (float)n, out[6] = hit / (msk + 1e-6f), out[7] = 0.f;
+    *loss = out[3];
+  }
+}
+// gradient of the total loss (g_loss[0]) w.r.t. the 8 + 1 + 3 terms
+__global__ void loss_tail_bwd_kernel(const float *__restrict__ g_loss, float *__restrict__ gdet, float *__restrict__ gcap,
+                                     float *__restrict__ grel) {
+  const int t = threadIdx.x;
+  const float gl = g_loss[0];
+  const float d_det = 10.f * gl, d_box = d_det, d_rel = 0.1f * gl;
+  if (t < 8) {
+    const float wbox[8] = {0.f, 0.f, 1.f, 0.1f, 1.f, 0.1f, 1.f, 0.f}, wdet[8] = {1.f, 0.5f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.1f};
+    gdet[t] = d_box * wbox[t] + d_det * wdet[t];
+  } else if (t < 12) {
+    gcap[t - 8] = t == 8 ? gl : 0.f;
+  } else if (t < 19 && grel) {
+    grel[t - 12] = t < 15 ? d_rel : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int spacap_loss_tail_fwd_f32(const float *det, const float *cap, const float *rel, const int64_t *obj_label,
+                                        const float *obj_mask, const int64_t *bbox_mask, int n, float *out, float *loss,
+                                        spacap_stream_t stream) {
+  const char *what = "spacap_loss_tail_fwd_f32";
+  SPACAP_REQUIRE(det && cap && obj_label && obj_mask && bbox_mask && out && loss && n >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(loss_tail_fwd_kernel, dim3(1), dim3(256), 0, spacap::as_stream(stream), det, cap, rel, obj_label, obj_mask,
+                     bbox_mask, n, out, loss);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+extern "C" int spacap_loss_tail_bwd_f32(const float *g_loss, float *g_det, float *g_cap, float *g_rel, spacap_stream_t stream) {
+  const char *what = "spacap_loss_tail_bwd_f32";
+  SPACAP_REQUIRE(g_loss && g_det && g_cap, "%s: null pointer", what);
+  hipLaunchKernelGGL(loss_tail_bwd_kernel, dim3(1), dim3(64), 0, spacap::as_stream(stream), g_loss, g_det, g_cap, g_rel);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

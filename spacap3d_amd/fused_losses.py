@@ -76,6 +76,7 @@ def detection_losses(d, num_heading_bin, num_size_cluster, mean_size_f32, near_t
         d["heading_class_label"], d["heading_residual_label"], d["size_class_label"], d["size_residual_label"],
         d["sem_cls_label"], mean_size_f32, d["seed_xyz"], d["seed_inds"], d["vote_label"], d["vote_label_mask"],
         num_heading_bin, num_size_cluster, near_thr, far_thr, w[0], w[1])
+    d["_det_vec"] = losses     # (8,): loss_helper's fused tail reads the vector itself
     vote, objn, center, hcls, hreg, scls, sreg, sem = losses.unbind(0)
     # box_loss (= center + 0.1 * hcls + hreg + 0.1 * scls + sreg) is left to the caller: loss_helper folds it into
     # the one matrix-vector product that also forms det_loss and the total
@@ -121,6 +122,7 @@ def relation_losses(d):
     """{x,y,z}_loss and {x,y,z}_acc as ``loss_helper.compute_relation_loss`` returns them."""
     out = RelationLoss.apply(d["relation_pred"], d["object_assignment"], d["box_label_mask_int"], d["objectness_label"],
                              d["x_label"], d["y_label"], d["z_label"])
+    d["_rel_vec"] = out
     return {"x_loss": out[0], "y_loss": out[1], "z_loss": out[2], "x_acc": out[3], "y_acc": out[4], "z_acc": out[5]}
 
 
@@ -169,7 +171,45 @@ class CaptionHeadLoss(Function):
 def caption_head_loss(logits, lang_ids, good):
     """(lang_cap log-probabilities, cap_loss, cap_acc) -- see CaptionHeadLoss."""
     logp, out = CaptionHeadLoss.apply(logits, lang_ids, good)
-    return logp, out[0], out[1]
+    return logp, out[0], out[1], out
+
+
+class LossTail(Function):
+    """(det (8,), cap (4,), rel (7,) or None, objectness_label, objectness_mask, bbox_mask) -> (loss (), out (8,)) with out =
+    (box_loss, det_loss, relation_loss, loss, pos_ratio, neg_ratio, obj_acc, 0): the tail of get_scene_cap_loss
+    (lib/loss_helper.py:340-383) as one launch each way.  Only ``loss`` is differentiable (``out`` is for the log entries);
+    the three component ops receive dense gradient vectors."""
+
+    @staticmethod
+    def forward(ctx, det, cap, rel, obj_label, obj_mask, bbox_mask):
+        dev = det.device
+        with torch.cuda.device(dev):
+            out = torch.empty(8, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            ol, om, bm = obj_label.contiguous().view(-1), obj_mask.contiguous().view(-1), bbox_mask.contiguous().view(-1)
+            check(lib.spacap_loss_tail_fwd_f32(det.contiguous().data_ptr(), cap.contiguous().data_ptr(),
+                                               rel.contiguous().data_ptr() if rel is not None else None, ol.data_ptr(),
+                                               om.data_ptr(), bm.data_ptr(), ol.numel(), out.data_ptr(), loss.data_ptr(),
+                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_loss_tail_fwd_f32")
+        ctx.has_rel = rel is not None
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        dev = g_loss.device
+        with torch.cuda.device(dev):
+            gdet = torch.empty(8, dtype=torch.float32, device=dev)
+            gcap = torch.empty(4, dtype=torch.float32, device=dev)
+            grel = torch.empty(7, dtype=torch.float32, device=dev) if ctx.has_rel else None
+            check(lib.spacap_loss_tail_bwd_f32(g_loss.contiguous().data_ptr(), gdet.data_ptr(), gcap.data_ptr(),
+                                               grel.data_ptr() if grel is not None else None,
+                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_loss_tail_bwd_f32")
+        return gdet, gcap, grel, None, None, None
+
+
+def loss_tail(det, cap, rel, obj_label, obj_mask, bbox_mask):
+    return LossTail.apply(det, cap, rel, obj_label, obj_mask, bbox_mask)
 
 
 class L2NormRows(Function):

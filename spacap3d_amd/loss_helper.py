@@ -228,11 +228,17 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     d["objectness_label"] = objectness_label
     d["objectness_mask"] = objectness_mask
     d["object_assignment"] = object_assignment
-    d["pos_ratio"] = torch.sum(objectness_label.float()) / float(total)
-    d["neg_ratio"] = torch.sum(objectness_mask) / float(total) - d["pos_ratio"]
-
-    d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
-        torch.sum(objectness_mask) + 1e-6)
+    # every derived scalar (box / det / relation / total loss and the three ratios below) in ONE launch each way when the three
+    # fused component ops left their result vectors (fused_losses.LossTail); else the composition that follows
+    tail = None
+    if fast and "_det_vec" in d and "_cap_vec" in d:
+        from .backend import ops as _ops
+        tail = getattr(_ops(), "loss_tail", None)
+    if tail is None:
+        d["pos_ratio"] = torch.sum(objectness_label.float()) / float(total)
+        d["neg_ratio"] = torch.sum(objectness_mask) / float(total) - d["pos_ratio"]
+        d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
+            torch.sum(objectness_mask) + 1e-6)
 
     if use_relation:
         from .backend import ops
@@ -254,6 +260,17 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     if not detection:
         d["det_loss"] = zero
 
+    if tail is not None and "_rel_vec" in d:
+        d["loss"], out = tail(d.pop("_det_vec"), d.pop("_cap_vec"), d.pop("_rel_vec"), objectness_label, objectness_mask,
+                              d["bbox_mask"])
+        d["box_loss"], d["det_loss"], d["relation_loss"] = out[0], out[1], out[2]
+        d["pos_ratio"], d["neg_ratio"], d["obj_acc"] = out[4], out[5], out[6]
+        return d
+    if tail is not None:   # (the relation op did not leave its vector: finish the ratios the composition way)
+        d["pos_ratio"] = torch.sum(objectness_label.float()) / float(total)
+        d["neg_ratio"] = torch.sum(objectness_mask) / float(total) - d["pos_ratio"]
+        d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
+            torch.sum(objectness_mask) + 1e-6)
     if fast:
         # box_loss, det_loss, relation_loss and the total (lib/loss_helper.py:340-383) as ONE 4 x 12 matrix-vector
         # product over the stacked terms instead of ~17 scalar kernels forward and as many backward

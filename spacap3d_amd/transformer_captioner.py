@@ -485,7 +485,7 @@ class TransformerDecoderModel(nn.Module):
         if fused is not None and ep["lang_ids"].shape[1] >= out.shape[1] + 1:
             # vocabulary projection, then log-softmax + the caption loss / accuracy in one op (fused_losses.CaptionHeadLoss);
             # loss_helper.get_scene_cap_loss picks the pair up instead of recomputing it from the log-probabilities
-            ep["lang_cap"], cl, ca = fused(self.model.generator.proj(out), ep["lang_ids"], good)
+            ep["lang_cap"], cl, ca, ep["_cap_vec"] = fused(self.model.generator.proj(out), ep["lang_ids"], good)
             ep["_cap_loss"] = (cl, ca)
         else:
             ep["lang_cap"] = self.model.generator(out)

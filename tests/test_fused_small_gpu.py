@@ -34,7 +34,8 @@ def test_caption_head_loss_matches_the_composition(B, W, V, good_pattern):
     logits[0, 1, 5] = logits[0, 1, 9] = 60.0
     la = logits.clone().requires_grad_(True)
     lb = logits.clone().requires_grad_(True)
-    cap_a, loss_a, acc_a = caption_head_loss(la, ids, good)
+    cap_a, loss_a, acc_a, vec_a = caption_head_loss(la, ids, good)
+    assert vec_a.shape == (4,) and float(vec_a[0]) == float(loss_a)
     cap_b, loss_b, acc_b = _reference_cap(lb, ids, good)
     assert float((cap_a - cap_b).abs().max()) < 2e-5
     assert abs(float(loss_a) - float(loss_b)) <= 1e-5 * max(1.0, abs(float(loss_b)))
@@ -59,3 +60,31 @@ def test_l2norm_rows_matches_div_by_norm(shape):
     (ya * w).sum().backward()
     (yb * w).sum().backward()
     assert float((a.grad - b.grad).abs().max()) <= 2e-6 * float(b.grad.abs().max())
+
+
+def test_loss_tail_matches_the_composition():
+    """fused_losses.LossTail (one launch each way) against lib/loss_helper.py:340-383 composed from scalar ops."""
+    from spacap3d_amd.fused_losses import loss_tail
+    g = torch.Generator().manual_seed(3)
+    det = torch.rand(8, generator=g).to(DEV).requires_grad_()
+    cap = torch.rand(4, generator=g).to(DEV).requires_grad_()
+    rel = torch.rand(7, generator=g).to(DEV).requires_grad_()
+    n = 8 * 256
+    label = (torch.rand(n, generator=g) > 0.7).long().to(DEV)
+    mask = (torch.rand(n, generator=g) > 0.4).float().to(DEV)
+    bbox = (torch.rand(n, generator=g) > 0.5).long().to(DEV)
+    loss, out = loss_tail(det, cap, rel, label.view(8, 256), mask.view(8, 256), bbox.view(8, 256))
+    (loss * 1.3).backward()
+    d6, c6, r6 = (t.detach().double().requires_grad_() for t in (det, cap, rel))
+    box = d6[2] + 0.1 * d6[3] + d6[4] + 0.1 * d6[5] + d6[6]
+    dl = d6[0] + 0.5 * d6[1] + box + 0.1 * d6[7]
+    rl = r6[0] + r6[1] + r6[2]
+    want = 10 * dl + c6[0] + 0.1 * rl
+    (want * 1.3).backward()
+    pos = label.double().sum() / n
+    ref = [box, dl, rl, want, pos, mask.double().sum() / n - pos, ((bbox == label).double() * mask.double()).sum() / (mask.double().sum() + 1e-6)]
+    for i, w in enumerate(ref):
+        assert abs(float(out[i]) - float(w)) < 1e-5 * max(1.0, abs(float(w))), i
+    assert float(loss) == float(out[3]) and not out.requires_grad
+    for a, b in ((det, d6), (cap, c6), (rel, r6)):
+        assert float((a.grad.double() - b.grad).abs().max()) < 1e-6
