@@ -514,6 +514,18 @@ int spacap_cap_loss_fwd_f32(const float *logits, const int64_t *target, const ui
 int spacap_cap_loss_bwd_f32(const float *logp, const int64_t *target, const uint8_t *good, const float *out, const float *gloss,
                             int B, int W, int V, int tstride, float *dlogits, spacap_stream_t stream);
 
+/* ---- score decoding of the proposal head (models/proposal_module.py:106-158 decode_scores, :81-104 decode_pred_box).
+ * net f32 [B, CH, K] (the head's Conv1d output, CH = 5 + 2 NH + 4 NS + NC), agg_xyz f32 [B,K,3], mean_size f32 [NS,3] ->
+ * nt f32 [B,K,CH] (net transposed: the rows every score slice is a view of), center f32 [B,K,3] = agg_xyz + nt[...,2:5],
+ * heading_res f32 [B,K,NH] = nt[...,5+NH:5+2NH] * pi/NH, size_res f32 [B,K,NS,3] = normalised residuals * mean_size,
+ * corners f64 [B,K,8,3] of the arg-max size class box (heading 0; mean_size_f64 f64 [NS,3] or NULL = the fp32 table widened), bbox_mask / sem_cls / size_cls i64 [B,K] (first maxima).
+ * Backward: d_net f32 [B,CH,K] from the gradients of nt / center / heading_res / size_res (each nullable). */
+int spacap_proposal_decode_fwd_f32(const float *net, const float *agg_xyz, const float *mean_size, const double *mean_size_f64,
+                                   int B, int K, int NH, int NS, int NC, float *nt, float *center, float *heading_res, float *size_res, double *corners,
+                                   int64_t *bbox_mask, int64_t *sem_cls, int64_t *size_cls, spacap_stream_t stream);
+int spacap_proposal_decode_bwd_f32(const float *g_nt, const float *g_center, const float *g_heading_res, const float *g_size_res,
+                                   const float *mean_size, int B, int K, int NH, int NS, int NC, float *d_net, spacap_stream_t stream);
+
 /* ---- tail of get_scene_cap_loss (lib/loss_helper.py:340-383): det f32 [8] = (vote, objectness, center, heading_cls, heading_reg,
  * size_cls, size_reg, sem_cls), cap f32 [4] (cap[0] = caption loss), rel f32 [7] or NULL (rel[0..2] = x, y, z loss);
  * obj_label i64 [n], obj_mask f32 [n], bbox_mask i64 [n] -> out f32 [8] = (box_loss, det_loss, relation_loss, loss, pos_ratio,

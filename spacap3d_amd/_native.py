@@ -124,6 +124,8 @@ SIGNATURES = {
     "spacap_layernorm_bwd_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_layernorm_bwd_f32": (_i, [_p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
     "spacap_layernorm_bwd_add_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _f, _p, _p, _p, _p, _p]),
+    "spacap_proposal_decode_fwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "spacap_proposal_decode_bwd_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "spacap_loss_tail_fwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p]),
     "spacap_loss_tail_bwd_f32": (_i, [_p, _p, _p, _p, _p]),
     "spacap_tf_rows_f32": (_i, [_p, _p]),

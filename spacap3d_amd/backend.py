@@ -36,6 +36,7 @@ class HipBackend:
         self.relation_losses = _fl.relation_losses
         self.caption_head_loss = _fl.caption_head_loss
         self.loss_tail = _fl.loss_tail
+        self.proposal_decode = _fl.proposal_decode
         self.l2norm_rows = _fl.l2norm_rows
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout

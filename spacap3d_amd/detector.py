@@ -292,6 +292,29 @@ class ProposalModule(nn.Module):
 
     def decode_scores(self, net, data_dict):
         NH, NS = self.num_heading_bin, self.num_size_cluster
+        from .backend import ops
+        fused = getattr(ops(), "proposal_decode", None) if net.is_cuda else None
+        if fused is not None:
+            # transpose, centre add, residual scalings, the four arg-maxes and the float64 box corners in one launch
+            nt, center, hres, sres, corners, bmask, sem, scls = fused(net, data_dict["aggregated_vote_xyz"], self.mean_size_f32,
+                                                                      self.mean_size_f64, NH, NS)
+            d = data_dict
+            d["_proposal_net"] = nt
+            d["objectness_scores"], d["center"] = nt[:, :, 0:2], center
+            d["heading_scores"] = nt[:, :, 5:5 + NH]
+            d["heading_residuals_normalized"] = nt[:, :, 5 + NH:5 + NH * 2]
+            d["heading_residuals"] = hres
+            d["size_scores"] = nt[:, :, 5 + NH * 2:5 + NH * 2 + NS]
+            d["size_residuals_normalized"] = nt[:, :, 5 + NH * 2 + NS:5 + NH * 2 + NS * 4].view(nt.shape[0], nt.shape[1], NS, 3)
+            d["size_residuals"] = sres
+            if self.size_decoded:
+                cls = scls.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)
+                d["pred_size"] = torch.gather(sres + self.mean_size_f32.unsqueeze(0).unsqueeze(0), 2, cls).squeeze(2)
+            d["sem_cls_scores"] = nt[:, :, 5 + NH * 2 + NS * 4:]
+            d["bbox_corner"] = corners
+            d["bbox_feature"] = d["aggregated_vote_features"]
+            d["bbox_mask"], d["bbox_sems"], d["sem_cls"] = bmask, sem, sem
+            return d
         nt = net.transpose(2, 1).contiguous()
         B, P = nt.shape[0], nt.shape[1]
         objectness_scores = nt[:, :, 0:2]

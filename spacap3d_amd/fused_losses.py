@@ -174,6 +174,57 @@ def caption_head_loss(logits, lang_ids, good):
     return logp, out[0], out[1], out
 
 
+class ProposalDecode(Function):
+    """(net (B,CH,K), agg_xyz (B,K,3), mean_size (NS,3)) -> (nt (B,K,CH), center, heading_residuals, size_residuals, bbox_corner
+    f64 (B,K,8,3), bbox_mask, sem_cls, size_cls): decode_scores + decode_pred_box (models/proposal_module.py:81-158) as one
+    launch each way (csrc/decode.hip)."""
+
+    @staticmethod
+    def forward(ctx, net, agg_xyz, mean_size, mean_size_f64, NH, NS):
+        if not net.is_cuda:
+            raise RuntimeError("CPU not supported")
+        net, agg, msa = net.contiguous(), agg_xyz.contiguous(), mean_size.contiguous()
+        B, CH, K = net.shape
+        NC = CH - 5 - 2 * NH - 4 * NS
+        dev = net.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            nt, center = torch.empty(B, K, CH, **f32), torch.empty(B, K, 3, **f32)
+            hres, sres = torch.empty(B, K, NH, **f32), torch.empty(B, K, NS, 3, **f32)
+            corners = torch.empty(B, K, 8, 3, dtype=torch.float64, device=dev)
+            bm, sem, sc = torch.empty(B, K, **i64), torch.empty(B, K, **i64), torch.empty(B, K, **i64)
+            check(lib.spacap_proposal_decode_fwd_f32(net.data_ptr(), agg.data_ptr(), msa.data_ptr(),
+                                                     mean_size_f64.contiguous().data_ptr() if mean_size_f64 is not None else None, B, K, int(NH), int(NS), int(NC),
+                                                     nt.data_ptr(), center.data_ptr(), hres.data_ptr(), sres.data_ptr(),
+                                                     corners.data_ptr(), bm.data_ptr(), sem.data_ptr(), sc.data_ptr(),
+                                                     torch.cuda.current_stream(dev).cuda_stream), "spacap_proposal_decode_fwd_f32")
+        ctx.save_for_backward(msa)
+        ctx.meta = (B, K, CH, int(NH), int(NS), int(NC))
+        ctx.mark_non_differentiable(corners, bm, sem, sc)
+        ctx.set_materialize_grads(False)
+        return nt, center, hres, sres, corners, bm, sem, sc
+
+    @staticmethod
+    def backward(ctx, g_nt, g_center, g_hres, g_sres, *_):
+        (msa,) = ctx.saved_tensors
+        B, K, CH, NH, NS, NC = ctx.meta
+        dev = msa.device
+        c = lambda t: t.contiguous() if t is not None else None
+        g_nt, g_center, g_hres, g_sres = c(g_nt), c(g_center), c(g_hres), c(g_sres)
+        p = lambda t: t.data_ptr() if t is not None else None
+        with torch.cuda.device(dev):
+            d_net = torch.empty(B, CH, K, dtype=torch.float32, device=dev)
+            check(lib.spacap_proposal_decode_bwd_f32(p(g_nt), p(g_center), p(g_hres), p(g_sres), msa.data_ptr(), B, K, NH, NS, NC,
+                                                     d_net.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_proposal_decode_bwd_f32")
+        return d_net, g_center, None, None, None, None
+
+
+def proposal_decode(net, agg_xyz, mean_size, mean_size_f64, NH, NS):
+    return ProposalDecode.apply(net, agg_xyz, mean_size, mean_size_f64, NH, NS)
+
+
 class LossTail(Function):
     """(det (8,), cap (4,), rel (7,) or None, objectness_label, objectness_mask, bbox_mask) -> (loss (), out (8,)) with out =
     (box_loss, det_loss, relation_loss, loss, pos_ratio, neg_ratio, obj_acc, 0): the tail of get_scene_cap_loss

@@ -88,3 +88,40 @@ def test_loss_tail_matches_the_composition():
     assert float(loss) == float(out[3]) and not out.requires_grad
     for a, b in ((det, d6), (cap, c6), (rel, r6)):
         assert float((a.grad.double() - b.grad).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("B,K,NH", [(8, 256, 1), (2, 70, 1), (1, 64, 12)])
+def test_proposal_decode_matches_the_composition(B, K, NH):
+    """fused_losses.ProposalDecode against ProposalModule.decode_scores / decode_pred_box composed from torch ops (the
+    specification: models/proposal_module.py:81-158), values exact and every gradient."""
+    import math
+    from spacap3d_amd import synthetic as S
+    from spacap3d_amd.fused_losses import proposal_decode
+    NS, NC = 18, 18
+    CH = 5 + 2 * NH + 4 * NS + NC
+    g = torch.Generator().manual_seed(B * K)
+    net0 = torch.randn(B, CH, K, generator=g).to(DEV)
+    net0[0, 5 + 2 * NH + 3, 0] = net0[0, 5 + 2 * NH + 7, 0] = 9.0      # an exact tie among the size scores: first maximum
+    agg0 = torch.randn(B, K, 3, generator=g).to(DEV)
+    msa64 = S.mean_size_arr().double().to(DEV)
+    msa = msa64.float()
+    na, aa = net0.clone().requires_grad_(), agg0.clone().requires_grad_()
+    nt, center, hres, sres, corners, bmask, sem, scls = proposal_decode(na, aa, msa, msa64, NH, NS)
+    nb, ab = net0.clone().requires_grad_(), agg0.clone().requires_grad_()
+    ntb = nb.transpose(2, 1).contiguous()
+    cb = ab + ntb[:, :, 2:5]
+    hb = ntb[:, :, 5 + NH:5 + 2 * NH] * (math.pi / NH)
+    sb = ntb[:, :, 5 + 2 * NH + NS:5 + 2 * NH + 4 * NS].view(B, K, NS, 3) * msa
+    clsb = torch.argmax(ntb[:, :, 5 + 2 * NH:5 + 2 * NH + NS], -1)
+    signs = torch.tensor([[1, 1, 1], [1, -1, 1], [-1, -1, 1], [-1, 1, 1], [1, 1, -1], [1, -1, -1], [-1, -1, -1], [-1, 1, -1]],
+                         dtype=torch.float64, device=DEV)
+    size_res = torch.gather(sb.detach(), 2, clsb.unsqueeze(-1).unsqueeze(-1).expand(-1, -1, 1, 3)).squeeze(2)
+    cornb = cb.detach().double().unsqueeze(2) + signs * ((msa64[clsb] + size_res.double()) / 2).unsqueeze(2)
+    assert torch.equal(nt, ntb) and torch.equal(center, cb) and torch.equal(hres, hb) and torch.equal(sres, sb)
+    assert torch.equal(scls, clsb) and torch.equal(bmask, ntb[:, :, 0:2].argmax(-1)) and torch.equal(sem, ntb[:, :, 5 + 2 * NH + 4 * NS:].argmax(-1))
+    assert torch.equal(corners, cornb)
+    w = [torch.randn_like(t) for t in (nt, center, hres, sres)]
+    (nt * w[0]).sum().add((center * w[1]).sum()).add((hres * w[2]).sum()).add((sres * w[3]).sum()).backward()
+    (ntb * w[0]).sum().add((cb * w[1]).sum()).add((hb * w[2]).sum()).add((sb * w[3]).sum()).backward()
+    assert float((na.grad - nb.grad).abs().max()) <= 1e-6 * float(nb.grad.abs().max())
+    assert torch.equal(aa.grad, ab.grad)
