@@ -181,6 +181,17 @@ int spacap_mha_bwd_f32(const float *q, const float *k, const float *v, long q_sb
                        const float *stats, const float *d_out, const float *d_p, void *workspace,
                        float *dq, float *dk, float *dv, long grad_row_stride, spacap_stream_t stream);
 
+/* As spacap_mha_bwd_f32 with delta f32 [B,h,Lq] = sum_k p_attn d(p_attn) precomputed by the caller (without a gradient on
+ * p_attn itself: sum_d out[b,q,head,d] d_out[b,q,head,d]; spacap_tf_rows_f32 emits it): the dQ and dK / dV halves are then
+ * independent and run as ONE launch.  Self-attention shapes only (Lq, Lk both <= 64 or both > 64). */
+int spacap_mha_bwd_delta_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
+                             long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
+                             const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
+                             long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
+                             int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                             const float *stats, const float *d_out, const float *delta,
+                             float *dq, float *dk, float *dv, long grad_row_stride, spacap_stream_t stream);
+
 /* ---- train-mode BatchNorm + ReLU (+ max over the samples) of the shared MLPs ---------------------
  * (replaces BatchNorm2d -> ReLU [-> F.max_pool2d] of lib/pointnet2/pytorch_utils.py:11-36 and
  *  lib/pointnet2/pointnet2_modules.py:253-259, forward and backward).  z f32 [B,C,L] dense (L = npoint*nsample).
@@ -580,6 +591,12 @@ typedef struct {
   float *out2;
   int n2;
   int nparts; /* > 0: a1 is [nparts][R][128], partial sums of the first product (spacap_tf_gemm_f32), added in order */
+  /* mode 1 with n2 == 128 (out2 = the gradient of the attention output): attn_out [R,128] = that output; delta_out
+   * f32 [R/lq, 8, lq] (nullable) receives sum_d out2[r, 16 head + d] attn_out[r, 16 head + d], the per-(row, head) term
+   * spacap_mha_bwd_delta_f32 takes as `delta` (8 heads of 16; rows r = b * lq + q) */
+  const float *attn_out;
+  float *delta_out;
+  int lq;
 } spacap_tf_rows_args;
 int spacap_tf_rows_f32(const spacap_tf_rows_args *args, spacap_stream_t stream);
 int spacap_tf_rows_parts(long R);

@@ -139,6 +139,8 @@ SIGNATURES = {
     "spacap_mha_fwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
                            + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p]),
     "spacap_mha_bwd_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i]),
+    "spacap_mha_bwd_delta_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
+                                 + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
     "spacap_mha_bwd_f32": (_i, [_p, _p, _p] + [_l] * 9 + [_p, _l, _l, _p, _l, _l, _l]
                            + [_i] * 5 + [_f, _f, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _l, _p]),
 }
@@ -148,7 +150,7 @@ class TfRowsArgs(ctypes.Structure):
     """``spacap_tf_rows_args`` of include/spacap_hip.h (same field order; ctypes applies the C layout rules)."""
     _fields_ = [("mode", _i), ("R", _l), ("a1", _p), ("w1", _p), ("bias1", _p), ("k1", _i), ("drop_p", _f), ("eps", _f),
                 ("seed", _u64), ("seed_dev", _p), ("res", _p), ("x_out", _p), ("ln_a", _p), ("ln_b", _p), ("n_out", _p),
-                ("stats", _p), ("x_ln", _p), ("g", _p), ("part", _p), ("w2", _p), ("bias2", _p), ("out2", _p), ("n2", _i), ("nparts", _i)]
+                ("stats", _p), ("x_ln", _p), ("g", _p), ("part", _p), ("w2", _p), ("bias2", _p), ("out2", _p), ("n2", _i), ("nparts", _i), ("attn_out", _p), ("delta_out", _p), ("lq", _i)]
 
 
 def _load():

@@ -20,12 +20,16 @@ __global__ __launch_bounds__(64) void proposal_decode_fwd_kernel(const float *__
                                                                  float *__restrict__ hres, float *__restrict__ sres,
                                                                  double *__restrict__ corners, int64_t *__restrict__ bbox_mask,
                                                                  int64_t *__restrict__ sem_cls, int64_t *__restrict__ size_cls) {
-  const int b = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;
+  // the 64 proposals' channels through LDS: channel-major reads and proposal-major writes are both coalesced
+  extern __shared__ float s_x[];                         // [64][CH + 1]
+  const int b = blockIdx.y, k0 = blockIdx.x * 64, k = k0 + threadIdx.x;
+  const int CH = 5 + 2 * NH + 4 * NS + NC, LD = CH + 1, nk = min(64, K - k0);
+  for (int c = 0; c < CH; ++c)
+    if (k < K) s_x[threadIdx.x * LD + c] = net[((size_t)b * CH + c) * K + k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < nk * CH; i += 64) nt[((size_t)b * K + k0) * CH + i] = s_x[(i / CH) * LD + i % CH];
   if (k >= K) return;
-  const int CH = 5 + 2 * NH + 4 * NS + NC;
-  const float *x = net + (size_t)b * CH * K + k;          // x[c * K] = channel c of proposal k
-  float *row = nt + ((size_t)b * K + k) * CH;
-  for (int c = 0; c < CH; ++c) row[c] = x[(size_t)c * K];
+  const float *row = s_x + threadIdx.x * LD;
   const size_t p = (size_t)b * K + k;
   bbox_mask[p] = row[1] > row[0] ? 1 : 0;                 // argmax over (no object, object): first maximum
   float cen[3];
@@ -72,20 +76,23 @@ __global__ __launch_bounds__(64) void proposal_decode_bwd_kernel(const float *__
                                                                  const float *__restrict__ g_hres, const float *__restrict__ g_sres,
                                                                  const float *__restrict__ msa, int K, int NH, int NS, int NC,
                                                                  float *__restrict__ d_net) {
-  const int b = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= K) return;
-  const int CH = 5 + 2 * NH + 4 * NS + NC;
-  const size_t p = (size_t)b * K + k;
-  float *o = d_net + (size_t)b * CH * K + k;
+  extern __shared__ float s_x[];                         // [64][CH + 1]
+  const int b = blockIdx.y, k0 = blockIdx.x * 64, k = k0 + threadIdx.x;
+  const int CH = 5 + 2 * NH + 4 * NS + NC, LD = CH + 1, nk = min(64, K - k0);
   const float hs = (float)(M_PI / (double)NH);
-  for (int c = 0; c < CH; ++c) {
+  const int s0 = 5 + 2 * NH + NS;
+  for (int i = threadIdx.x; i < nk * CH; i += 64) {      // proposal-major reads, coalesced
+    const int kk = i / CH, c = i % CH;
+    const size_t p = (size_t)b * K + k0 + kk;
     float v = g_nt ? g_nt[p * CH + c] : 0.f;
     if (g_center && c >= 2 && c < 5) v += g_center[p * 3 + (c - 2)];
     if (g_hres && c >= 5 + NH && c < 5 + 2 * NH) v += g_hres[p * NH + (c - 5 - NH)] * hs;
-    const int s0 = 5 + 2 * NH + NS;
     if (g_sres && c >= s0 && c < s0 + 3 * NS) v += g_sres[p * NS * 3 + (c - s0)] * msa[c - s0];
-    o[(size_t)c * K] = v;
+    s_x[kk * LD + c] = v;
   }
+  __syncthreads();
+  if (k >= K) return;
+  for (int c = 0; c < CH; ++c) d_net[((size_t)b * CH + c) * K + k] = s_x[threadIdx.x * LD + c];
 }
 
 }  // namespace
@@ -99,7 +106,10 @@ extern "C" int spacap_proposal_decode_fwd_f32(const float *net, const float *agg
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(net && agg_xyz && mean_size && nt && center && heading_res && size_res && corners && bbox_mask && sem_cls && size_cls,
                  "%s: null pointer", what);
-  hipLaunchKernelGGL(proposal_decode_fwd_kernel, dim3((K + 63) / 64, B), dim3(64), 0, spacap::as_stream(stream), net, agg_xyz, mean_size,
+  const int CH = 5 + 2 * NH + 4 * NS + NC;
+  SPACAP_REQUIRE((size_t)64 * (CH + 1) * sizeof(float) <= 64 * 1024, "%s: too many channels (%d)", what, CH);
+  hipLaunchKernelGGL(proposal_decode_fwd_kernel, dim3((K + 63) / 64, B), dim3(64), (size_t)64 * (CH + 1) * sizeof(float),
+                     spacap::as_stream(stream), net, agg_xyz, mean_size,
                      mean_size_f64, K, NH, NS, NC, nt, center, heading_res, size_res, corners, bbox_mask, sem_cls, size_cls);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -112,7 +122,10 @@ extern "C" int spacap_proposal_decode_bwd_f32(const float *g_nt, const float *g_
   SPACAP_REQUIRE(B >= 0 && K >= 1 && NH >= 1 && NS >= 1 && NC >= 1, "%s: bad sizes", what);
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(mean_size && d_net, "%s: null pointer", what);
-  hipLaunchKernelGGL(proposal_decode_bwd_kernel, dim3((K + 63) / 64, B), dim3(64), 0, spacap::as_stream(stream), g_nt, g_center,
+  const int CH = 5 + 2 * NH + 4 * NS + NC;
+  SPACAP_REQUIRE((size_t)64 * (CH + 1) * sizeof(float) <= 64 * 1024, "%s: too many channels (%d)", what, CH);
+  hipLaunchKernelGGL(proposal_decode_bwd_kernel, dim3((K + 63) / 64, B), dim3(64), (size_t)64 * (CH + 1) * sizeof(float),
+                     spacap::as_stream(stream), g_nt, g_center,
                      g_heading_res, g_size_res, mean_size, K, NH, NS, NC, d_net);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;

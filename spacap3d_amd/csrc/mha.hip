@@ -204,12 +204,14 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const MhaArgs A) {
 // ------------------------------------------------------------------------------------------------
 // backward A: dQ and delta.  One wave (= one workgroup) per 16 queries.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int DK>
-__global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
+// PRE: delta[b, head, q] = sum_k p d(p) was formed by the caller (= sum_d out d_out when no gradient arrives on p_attn
+// itself): the dQ and the dK / dV halves are then independent and run as ONE launch (mha_bwd_both_*).
+template <int NT, int DK, bool PRE>
+__device__ __forceinline__ void bwd_dq_body(const MhaArgs &A, int bx) {
   const DropSeed sd = drop_seed(A);
   const int lane = threadIdx.x;
   const int b = blockIdx.z, hh = blockIdx.y;
-  const int q0 = blockIdx.x * 16;
+  const int q0 = bx * 16;
   const int lq = lane & 15, lg = lane >> 4;
   const int q = q0 + lq;
   const int qc = q < A.Lq ? q : A.Lq - 1;
@@ -259,9 +261,13 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
       }
     }
   }
-  delta += __shfl_xor(delta, 16);
-  delta += __shfl_xor(delta, 32);
-  if (lg == 0 && q < A.Lq) A.delta[((size_t)b * A.h + hh) * A.Lq + q] = delta;
+  if (PRE) {
+    delta = A.delta[((size_t)b * A.h + hh) * A.Lq + qc];
+  } else {
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    if (lg == 0 && q < A.Lq) A.delta[((size_t)b * A.h + hh) * A.Lq + q] = delta;
+  }
 
   f32x4 dq[DK / 16];
 #pragma unroll
@@ -291,16 +297,21 @@ __global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
   }
 }
 
+template <int NT, int DK>
+__global__ __launch_bounds__(64) void mha_bwd_dq_kernel(const MhaArgs A) {
+  bwd_dq_body<NT, DK, false>(A, blockIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward B: dK and dV.  One wave per 16 keys, loops over query tiles; S (not S^T) orientation so the
 // accumulator registers are again directly the A operands of the products that sum over queries.
 // ------------------------------------------------------------------------------------------------
 template <int DK>
-__global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
+__device__ __forceinline__ void bwd_dkv_body(const MhaArgs &A, int bx) {
   const DropSeed sd = drop_seed(A);
   const int lane = threadIdx.x;
   const int b = blockIdx.z, hh = blockIdx.y;
-  const int key0 = blockIdx.x * 16;
+  const int key0 = bx * 16;
   const int lq = lane & 15, lg = lane >> 4;
   const int key = key0 + lq;  // the key this lane carries (C-layout column)
   const int kc = key < A.Lk ? key : A.Lk - 1;
@@ -371,6 +382,19 @@ __global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
     }
   }
 }
+
+template <int DK>
+__global__ __launch_bounds__(64) void mha_bwd_dkv_kernel(const MhaArgs A) {
+  bwd_dkv_body<DK>(A, blockIdx.x);
+}
+
+// both halves in one launch (delta precomputed): blocks [0, nqb) form dQ, the rest dK / dV
+template <int NT, int DK>
+__global__ __launch_bounds__(64) void mha_bwd_both_kernel(const MhaArgs A, int nqb) {
+  if ((int)blockIdx.x < nqb) bwd_dq_body<NT, DK, true>(A, blockIdx.x);
+  else bwd_dkv_body<DK>(A, (int)blockIdx.x - nqb);
+}
+
 
 
 // ------------------------------------------------------------------------------------------------
@@ -497,14 +521,14 @@ __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
   }
 }
 
-template <int NTW, int DK>
-__global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) {
+template <int NTW, int DK, bool PRE>
+__device__ __forceinline__ void bwd_dq_split_body(const MhaArgs &A, int bx) {
   const DropSeed sd = drop_seed(A);
   __shared__ float s_d[4][16];
   __shared__ float s_o[4][16][DK + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
-  const int q0 = blockIdx.x * 16;
+  const int q0 = bx * 16;
   const int lq = lane & 15, lg = lane >> 4;
   const int q = q0 + lq;
   const int qc = q < A.Lq ? q : A.Lq - 1;
@@ -556,12 +580,16 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) 
       }
     }
   }
-  delta += __shfl_xor(delta, 16);
-  delta += __shfl_xor(delta, 32);
-  if (lg == 0) s_d[w][lq] = delta;
-  __syncthreads();
-  delta = (s_d[0][lq] + s_d[1][lq]) + (s_d[2][lq] + s_d[3][lq]);
-  if (w == 0 && lg == 0 && q < A.Lq) A.delta[((size_t)b * A.h + hh) * A.Lq + q] = delta;
+  if (PRE) {
+    delta = A.delta[((size_t)b * A.h + hh) * A.Lq + qc];
+  } else {
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    if (lg == 0) s_d[w][lq] = delta;
+    __syncthreads();
+    delta = (s_d[0][lq] + s_d[1][lq]) + (s_d[2][lq] + s_d[3][lq]);
+    if (w == 0 && lg == 0 && q < A.Lq) A.delta[((size_t)b * A.h + hh) * A.Lq + q] = delta;
+  }
 
   f32x4 dq[DK / 16];
 #pragma unroll
@@ -594,14 +622,19 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) 
   }
 }
 
+template <int NTW, int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dq_split_kernel(const MhaArgs A) {
+  bwd_dq_split_body<NTW, DK, false>(A, blockIdx.x);
+}
+
 // dK / dV: 16 keys per workgroup, the query tiles interleaved over the 4 waves
 template <int DK>
-__global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A) {
+__device__ __forceinline__ void bwd_dkv_split_body(const MhaArgs &A, int bx) {
   const DropSeed sd = drop_seed(A);
   __shared__ float s_k[4][16][DK + 1], s_v[4][16][DK + 1];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int b = blockIdx.z, hh = blockIdx.y;
-  const int key0 = blockIdx.x * 16;
+  const int key0 = bx * 16;
   const int lq = lane & 15, lg = lane >> 4;
   const int key = key0 + lq;
   const int kc = key < A.Lk ? key : A.Lk - 1;
@@ -676,6 +709,17 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A)
   }
 }
 
+template <int DK>
+__global__ __launch_bounds__(256) void mha_bwd_dkv_split_kernel(const MhaArgs A) {
+  bwd_dkv_split_body<DK>(A, blockIdx.x);
+}
+
+template <int NTW, int DK>
+__global__ __launch_bounds__(256) void mha_bwd_both_split_kernel(const MhaArgs A, int nqb) {
+  if ((int)blockIdx.x < nqb) bwd_dq_split_body<NTW, DK, true>(A, blockIdx.x);
+  else bwd_dkv_split_body<DK>(A, (int)blockIdx.x - nqb);
+}
+
 int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, const float *v, long q_sb,
               long q_sh, long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
               const uint8_t *mask, long mask_sb, long mask_sq, const float *bias, long bias_sb, long bias_sh,
@@ -713,6 +757,25 @@ void launch_fwd(const MhaArgs &A, hipStream_t s) {
   else if (A.Lk <= 128) hipLaunchKernelGGL((mha_fwd_split_kernel<2, DK>), gs, dim3(256), 0, s, A);
   else if (A.Lk <= 256) hipLaunchKernelGGL((mha_fwd_split_kernel<4, DK>), gs, dim3(256), 0, s, A);
   else hipLaunchKernelGGL((mha_fwd_split_kernel<8, DK>), gs, dim3(256), 0, s, A);
+}
+
+// delta precomputed: ONE launch when both halves use the same kernel family (self-attention: Lq == Lk)
+template <int DK>
+bool launch_bwd_both(const MhaArgs &A, hipStream_t s) {
+  const int nqb = (A.Lq + 15) / 16, nkb = (A.Lk + 15) / 16;
+  const dim3 g(nqb + nkb, A.h, A.B);
+  if (A.Lk <= 64 && A.Lq <= 64) {
+    if (A.Lk <= 32) hipLaunchKernelGGL((mha_bwd_both_kernel<2, DK>), g, dim3(64), 0, s, A, nqb);
+    else hipLaunchKernelGGL((mha_bwd_both_kernel<4, DK>), g, dim3(64), 0, s, A, nqb);
+    return true;
+  }
+  if (A.Lk > 64 && A.Lq > 64) {
+    if (A.Lk <= 128) hipLaunchKernelGGL((mha_bwd_both_split_kernel<2, DK>), g, dim3(256), 0, s, A, nqb);
+    else if (A.Lk <= 256) hipLaunchKernelGGL((mha_bwd_both_split_kernel<4, DK>), g, dim3(256), 0, s, A, nqb);
+    else hipLaunchKernelGGL((mha_bwd_both_split_kernel<8, DK>), g, dim3(256), 0, s, A, nqb);
+    return true;
+  }
+  return false;
 }
 
 template <int DK>
@@ -787,5 +850,35 @@ extern "C" int spacap_mha_bwd_f32(const float *q, const float *k, const float *v
   else if (d_k == 32) launch_bwd<32>(A, s);
   else launch_bwd<64>(A, s);
   SPACAP_CHECK_LAUNCH("spacap_mha_bwd_f32");
+  return SPACAP_OK;
+}
+
+/* As spacap_mha_bwd_f32 with delta[b, head, q] = sum_k p_attn d(p_attn) PRECOMPUTED by the caller (f32 [B,h,Lq]; without a
+   gradient on p_attn itself it equals sum_d out[b,q,head,d] d_out[b,q,head,d]): the dQ and the dK / dV halves are then
+   independent and run as one launch for self-attention shapes.  d_p must be NULL. */
+extern "C" int spacap_mha_bwd_delta_f32(const float *q, const float *k, const float *v, long q_sb, long q_sh,
+                                        long q_sl, long k_sb, long k_sh, long k_sl, long v_sb, long v_sh, long v_sl,
+                                        const uint8_t *mask, long mask_sb, long mask_sq, const float *bias,
+                                        long bias_sb, long bias_sh, long bias_sq, int B, int h, int Lq, int Lk,
+                                        int d_k, float scale, float dropout_p, uint64_t seed, const uint64_t *seed_dev,
+                                        const float *stats, const float *d_out, const float *delta,
+                                        float *dq, float *dk, float *dv, long grad_row_stride, spacap_stream_t stream) {
+  const char *what = "spacap_mha_bwd_delta_f32";
+  MhaArgs A;
+  int rc = fill_args(A, what, q, k, v, q_sb, q_sh, q_sl, k_sb, k_sh, k_sl, v_sb, v_sh, v_sl, mask,
+                     mask_sb, mask_sq, bias, bias_sb, bias_sh, bias_sq, B, h, Lq, Lk, d_k, scale, dropout_p, seed, seed_dev);
+  if (rc) return rc;
+  if (B == 0 || Lq == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(dq && dk && dv && stats && d_out && delta, "%s: null pointer", what);
+  SPACAP_REQUIRE(grad_row_stride == 0 || grad_row_stride >= (long)h * d_k, "%s: bad grad_row_stride", what);
+  hipStream_t s = spacap::as_stream(stream);
+  A.g_sl = grad_row_stride ? grad_row_stride : (long)h * d_k;
+  A.stats = const_cast<float *>(stats);
+  A.d_out = d_out; A.d_p = nullptr;
+  A.dq = dq; A.dk = dk; A.dv = dv;
+  A.delta = const_cast<float *>(delta);
+  const bool ok = d_k == 16 ? launch_bwd_both<16>(A, s) : d_k == 32 ? launch_bwd_both<32>(A, s) : launch_bwd_both<64>(A, s);
+  SPACAP_REQUIRE(ok, "%s: (Lq=%d, Lk=%d) has no single-launch form (self-attention shapes only)", what, Lq, Lk);
+  SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

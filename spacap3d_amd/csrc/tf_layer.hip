@@ -88,6 +88,9 @@ struct TfRowsArgs {
   float *out2;           // [R][N2]
   int N2;                // 0: no second product
   int nparts;            // > 0: A1 holds that many partial results of the first product (added in order), no GEMM here
+  const float *attn_out; // BWD with N2 == 128 (out2 = gradient of the attention output a): a itself [R][128], and
+  float *delta_out;      //   delta_out [R / Lq][8][Lq] receives sum_d out2[r, 16 head + d] a[r, 16 head + d] per (row, head):
+  int Lq;                //   the softmax-backward row term of the attention kernel (h = 8 heads of 16), rows r = b Lq + q
 };
 
 // Row-tile kernel: see the file header.  256 threads = 4 waves; wave w owns columns [32 w, 32 w + 32) of the
@@ -397,12 +400,23 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
         acc[0] = MFMA16(wv2[q * 4 + i][0], at[q][i], acc[0]);
         acc[1] = MFMA16(wv2[q * 4 + i][1], at[q][i], acc[1]);
       }
-    if (valid) {
+    float dsum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
-        // columns cb[g] + e: e = 2 (u & 1) + i with u >> 1 == g
-        const f32x4 o = {acc[0][2 * g], acc[1][2 * g], acc[0][2 * g + 1], acc[1][2 * g + 1]};
-        st4(P.out2 + (size_t)row * D + cb[g], o);
+    for (int g = 0; g < 2; ++g) {
+      // columns cb[g] + e: e = 2 (u & 1) + i with u >> 1 == g
+      const f32x4 o = {acc[0][2 * g], acc[1][2 * g], acc[0][2 * g + 1], acc[1][2 * g + 1]};
+      if (valid) st4(P.out2 + (size_t)row * D + cb[g], o);
+      if (P.delta_out) {
+        const f32x4 a4 = ld4(P.attn_out + (size_t)rowc * D + cb[g]);
+        dsum += (o[0] * a4[0] + o[1] * a4[1]) + (o[2] * a4[2] + o[3] * a4[3]);
+      }
+    }
+    if (P.delta_out) {
+      // the lane's 8 columns 32 w + 8 lg .. + 7 are half of head 2 w + (lg >> 1); the other half sits in lane ^ 16
+      dsum += __shfl_xor(dsum, 16);
+      if (valid && (lg & 1) == 0) {
+        const long bi = row / P.Lq, qi = row - bi * P.Lq;
+        P.delta_out[((size_t)bi * 8 + 2 * w + (lg >> 1)) * P.Lq + qi] = dsum;
       }
     }
   }
@@ -730,6 +744,9 @@ extern "C" int spacap_tf_rows_f32(const spacap_tf_rows_args *a, spacap_stream_t 
   P.res = a->res, P.x_out = a->x_out, P.ln_a = a->ln_a, P.ln_b = a->ln_b, P.n_out = a->n_out, P.stats = a->stats;
   P.x_ln = a->x_ln, P.G = a->g, P.part = a->part, P.W2 = a->w2, P.bias2 = a->bias2, P.out2 = a->out2, P.N2 = a->n2;
   P.nparts = a->nparts;
+  P.attn_out = a->attn_out, P.delta_out = a->delta_out, P.Lq = a->lq;
+  SPACAP_REQUIRE(!P.delta_out || (a->mode == 1 && P.N2 == 128 && P.attn_out && P.Lq >= 1 && a->R % P.Lq == 0 && al16(P.attn_out)),
+                 "%s: delta_out needs mode 1, n2 = 128, attn_out and lq dividing R", what);
   SPACAP_REQUIRE(P.nparts >= 0 && (P.nparts == 0 || P.A1), "%s: nparts = %d needs the partial sums in a1", what, P.nparts);
   const bool bwd = a->mode == 1;
   if (P.A1 && P.nparts == 0) SPACAP_REQUIRE(P.W1 && P.K1 >= 128 && P.K1 % 128 == 0, "%s: first product needs weights and K1 a multiple of 128 (K1=%d)", what, P.K1);

@@ -42,6 +42,7 @@ def _rows(mode, R, dev, **kw):
     a.k1 = int(kw.pop("k1", 0))
     a.n2 = int(kw.pop("n2", 0))
     a.nparts = int(kw.pop("nparts", 0))
+    a.lq = int(kw.pop("lq", 0))
     a.drop_p = float(kw.pop("drop_p", 0.0))
     a.eps = float(kw.pop("eps", 1e-6))
     a.seed = int(kw.pop("seed", 0))
@@ -200,6 +201,89 @@ class AttnOutFfn1(Function):
         return da, dx1, dWo, dbo, dln_a, dln_b, dW1, db1, None, None, None, None, None, None
 
 
+class AttnFfn1(Function):
+    """``AttnOutFfn1`` with the self-attention in front of it inside the same node:  a = attention(qkv) (one launch);
+    (x1, h, parts) as AttnOutFfn1.  Owning both lets the backward run the attention gradient as ONE launch: the row kernel
+    that forms d a = dy Wo also emits delta[b, head, q] = sum_d a d a (the softmax-backward row term), after which the dQ
+    and the dK / dV halves are independent (spacap_mha_bwd_delta_f32).  No attention matrix is returned: layers whose
+    p_attn is consumed (the relation head's last encoder layer) use the separate attention node."""
+
+    @staticmethod
+    def forward(ctx, qkv, xres, mask_u8, mask_sb, mask_sq, heads, p_att, seed_att, Wo, bo, ln_a, ln_b, W1, b1, W2, eps, p_sub,
+                p_ffn, seed1, seed2):
+        if not qkv.is_cuda:
+            raise RuntimeError("CPU not supported")
+        import math
+        from .attention import rng_state
+        qc, xr = qkv.contiguous(), xres.contiguous()
+        B, L, three = qc.shape
+        hd = three // 3
+        dk = hd // heads
+        R, dev = B * L, xr.device
+        dff = W1.shape[0]
+        es = qc.element_size()
+        strides = (L * three, dk, three)
+        scale = 1.0 / math.sqrt(dk)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            a, lse = _new(dev, B, L, hd), _new(dev, B, heads, L, 2)
+            base = qc.data_ptr()
+            check(lib.spacap_mha_fwd_f32(base, base + hd * es, base + 2 * hd * es, *strides, *strides, *strides, _p(mask_u8), mask_sb,
+                                         mask_sq, None, 0, 0, 0, B, heads, L, L, dk, scale, float(p_att), int(seed_att),
+                                         rng_state(dev).data_ptr() if p_att > 0.0 else None, a.data_ptr(), None, lse.data_ptr(), st),
+                  "spacap_mha_fwd_f32")
+            x1, n2, stats = _new(dev, *xr.shape), _new(dev, R, D_MODEL), _new(dev, R, 2)
+            _rows(0, R, dev, a1=a, w1=Wo, bias1=bo, k1=D_MODEL, drop_p=p_sub, seed=seed1, res=xr, x_out=x1, ln_a=ln_a,
+                  ln_b=ln_b, eps=eps, n_out=n2, stats=stats)
+            h, parts = _ffn(0, n2, W1, W2, b1, None, dff, p_ffn, seed2, dev)
+        ctx.save_for_backward(qc, mask_u8, lse, a, x1, n2, stats, ln_a, Wo, W1)
+        ctx.meta = (float(eps), float(p_sub), int(seed1), int(heads), mask_sb, mask_sq, float(p_att), int(seed_att), scale)
+        ctx.set_materialize_grads(False)
+        return x1, h.view(*xr.shape[:-1], dff), parts
+
+    @staticmethod
+    def backward(ctx, g_x1, g_hpre, g_parts):
+        from .attention import rng_state
+        qc, mask_u8, lse, a, x1, n2, stats, ln_a, Wo, W1 = ctx.saved_tensors
+        eps, p_sub, seed1, heads, mask_sb, mask_sq, p_att, seed_att, scale = ctx.meta
+        B, L, three = qc.shape
+        hd = three // 3
+        dk = hd // heads
+        R, dev = B * L, x1.device
+        dff = W1.shape[0]
+        es = qc.element_size()
+        strides = (L * three, dk, three)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            dx1, dy1, da, part = _new(dev, *x1.shape), _new(dev, R, D_MODEL), _new(dev, B, L, hd), _parts(dev, R)
+            delta = _new(dev, B, heads, L)
+            kw = dict(x_ln=x1, stats=stats, ln_a=ln_a, eps=eps, res=g_x1.contiguous() if g_x1 is not None else None,
+                      x_out=dx1, part=part, drop_p=p_sub, seed=seed1, n_out=dy1, w2=Wo, n2=D_MODEL, out2=da, attn_out=a,
+                      delta_out=delta, lq=L)
+            dW1 = db1 = None
+            if g_hpre is not None and g_parts is not None:
+                gh, gp = g_hpre.reshape(R, dff).contiguous(), g_parts.contiguous()
+                _rows(1, R, dev, a1=gp, nparts=gp.shape[0], **kw)
+                dW1, db1 = _linear_grads(gh, n2, W1)
+            elif g_hpre is not None:
+                gh = g_hpre.reshape(R, dff).contiguous()
+                parts, S = _split_product(gh, W1, False)
+                _rows(1, R, dev, a1=parts, nparts=S, **kw)
+                dW1, db1 = _linear_grads(gh, n2, W1)
+            else:
+                _rows(1, R, dev, g=torch.zeros(R, D_MODEL, dtype=torch.float32, device=dev), **kw)
+            dln_a, dln_b = _ln_param_grads(part)
+            dWo, dbo = _linear_grads(dy1, a.reshape(R, D_MODEL), Wo)
+            dqkv = torch.empty_like(qc)
+            base, gb = qc.data_ptr(), dqkv.data_ptr()
+            check(lib.spacap_mha_bwd_delta_f32(base, base + hd * es, base + 2 * hd * es, *strides, *strides, *strides, _p(mask_u8),
+                                               mask_sb, mask_sq, None, 0, 0, 0, B, heads, L, L, dk, scale, p_att, seed_att,
+                                               rng_state(dev).data_ptr() if p_att > 0.0 else None, lse.data_ptr(), da.data_ptr(),
+                                               delta.data_ptr(), gb, gb + hd * es, gb + 2 * hd * es, three, st),
+                  "spacap_mha_bwd_delta_f32")
+        return (dqkv, dx1, None, None, None, None, None, None, dWo, dbo, dln_a, dln_b, dW1, db1, None, None, None, None, None, None)
+
+
 class Ffn2Ln(Function):
     """x2 = x1 + dropout(h W2^T + b2) -- ``parts`` = the partial sums of h W2^T from ``AttnOutFfn1`` --;
     n = LayerNorm(x2) with the NEXT layer's (or the stack's final) norm;  returns (x2, n Wqkv^T + bqkv) -- or (n,) when ``pw``
@@ -295,7 +379,7 @@ def stack_supported(layers, x):
 def run_stack(layers, final_norm, x, mask):
     """The N pre-norm layers (self-attention + feed-forward each) followed by ``final_norm``
     (models/transformer_captioner.py: Encoder :166-178 / Decoder :193-207 in early-guide mode)."""
-    from .attention import _next_seed, self_attention_packed
+    from .attention import _next_seed, _prep_mask, self_attention_packed
 
     def drop(m):
         return float(m.p) if m.training else 0.0
@@ -312,14 +396,23 @@ def run_stack(layers, final_norm, x, mask):
         sa, ff = l.self_attn, l.feed_forward
         s_att, s_ffn = sub(l)
         need_p = sa.keep_value if sa.store_attn is None else (sa.store_attn or sa.keep_value)
-        a, sa.attn = self_attention_packed(qkv, sa.h, mask=mask, dropout_p=sa.dropout.p, training=sa.dropout.training,
-                                           need_p=need_p)
-        if sa.keep_value:
-            hd = sa.h * sa.d_k
-            sa.value = qkv[..., 2 * hd:].view(qkv.shape[0], -1, sa.h, sa.d_k).transpose(1, 2)
         p1, pf, p3 = drop(s_att.dropout), drop(ff.dropout), drop(s_ffn.dropout)
-        x1, h, parts = AttnOutFfn1.apply(a, xres, sa.linears[-1].weight, sa.linears[-1].bias, s_ffn.norm.a_2, s_ffn.norm.b_2,
-                                         ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, s_ffn.norm.eps, p1, pf, seed(p1), seed(pf))
+        wo = sa.linears[-1]
+        tail = (wo.weight, wo.bias, s_ffn.norm.a_2, s_ffn.norm.b_2, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, s_ffn.norm.eps, p1, pf)
+        if not need_p and sa.d_k == 16 and sa.h == 8:
+            # attention inside the node: its gradient is one launch (see AttnFfn1)
+            B_, L_ = qkv.shape[0], qkv.shape[1]
+            m8, msb, msq = _prep_mask(mask, B_, L_, L_)
+            pa = float(sa.dropout.p) if sa.dropout.training else 0.0
+            sa.attn = None
+            x1, h, parts = AttnFfn1.apply(qkv, xres, m8, msb, msq, sa.h, pa, seed(pa), *tail, seed(p1), seed(pf))
+        else:
+            a, sa.attn = self_attention_packed(qkv, sa.h, mask=mask, dropout_p=sa.dropout.p, training=sa.dropout.training,
+                                               need_p=need_p)
+            if sa.keep_value:
+                hd = sa.h * sa.d_k
+                sa.value = qkv[..., 2 * hd:].view(qkv.shape[0], -1, sa.h, sa.d_k).transpose(1, 2)
+            x1, h, parts = AttnOutFfn1.apply(a, xres, *tail, seed(p1), seed(pf))
         if i + 1 < len(layers):
             nxt = layers[i + 1]
             nn_ = nxt.sublayer[0].norm

@@ -264,3 +264,46 @@ def test_decode_attention_step_over_the_cache(tf):
         want = (p @ v).transpose(1, 2).reshape(R, 128)
         assert rel(out, want) < 3e-6, t
         assert torch.equal(kc[:, t], qkv[:, 128:256]) and torch.equal(vc[:, t], qkv[:, 256:])
+
+
+@pytest.mark.parametrize("B,L,mask_kind,p", [(2, 256, "key", 0.0), (3, 32, "causal", 0.0), (2, 256, "key", 0.2), (1, 96, None, 0.0)])
+def test_single_launch_attention_backward_equals_the_two_launch_form(tf, B, L, mask_kind, p):
+    """spacap_mha_bwd_delta_f32 (delta = sum_d out d_out handed in, dQ and dK/dV halves in one launch) against
+    spacap_mha_bwd_f32 (two launches, delta formed by the first): same kernels' arithmetic, so bitwise equal gradients; the
+    handed-in delta itself equals the first form's up to fp32 summation order."""
+    import math
+    from spacap3d_amd._native import check, lib
+    h, dk, hd = 8, 16, 128
+    qkv = _rand(B, L, 3 * hd, seed=1)
+    dout = _rand(B, L, hd, seed=2)
+    if mask_kind == "key":
+        mask = (torch.rand(B, 1, L, generator=torch.Generator().manual_seed(3)) > 0.3).to(torch.uint8).to(DEV)
+        mask[..., 0] = 1
+        msb, msq = L, 0
+    elif mask_kind == "causal":
+        mask = torch.ones(B, L, L, dtype=torch.uint8).tril().to(DEV).contiguous()
+        msb, msq = L * L, L
+    else:
+        mask, msb, msq = None, 0, 0
+    st = torch.cuda.current_stream().cuda_stream
+    strides = (L * 3 * hd, dk, 3 * hd)
+    base = qkv.data_ptr()
+    mp = mask.data_ptr() if mask is not None else None
+    rng = torch.zeros(1, dtype=torch.int64, device=DEV)
+    rp = rng.data_ptr() if p > 0 else None
+    out, lse = torch.empty(B, L, hd, device=DEV), torch.empty(B, h, L, 2, device=DEV)
+    args = (base, base + hd * 4, base + 2 * hd * 4, *strides, *strides, *strides, mp, msb, msq, None, 0, 0, 0, B, h, L, L, dk,
+            1.0 / math.sqrt(dk), p, 77, rp)
+    check(lib.spacap_mha_fwd_f32(*args, out.data_ptr(), None, lse.data_ptr(), st), "fwd")
+    g1, g2 = torch.empty_like(qkv), torch.empty_like(qkv)
+    ws = torch.empty(B * h * L, device=DEV)
+    check(lib.spacap_mha_bwd_f32(*args, lse.data_ptr(), dout.data_ptr(), None, ws.data_ptr(), g1.data_ptr(), g1.data_ptr() + hd * 4,
+                                 g1.data_ptr() + 2 * hd * 4, 3 * hd, st), "bwd")
+    delta = (out * dout).view(B, L, h, dk).sum(-1).permute(0, 2, 1).contiguous()
+    assert rel(delta.view(-1), ws) < 2e-5
+    check(lib.spacap_mha_bwd_delta_f32(*args, lse.data_ptr(), dout.data_ptr(), ws.data_ptr(), g2.data_ptr(), g2.data_ptr() + hd * 4,
+                                       g2.data_ptr() + 2 * hd * 4, 3 * hd, st), "bwd delta")
+    assert torch.equal(g1, g2)
+    check(lib.spacap_mha_bwd_delta_f32(*args, lse.data_ptr(), dout.data_ptr(), delta.data_ptr(), g2.data_ptr(),
+                                       g2.data_ptr() + hd * 4, g2.data_ptr() + 2 * hd * 4, 3 * hd, st), "bwd delta")
+    assert rel(g2, g1) < 2e-5
