@@ -48,6 +48,7 @@ struct MhaArgs {
   const float *d_out, *d_p;         // backward inputs
   float *dq, *dk, *dv, *delta;      // backward outputs / scratch
   long g_sl;                        // row stride (floats) of dq / dk / dv: h * d_k when dense
+  int vec;                          // q / k / v rows are 16-byte aligned (bases and strides): operands by 16-byte loads
 };
 
 // Dropout keep decision of element (b, head, q, key): a counter hash (murmur3 fmix32 over the element index mixed
@@ -87,6 +88,37 @@ __device__ __forceinline__ float logit(const MhaArgs &A, float dot, int b, int h
   }
   if (key >= A.Lk) s = -INFINITY;
   return s;
+}
+
+// the mask bytes of 4 consecutive keys of one query as one 32-bit load where the row allows it (else 4 byte loads):
+// byte r = mask of key0 + r; 0xff.. for positions past Lk (those logits are -inf anyway)
+static __device__ __forceinline__ unsigned mask4(const MhaArgs &A, int b, int qc, int key0) {
+  if (!A.mask) return 0x01010101u;
+  const uint8_t *m = A.mask + b * A.mask_sb + qc * A.mask_sq;
+  if (key0 + 3 < A.Lk && ((reinterpret_cast<uintptr_t>(m) + key0) & 3) == 0) return *reinterpret_cast<const unsigned *>(m + key0);
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r |= (unsigned)m[key0 + i < A.Lk ? key0 + i : A.Lk - 1] << (8 * i);
+  return r;
+}
+// logit with the mask byte handed in (see logit())
+static __device__ __forceinline__ float logit_m(const MhaArgs &A, float dot, int b, int hh, int q, int key, unsigned mbyte, bool &masked) {
+  float s = dot * A.scale;
+  if (A.bias) {
+    const int qc = q < A.Lq ? q : A.Lq - 1, kc = key < A.Lk ? key : A.Lk - 1;
+    s += A.bias[b * A.bias_sb + hh * A.bias_sh + qc * A.bias_sq + kc];
+  }
+  masked = false;
+  if (A.mask && mbyte == 0) {
+    s = -1e9f;
+    masked = true;
+  }
+  if (key >= A.Lk) s = -INFINITY;
+  return s;
+}
+static __device__ __forceinline__ f32x4 ldv(const float *p, int vec) {
+  if (vec) return *reinterpret_cast<const f32x4 *>(p);
+  return f32x4{p[0], p[1], p[2], p[3]};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -417,10 +449,15 @@ __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
   const int qc = q < A.Lq ? q : A.Lq - 1;
   const int t0 = w * NTW;
 
+  // operands as 16-byte loads: step (j, s) of the dot product covers k = 16 j + 4 lg + s in BOTH operands (any order of k
+  // gives the same sum of products; one load instruction per 16 keys x 16 channels instead of four)
   const float *qp = A.q + b * A.q_sb + hh * A.q_sh + qc * A.q_sl;
-  float qreg[DK / 4];
+  f32x4 qv[DK / 16];
 #pragma unroll
-  for (int s = 0; s < DK / 4; ++s) qreg[s] = qp[4 * s + lg];
+  for (int j = 0; j < DK / 16; ++j) {
+    if (A.vec) qv[j] = *reinterpret_cast<const f32x4 *>(qp + 16 * j + 4 * lg);
+    else qv[j] = f32x4{qp[16 * j + 4 * lg], qp[16 * j + 4 * lg + 1], qp[16 * j + 4 * lg + 2], qp[16 * j + 4 * lg + 3]};
+  }
 
   f32x4 acc[NTW];
   const float *kbase = A.k + b * A.k_sb + hh * A.k_sh;
@@ -432,16 +469,23 @@ __global__ __launch_bounds__(256) void mha_fwd_split_kernel(const MhaArgs A) {
       const int key = 16 * t + lq;
       const float *kp = kbase + (key < A.Lk ? key : A.Lk - 1) * A.k_sl;
 #pragma unroll
-      for (int s = 0; s < DK / 4; ++s) acc[tt] = MFMA16(kp[4 * s + lg], qreg[s], acc[tt]);
+      for (int j = 0; j < DK / 16; ++j) {
+        f32x4 kv;
+        if (A.vec) kv = *reinterpret_cast<const f32x4 *>(kp + 16 * j + 4 * lg);
+        else kv = f32x4{kp[16 * j + 4 * lg], kp[16 * j + 4 * lg + 1], kp[16 * j + 4 * lg + 2], kp[16 * j + 4 * lg + 3]};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[tt] = MFMA16(kv[s], qv[j][s], acc[tt]);
+      }
     }
   }
   float m = -INFINITY;
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) {
+    const unsigned m4 = mask4(A, b, qc, 16 * (t0 + tt) + 4 * lg);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       bool masked;
-      acc[tt][r] = logit(A, acc[tt][r], b, hh, q, 16 * (t0 + tt) + 4 * lg + r, masked);
+      acc[tt][r] = logit_m(A, acc[tt][r], b, hh, q, 16 * (t0 + tt) + 4 * lg + r, (m4 >> (8 * r)) & 0xffu, masked);
       m = fmaxf(m, acc[tt][r]);
     }
   }
@@ -536,11 +580,12 @@ __device__ __forceinline__ void bwd_dq_split_body(const MhaArgs &A, int bx) {
 
   const float *qp = A.q + b * A.q_sb + hh * A.q_sh + qc * A.q_sl;
   const float *dop = A.d_out + (((size_t)b * A.Lq + qc) * A.h + hh) * DK;
-  float qreg[DK / 4], doreg[DK / 4];
+  // (16-byte operand loads, k permuted as in the forward kernel: step (j, s) covers k = 16 j + 4 lg + s in both operands)
+  f32x4 qv[DK / 16], dov[DK / 16];
 #pragma unroll
-  for (int s = 0; s < DK / 4; ++s) {
-    qreg[s] = qp[4 * s + lg];
-    doreg[s] = dop[4 * s + lg];
+  for (int j = 0; j < DK / 16; ++j) {
+    qv[j] = ldv(qp + 16 * j + 4 * lg, A.vec);
+    dov[j] = ldv(dop + 16 * j + 4 * lg, (DK * A.h) % 4 == 0);
   }
   const float *st = A.stats + (((size_t)b * A.h + hh) * A.Lq + qc) * 2;
   const float m = st[0], inv_l = 1.0f / st[1];
@@ -561,15 +606,20 @@ __device__ __forceinline__ void bwd_dq_split_body(const MhaArgs &A, int bx) {
       const float *kp = kbase + kcl * A.k_sl;
       const float *vp = vbase + kcl * A.v_sl;
 #pragma unroll
-      for (int s = 0; s < DK / 4; ++s) {
-        p[tt] = MFMA16(kp[4 * s + lg], qreg[s], p[tt]);
-        dp[tt] = MFMA16(vp[4 * s + lg], doreg[s], dp[tt]);
+      for (int j = 0; j < DK / 16; ++j) {
+        const f32x4 kv = ldv(kp + 16 * j + 4 * lg, A.vec), vv = ldv(vp + 16 * j + 4 * lg, A.vec);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          p[tt] = MFMA16(kv[s], qv[j][s], p[tt]);
+          dp[tt] = MFMA16(vv[s], dov[j][s], dp[tt]);
+        }
       }
+      const unsigned m4 = mask4(A, b, qc, 16 * t + 4 * lg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * t + 4 * lg + r;
         bool masked;
-        const float s = logit(A, p[tt][r], b, hh, q, key, masked);
+        const float s = logit_m(A, p[tt][r], b, hh, q, key, (m4 >> (8 * r)) & 0xffu, masked);
         const float pr = (key < A.Lk) ? expf(s - m) * inv_l : 0.f;
         float g = dp[tt][r];
         if (dprow && key < A.Lk) g += dprow[key];
@@ -641,11 +691,11 @@ __device__ __forceinline__ void bwd_dkv_split_body(const MhaArgs &A, int bx) {
 
   const float *kp = A.k + b * A.k_sb + hh * A.k_sh + kc * A.k_sl;
   const float *vp = A.v + b * A.v_sb + hh * A.v_sh + kc * A.v_sl;
-  float kreg[DK / 4], vreg[DK / 4];
+  f32x4 kv[DK / 16], vv[DK / 16];   // (16-byte operand loads, k permuted: see the forward kernel)
 #pragma unroll
-  for (int s = 0; s < DK / 4; ++s) {
-    kreg[s] = kp[4 * s + lg];
-    vreg[s] = vp[4 * s + lg];
+  for (int j = 0; j < DK / 16; ++j) {
+    kv[j] = ldv(kp + 16 * j + 4 * lg, A.vec);
+    vv[j] = ldv(vp + 16 * j + 4 * lg, A.vec);
   }
   f32x4 dk[DK / 16], dv[DK / 16];
 #pragma unroll
@@ -664,24 +714,41 @@ __device__ __forceinline__ void bwd_dkv_split_body(const MhaArgs &A, int bx) {
     const float *dop = A.d_out + (((size_t)b * A.Lq + qac) * A.h + hh) * DK;
     f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < DK / 4; ++s) {
-      s4 = MFMA16(qp[4 * s + lg], kreg[s], s4);
-      g4 = MFMA16(dop[4 * s + lg], vreg[s], g4);
+    for (int j = 0; j < DK / 16; ++j) {
+      const f32x4 qq = ldv(qp + 16 * j + 4 * lg, A.vec), dd = ldv(dop + 16 * j + 4 * lg, (DK * A.h) % 4 == 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        s4 = MFMA16(qq[s], kv[j][s], s4);
+        g4 = MFMA16(dd[s], vv[j][s], g4);
+      }
     }
+    // the four queries of this lane are consecutive: their row statistics and delta as 16-byte loads when the tile is whole
+    const int qb = qt * 16 + 4 * lg;
+    const bool whole = qb + 3 < A.Lq && (A.Lq & 3) == 0;
+    f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, st1 = st0, dl4 = st0;
+    if (whole) {
+      st0 = *reinterpret_cast<const f32x4 *>(stb + qb * 2);
+      st1 = *reinterpret_cast<const f32x4 *>(stb + qb * 2 + 4);
+      dl4 = *reinterpret_cast<const f32x4 *>(delb + qb);
+    }
+    const unsigned mkey = (A.mask && A.mask_sq == 0) ? A.mask[b * A.mask_sb + kc] : 1u;   // key mask: the same for every query
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = qt * 16 + 4 * lg + r;
       const int qc = q < A.Lq ? q : A.Lq - 1;
       const bool valid = (q < A.Lq) && (key < A.Lk);
       bool masked;
-      const float s = logit(A, s4[r], b, hh, q, key, masked);
-      const float pr = valid ? expf(s - stb[qc * 2]) / stb[qc * 2 + 1] : 0.f;
+      const float rm = whole ? (r < 2 ? st0[2 * r] : st1[2 * r - 4]) : stb[qc * 2];
+      const float rl = whole ? (r < 2 ? st0[2 * r + 1] : st1[2 * r - 3]) : stb[qc * 2 + 1];
+      const float dlt = whole ? dl4[r] : delb[qc];
+      const float s = (A.mask && A.mask_sq != 0) ? logit(A, s4[r], b, hh, q, key, masked) : logit_m(A, s4[r], b, hh, q, key, mkey, masked);
+      const float pr = valid ? expf(s - rm) / rl : 0.f;
       float g = g4[r];
       if (A.d_p && valid) g += A.d_p[(((size_t)b * A.h + hh) * A.Lq + qc) * A.Lk + kc];
       const bool keep = keep_elem(A, sd, b, hh, q, key);
       g = keep ? g * A.keep_scale : 0.f;
       const float pd = keep ? pr * A.keep_scale : 0.f;
-      const float ds = (masked || !valid) ? 0.f : pr * (g - delb[qc]) * A.scale;
+      const float ds = (masked || !valid) ? 0.f : pr * (g - dlt) * A.scale;
       const float *qr = qbase + qc * A.q_sl;
       const float *dor = A.d_out + (((size_t)b * A.Lq + qc) * A.h + hh) * DK;
 #pragma unroll
@@ -743,6 +810,10 @@ int fill_args(MhaArgs &A, const char *what, const float *q, const float *k, cons
   A.drop_thresh = dropout_p > 0.f ? (unsigned)fmin(4294967295.0, (double)dropout_p * 4294967296.0) : 0u;
   A.seed = seed;
   A.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
+  auto al = [](const void *p, long a, long b2, long c) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && a % 4 == 0 && b2 % 4 == 0 && c % 4 == 0;
+  };
+  A.vec = al(q, q_sb, q_sh, q_sl) && al(k, k_sb, k_sh, k_sl) && al(v, v_sb, v_sh, v_sl) ? 1 : 0;
   A.out = A.p_out = A.stats = nullptr;
   A.d_out = A.d_p = nullptr;
   A.dq = A.dk = A.dv = A.delta = nullptr;

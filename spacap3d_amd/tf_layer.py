@@ -276,6 +276,7 @@ class AttnFfn1(Function):
             dWo, dbo = _linear_grads(dy1, a.reshape(R, D_MODEL), Wo)
             dqkv = torch.empty_like(qc)
             base, gb = qc.data_ptr(), dqkv.data_ptr()
+            # (the two halves of the attention gradient are independent once delta is known: one launch)
             check(lib.spacap_mha_bwd_delta_f32(base, base + hd * es, base + 2 * hd * es, *strides, *strides, *strides, _p(mask_u8),
                                                mask_sb, mask_sq, None, 0, 0, 0, B, heads, L, L, dk, scale, p_att, seed_att,
                                                rng_state(dev).data_ptr() if p_att > 0.0 else None, lse.data_ptr(), da.data_ptr(),

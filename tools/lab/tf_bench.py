@@ -46,10 +46,35 @@ def rows(mode, R, **kw):
     return lambda: check(lib.spacap_tf_rows_f32(ctypes.byref(a), st), "rows")
 
 
+def mha(B, L, p=0.1):
+    import math
+    h, dk, hd = 8, 16, 128
+    st = torch.cuda.current_stream().cuda_stream
+    qkv, dout = torch.randn(B, L, 3 * hd, device=DEV), torch.randn(B, L, hd, device=DEV)
+    mask = (torch.rand(B, 1, L, device=DEV) > 0.3).to(torch.uint8)
+    mask[..., 0] = 1
+    rng = torch.zeros(1, dtype=torch.int64, device=DEV)
+    out, lse = torch.empty(B, L, hd, device=DEV), torch.empty(B, h, L, 2, device=DEV)
+    strides = (L * 3 * hd, dk, 3 * hd)
+    base = qkv.data_ptr()
+    args = (base, base + hd * 4, base + 2 * hd * 4, *strides, *strides, *strides, mask.data_ptr(), L, 0, None, 0, 0, 0, B, h, L, L, dk,
+            1.0 / math.sqrt(dk), p, 77, rng.data_ptr())
+    g, ws = torch.empty_like(qkv), torch.empty(B * h * L, device=DEV)
+    gp = (g.data_ptr(), g.data_ptr() + hd * 4, g.data_ptr() + 2 * hd * 4, 3 * hd, st)
+    fl = 4.0 * B * h * L * L * dk
+    t(lambda: check(lib.spacap_mha_fwd_f32(*args, out.data_ptr(), None, lse.data_ptr(), st), "f"), f"mha fwd B={B} L={L}", fl)
+    t(lambda: check(lib.spacap_mha_bwd_f32(*args, lse.data_ptr(), dout.data_ptr(), None, ws.data_ptr(), *gp), "b"),
+      f"mha bwd, two launches B={B} L={L}", 2.5 * fl)
+    t(lambda: check(lib.spacap_mha_bwd_delta_f32(*args, lse.data_ptr(), dout.data_ptr(), ws.data_ptr(), *gp), "b"),
+      f"mha bwd, one launch (delta given) B={B} L={L}", 2.5 * fl)
+
+
 def main():
     r = lambda *s: torch.randn(*s, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     dff = 2048
+    mha(8, 256)
+    mha(8, 32)
     for R in (2048, 256):
         print(f"--- R = {R}")
         x, n, a_, h = r(R, 128), r(R, 128), r(R, 128), torch.relu(r(R, dff))
