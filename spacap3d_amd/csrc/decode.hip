@@ -13,75 +13,79 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void proposal_decode_fwd_kernel(const float *__restrict__ net, const float *__restrict__ agg_xyz,
-                                                                 const float *__restrict__ msa, const double *__restrict__ msa64,
-                                                                 int K, int NH, int NS, int NC,
-                                                                 float *__restrict__ nt, float *__restrict__ center,
-                                                                 float *__restrict__ hres, float *__restrict__ sres,
-                                                                 double *__restrict__ corners, int64_t *__restrict__ bbox_mask,
-                                                                 int64_t *__restrict__ sem_cls, int64_t *__restrict__ size_cls) {
-  // the 64 proposals' channels through LDS: channel-major reads and proposal-major writes are both coalesced
-  extern __shared__ float s_x[];                         // [64][CH + 1]
-  const int b = blockIdx.y, k0 = blockIdx.x * 64, k = k0 + threadIdx.x;
+__global__ __launch_bounds__(256) void proposal_decode_fwd_kernel(const float *__restrict__ net, const float *__restrict__ agg_xyz,
+                                                                  const float *__restrict__ msa, const double *__restrict__ msa64,
+                                                                  int K, int NH, int NS, int NC,
+                                                                  float *__restrict__ nt, float *__restrict__ center,
+                                                                  float *__restrict__ hres, float *__restrict__ sres,
+                                                                  double *__restrict__ corners, int64_t *__restrict__ bbox_mask,
+                                                                  int64_t *__restrict__ sem_cls, int64_t *__restrict__ size_cls) {
+  // 64 proposals per workgroup of 256 threads.  Phase A (all threads): the proposals' channels through LDS -- channel-major
+  // reads and proposal-major writes both coalesced.  Phase B (one thread per proposal): arg-maxes and the centre.  Phase C
+  // (all threads): the per-proposal output rows (size residuals, corners) written cooperatively.
+  extern __shared__ float s_x[];                         // [64][CH + 1], then [64][4] (centre x, y, z, size class)
+  const int b = blockIdx.y, k0 = blockIdx.x * 64, tid = threadIdx.x;
   const int CH = 5 + 2 * NH + 4 * NS + NC, LD = CH + 1, nk = min(64, K - k0);
-  for (int c = 0; c < CH; ++c)
-    if (k < K) s_x[threadIdx.x * LD + c] = net[((size_t)b * CH + c) * K + k];
+  float *s_c = s_x + 64 * LD;
+  for (int i = tid; i < CH * 64; i += 256) {
+    const int c = i >> 6, kk = i & 63;
+    if (kk < nk) s_x[kk * LD + c] = net[((size_t)b * CH + c) * K + k0 + kk];
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < nk * CH; i += 64) nt[((size_t)b * K + k0) * CH + i] = s_x[(i / CH) * LD + i % CH];
-  if (k >= K) return;
-  const float *row = s_x + threadIdx.x * LD;
-  const size_t p = (size_t)b * K + k;
-  bbox_mask[p] = row[1] > row[0] ? 1 : 0;                 // argmax over (no object, object): first maximum
-  float cen[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) cen[d] = agg_xyz[p * 3 + d] + row[2 + d], center[p * 3 + d] = cen[d];
-  const float hs = (float)(M_PI / (double)NH);
-  for (int i = 0; i < NH; ++i) hres[p * NH + i] = row[5 + NH + i] * hs;
-  const float *ss = row + 5 + 2 * NH, *sr = ss + NS;
-  int sc = 0;
-  float best = ss[0];
-  for (int j = 1; j < NS; ++j)
-    if (ss[j] > best) best = ss[j], sc = j;
-  size_cls[p] = sc;
-  float mine[3] = {0.f, 0.f, 0.f};
-  for (int j = 0; j < NS; ++j)
+  for (int i = tid; i < nk * CH; i += 256) nt[((size_t)b * K + k0) * CH + i] = s_x[(i / CH) * LD + i % CH];
+  if (tid < nk) {
+    const float *row = s_x + tid * LD;
+    const size_t p = (size_t)b * K + k0 + tid;
+    bbox_mask[p] = row[1] > row[0] ? 1 : 0;               // argmax over (no object, object): first maximum
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float v = sr[3 * j + d] * msa[3 * j + d];
-      sres[(p * NS + j) * 3 + d] = v;
-      if (j == sc) mine[d] = v;
+      const float c = agg_xyz[p * 3 + d] + row[2 + d];
+      center[p * 3 + d] = c;
+      s_c[tid * 4 + d] = c;
     }
-  const float *cl = sr + 3 * NS;
-  int am = 0;
-  best = cl[0];
-  for (int j = 1; j < NC; ++j)
-    if (cl[j] > best) best = cl[j], am = j;
-  sem_cls[p] = am;
+    const float *ss = row + 5 + 2 * NH;
+    int sc = 0;
+    float best = ss[0];
+    for (int j = 1; j < NS; ++j)
+      if (ss[j] > best) best = ss[j], sc = j;
+    size_cls[p] = sc;
+    s_c[tid * 4 + 3] = __int_as_float(sc);
+    const float *cl = ss + 4 * NS;
+    int am = 0;
+    best = cl[0];
+    for (int j = 1; j < NC; ++j)
+      if (cl[j] > best) best = cl[j], am = j;
+    sem_cls[p] = am;
+  }
+  __syncthreads();
+  const float hs = (float)(M_PI / (double)NH);
+  const size_t p0 = (size_t)b * K + k0;
+  for (int i = tid; i < nk * NH; i += 256) hres[p0 * NH + i] = s_x[(i / NH) * LD + 5 + NH + i % NH] * hs;
+  const int S3 = 3 * NS, so = 5 + 2 * NH + NS;
+  for (int i = tid; i < nk * S3; i += 256) sres[p0 * S3 + i] = s_x[(i / S3) * LD + so + i % S3] * msa[i % S3];
   // utils/box_util.py:377-379 corner order (l on x, w on y, h on z); heading is 0 for this dataset configuration
-  const double sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sy[8] = {1, -1, -1, 1, 1, -1, -1, 1}, sz[8] = {1, 1, 1, 1, -1, -1, -1, -1};
-  double half[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) half[d] = ((msa64 ? msa64[3 * sc + d] : (double)msa[3 * sc + d]) + (double)mine[d]) / 2.0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    corners[(p * 8 + c) * 3 + 0] = (double)cen[0] + sx[c] * half[0];
-    corners[(p * 8 + c) * 3 + 1] = (double)cen[1] + sy[c] * half[1];
-    corners[(p * 8 + c) * 3 + 2] = (double)cen[2] + sz[c] * half[2];
+  for (int i = tid; i < nk * 24; i += 256) {
+    const int kk = i / 24, e = i % 24, c = e / 3, d = e % 3;
+    const int sc = __float_as_int(s_c[kk * 4 + 3]);
+    const float mine = s_x[kk * LD + so + 3 * sc + d] * msa[3 * sc + d];
+    const double half = ((msa64 ? msa64[3 * sc + d] : (double)msa[3 * sc + d]) + (double)mine) / 2.0;
+    const double sgn = d == 0 ? ((c & 3) < 2 ? 1.0 : -1.0) : d == 1 ? (((c & 3) == 0 || (c & 3) == 3) ? 1.0 : -1.0) : (c < 4 ? 1.0 : -1.0);
+    corners[p0 * 24 + i] = (double)s_c[kk * 4 + d] + sgn * half;
   }
 }
 
 // d net[b, c, k] = g_nt[b, k, c] (+ g_center on channels 2..4, + g_hres * pi / NH on the heading residuals, + g_sres * mean
 // size on the size residuals); every gradient pointer may be null
-__global__ __launch_bounds__(64) void proposal_decode_bwd_kernel(const float *__restrict__ g_nt, const float *__restrict__ g_center,
+__global__ __launch_bounds__(256) void proposal_decode_bwd_kernel(const float *__restrict__ g_nt, const float *__restrict__ g_center,
                                                                  const float *__restrict__ g_hres, const float *__restrict__ g_sres,
                                                                  const float *__restrict__ msa, int K, int NH, int NS, int NC,
                                                                  float *__restrict__ d_net) {
   extern __shared__ float s_x[];                         // [64][CH + 1]
-  const int b = blockIdx.y, k0 = blockIdx.x * 64, k = k0 + threadIdx.x;
+  const int b = blockIdx.y, k0 = blockIdx.x * 64;
   const int CH = 5 + 2 * NH + 4 * NS + NC, LD = CH + 1, nk = min(64, K - k0);
   const float hs = (float)(M_PI / (double)NH);
   const int s0 = 5 + 2 * NH + NS;
-  for (int i = threadIdx.x; i < nk * CH; i += 64) {      // proposal-major reads, coalesced
+  for (int i = threadIdx.x; i < nk * CH; i += 256) {     // proposal-major reads, coalesced
     const int kk = i / CH, c = i % CH;
     const size_t p = (size_t)b * K + k0 + kk;
     float v = g_nt ? g_nt[p * CH + c] : 0.f;
@@ -91,8 +95,10 @@ __global__ __launch_bounds__(64) void proposal_decode_bwd_kernel(const float *__
     s_x[kk * LD + c] = v;
   }
   __syncthreads();
-  if (k >= K) return;
-  for (int c = 0; c < CH; ++c) d_net[((size_t)b * CH + c) * K + k] = s_x[threadIdx.x * LD + c];
+  for (int i = threadIdx.x; i < CH * 64; i += 256) {     // channel-major stores, coalesced over the proposals
+    const int c = i >> 6, kk = i & 63;
+    if (kk < nk) d_net[((size_t)b * CH + c) * K + k0 + kk] = s_x[kk * LD + c];
+  }
 }
 
 }  // namespace
@@ -108,7 +114,7 @@ extern "C" int spacap_proposal_decode_fwd_f32(const float *net, const float *agg
                  "%s: null pointer", what);
   const int CH = 5 + 2 * NH + 4 * NS + NC;
   SPACAP_REQUIRE((size_t)64 * (CH + 1) * sizeof(float) <= 64 * 1024, "%s: too many channels (%d)", what, CH);
-  hipLaunchKernelGGL(proposal_decode_fwd_kernel, dim3((K + 63) / 64, B), dim3(64), (size_t)64 * (CH + 1) * sizeof(float),
+  hipLaunchKernelGGL(proposal_decode_fwd_kernel, dim3((K + 63) / 64, B), dim3(256), (size_t)(64 * (CH + 1) + 256) * sizeof(float),
                      spacap::as_stream(stream), net, agg_xyz, mean_size,
                      mean_size_f64, K, NH, NS, NC, nt, center, heading_res, size_res, corners, bbox_mask, sem_cls, size_cls);
   SPACAP_CHECK_LAUNCH(what);
@@ -124,7 +130,7 @@ extern "C" int spacap_proposal_decode_bwd_f32(const float *g_nt, const float *g_
   SPACAP_REQUIRE(mean_size && d_net, "%s: null pointer", what);
   const int CH = 5 + 2 * NH + 4 * NS + NC;
   SPACAP_REQUIRE((size_t)64 * (CH + 1) * sizeof(float) <= 64 * 1024, "%s: too many channels (%d)", what, CH);
-  hipLaunchKernelGGL(proposal_decode_bwd_kernel, dim3((K + 63) / 64, B), dim3(64), (size_t)64 * (CH + 1) * sizeof(float),
+  hipLaunchKernelGGL(proposal_decode_bwd_kernel, dim3((K + 63) / 64, B), dim3(256), (size_t)64 * (CH + 1) * sizeof(float),
                      spacap::as_stream(stream), g_nt, g_center,
                      g_heading_res, g_size_res, mean_size, K, NH, NS, NC, d_net);
   SPACAP_CHECK_LAUNCH(what);
