@@ -46,6 +46,7 @@ class HipBackend:
         self.ffn_tail = _lin.ffn_tail
         self.conv1x1 = _lin.conv1x1
         self.relation_tail = _lin.relation_tail
+        self.relation_head = _lin.relation_head
         from . import tf_layer as _tf
         self.tf_stack = _tf
         from . import sa_mlp as _sa

@@ -289,3 +289,58 @@ def relation_tail(hid1, lin2, lin3):
             tuple(lin3.weight.shape) != (9, 128) or lin2.bias is None or lin3.bias is None or hid1.shape[-1] != 128:
         return None
     return RelationTail.apply(hid1, lin2.weight, lin2.bias, lin3.weight, lin3.bias)
+
+
+class RelationHead(Function):
+    """The whole relation head (models/transformer_captioner.py:319-326, 392-397) as one kernel each way
+    (csrc/relation_fused.hip): pred = W3 relu(W2 relu(b1 + sum_h P U) + b2) + b3 on the B*K*K pairs, with
+    U[b,j,h,:] = V[b,h,j,:] W1[:, 16h:16h+16]^T formed by the caller.  Neither the pair feature nor the first hidden layer
+    nor any gradient of pair size exists in HBM: the forward stores hid2 (the backward's one large input) and pred; the
+    backward returns dP, the dU partials and per-workgroup partial sums of dW2, dW3, db1, db2, db3."""
+
+    @staticmethod
+    def forward(ctx, P, U, b1, W2, b2, W3, b3):
+        P, U, W2c, W3c = P.contiguous(), U.contiguous(), W2.contiguous(), W3.contiguous()
+        B, H, K, _ = P.shape
+        dev = P.device
+        with torch.cuda.device(dev):
+            hid2 = torch.empty(B, K, K, 128, dtype=torch.float32, device=dev)
+            pred = torch.empty(B, K, K, 9, dtype=torch.float32, device=dev)
+            check(lib.spacap_relation_fused_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), W2c.data_ptr(), b2.data_ptr(),
+                                                    W3c.data_ptr(), b3.data_ptr(), B, K, hid2.data_ptr(), pred.data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream), "spacap_relation_fused_fwd_f32")
+        ctx.save_for_backward(P, U, b1, W2c, W3c, hid2)
+        return pred
+
+    @staticmethod
+    def backward(ctx, g):
+        P, U, b1, W2, W3, hid2 = ctx.saved_tensors
+        B, H, K, _ = P.shape
+        dev = P.device
+        g = g.contiguous()
+        with torch.cuda.device(dev):
+            PW = int(lib.spacap_relation_fused_part_floats())
+            part = torch.empty(int(lib.spacap_relation_fused_nparts(B, K)), PW, dtype=torch.float32, device=dev)
+            dP = torch.empty_like(P)
+            dU = torch.empty(int(lib.spacap_relation_fused_zsplit(B, K)), *U.shape, dtype=torch.float32, device=dev)
+            check(lib.spacap_relation_fused_bwd_f32(g.data_ptr(), hid2.data_ptr(), P.data_ptr(), U.data_ptr(), b1.data_ptr(),
+                                                    W2.data_ptr(), W3.data_ptr(), B, K, dP.data_ptr(), dU.data_ptr(),
+                                                    part.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_relation_fused_bwd_f32")
+            s = sum_slabs(part, deferrable=True)
+        o = 128 * 128
+        dW2, dW3 = s[:o].view(128, 128), s[o:o + 9 * 128].view(9, 128)
+        o += 9 * 128
+        return dP, sum_slabs(dU), s[o:o + 128], dW2, s[o + 128:o + 256], dW3, s[o + 256:o + 265]
+
+
+def relation_head(P, V, lin1, lin2, lin3):
+    """``lin3(relu(lin2(relu(lin1(feature(P, V))))))`` -> (B,K,K,9) through ``RelationHead``; ``None`` when the shape has
+    no fused kernel (the caller composes relation_layer1 / relation_tail instead).  P (B,h,K,K), V (B,h,K,d)."""
+    B, H, K, D = V.shape
+    if not P.is_cuda or P.dtype != torch.float32 or lin1.bias is None or lin2.bias is None or lin3.bias is None or \
+            tuple(lin1.weight.shape) != (128, H * D) or tuple(lin2.weight.shape) != (128, 128) or \
+            not lib.spacap_relation_fused_supported(H, K, 128, lin3.weight.shape[0]) or lin3.weight.shape[1] != 128:
+        return None
+    U = torch.einsum("bhjd,ohd->bjho", V, lin1.weight.view(128, H, D))  # (B,K,H,C): tiny, autograd gives dV and dW1
+    return RelationHead.apply(P, U, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias)

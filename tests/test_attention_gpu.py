@@ -301,6 +301,7 @@ def test_relation_tail_matches_the_three_module_composition(shape):
     """linear.RelationTail (Linear(128,128) -> ReLU -> Linear(128,9) of the relation head, one forward kernel + one
     streaming backward kernel + two GEMMs) against float64 autograd of the nn.Module composition."""
     from spacap3d_amd.linear import relation_tail
+    torch.manual_seed(sum(shape))   # (the Linear initialisers draw from the global generator)
     g = torch.Generator().manual_seed(sum(shape))
     lin2, lin3 = torch.nn.Linear(128, 128), torch.nn.Linear(128, 9)
     hid1 = torch.relu(torch.randn(*shape, generator=g))
@@ -322,6 +323,51 @@ def test_relation_tail_matches_the_three_module_composition(shape):
         err = float((a.double().cpu() - b).abs().max()) / (float(b.abs().max()) + 1e-12)
         assert err < 3e-5, err
     assert relation_tail(hg, torch.nn.Linear(128, 64).to(DEV), torch.nn.Linear(64, 9).to(DEV)) is None
+
+
+@pytest.mark.parametrize("B,K", [(2, 64), (1, 8), (3, 40), (8, 256)])
+def test_relation_head_one_kernel_each_way(B, K):
+    """linear.RelationHead (csrc/relation_fused.hip: feature + Linear-ReLU-Linear-ReLU-Linear of the relation head without
+    any pair-sized intermediate but hid2) against float64 autograd of the reference composition
+    (models/transformer_captioner.py:319-326, 392-397), values and every gradient; and against the composed
+    relation_layer1 + relation_tail path it replaces."""
+    from spacap3d_amd.linear import relation_head
+    H, D = 8, 16
+    torch.manual_seed(B * 1000 + K)
+    g = torch.Generator().manual_seed(B * 1000 + K)
+    P = torch.softmax(torch.randn(B, H, K, K, generator=g), -1)
+    V = torch.randn(B, H, K, D, generator=g)
+    w = torch.randn(B, K, K, 9, generator=g)
+    lins = [torch.nn.Linear(128, 128), torch.nn.Linear(128, 128), torch.nn.Linear(128, 9)]
+    refs = [torch.nn.Linear(l.in_features, l.out_features).double() for l in lins]
+    for l, r in zip(lins, refs):
+        r.load_state_dict({k: v.double() for k, v in l.state_dict().items()})
+    Pr, Vr = P.double().requires_grad_(True), V.double().requires_grad_(True)
+    feat = (Pr.unsqueeze(-1) * Vr.unsqueeze(2)).permute(0, 2, 3, 1, 4).reshape(B, K, K, H * D)
+    want = refs[2](torch.relu(refs[1](torch.relu(refs[0](feat)))))
+    (want * w.double()).sum().backward()
+    lins = [l.to(DEV) for l in lins]
+    Pg, Vg = P.to(DEV).requires_grad_(True), V.to(DEV).requires_grad_(True)
+    got = relation_head(Pg, Vg, *lins)
+    assert got is not None and got.shape == want.shape
+    assert float((got.double().cpu() - want.detach()).abs().max()) < 3e-5
+    (got * w.to(DEV)).sum().backward()
+    pairs = [(Pg.grad, Pr.grad), (Vg.grad, Vr.grad)]
+    for l, r in zip(lins, refs):
+        pairs += [(l.weight.grad, r.weight.grad), (l.bias.grad, r.bias.grad)]
+    for n, (a, b) in enumerate(pairs):
+        d = (a.double().cpu() - b).abs() / (float(b.abs().max()) + 1e-12)
+        if B * K * K < 100000:
+            assert float(d.max()) < 5e-5, (n, float(d.max()))
+        else:
+            # 67 M hidden units: a handful sit within fp32 rounding of zero and their ReLU gates differ from the float64
+            # reference's.  One such pair row moves a few dP / dV entries by a percent and each parameter sum by one row's share
+            if n < 2:
+                assert float((d > 5e-5).double().mean()) < 5e-3 and float(d.max()) < 0.1, (n, float(d.max()))
+            else:
+                assert float(d.max()) < 5e-3, (n, float(d.max()))
+    assert relation_head(Pg[:, :, :K - 1, :K - 1], Vg[:, :, :K - 1], *lins) is None    # K not a multiple of 8
+    assert relation_head(Pg, Vg, lins[0], lins[1], torch.nn.Linear(128, 5).to(DEV)) is None
 
 
 @pytest.mark.parametrize("shape", [(8, 256, 128), (8, 32, 128), (3, 7, 300)])
