@@ -254,19 +254,23 @@ int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, const float *P
  * pair feature): hid1 = relu(b1 + sum_h P U) as above, hid2 = relu(hid1 W2^T + b2), pred = hid2 W3^T + b3, for H = 8,
  * C = 128, 9 outputs and K a multiple of 8 (spacap_relation_fused_supported).  hid1 is never stored; hid2 f32 [B,K,K,128]
  * is the backward's only large input.  W2 f32 [128,128] (out, in), W3 f32 [9,128], pred f32 [B,K,K,9].
- * Backward: dpred -> dP f32 [B,H,K,K]; dU f32 [spacap_relation_fused_zsplit(B,K), B,K,H,C] partial sums per query chunk;
- * part f32 [spacap_relation_fused_nparts(B,K), spacap_relation_fused_part_floats()] per-workgroup partial sums laid out
- * dW2 [128*128] | dW3 [9*128] | db1 [128] | db2 [128] | db3 [16, 9 used], which the caller adds up in order. */
+ * Each launch is one workgroup per CU not reserved by spacap_sa_reserve_cus, every workgroup with a contiguous range of
+ * (scene, key block, query block) tiles.
+ * Backward: dpred -> dP f32 [B,H,K,K]; part f32 [nparts, spacap_relation_fused_part_floats()] per-workgroup partial sums laid
+ * out dW2 [128*128] | dW3 [9*128] | db1 [128] | db2 [128] | db3 [16, 9 used]; dU f32 [zslots, B,K,H,C] partial sums (a key
+ * block's query range can straddle workgroups; unused slots are written as zeros).  The caller adds both up in order.
+ * nparts = spacap_relation_fused_nparts(B, K) (the grid; depends on the reserved CUs at the time of the call) and
+ * zslots = spacap_relation_fused_zsplit(B, K, nparts) are passed back in so that buffers and launch agree. */
 int spacap_relation_fused_supported(int H, int K, int C, int n_out);
-int spacap_relation_fused_zsplit(int B, int K);
 int spacap_relation_fused_nparts(int B, int K);
+int spacap_relation_fused_zsplit(int B, int K, int nparts);
 int spacap_relation_fused_part_floats(void);
 int spacap_relation_fused_fwd_f32(const float *P, const float *U, const float *b1, const float *W2, const float *b2,
                                   const float *W3, const float *b3, int B, int K, float *hid2, float *pred,
                                   spacap_stream_t stream);
 int spacap_relation_fused_bwd_f32(const float *dpred, const float *hid2, const float *P, const float *U, const float *b1,
-                                  const float *W2, const float *W3, int B, int K, float *dP, float *dU, float *part,
-                                  spacap_stream_t stream);
+                                  const float *W2, const float *W3, int B, int K, int nparts, int zslots, float *dP,
+                                  float *dU, float *part, spacap_stream_t stream);
 
 /* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
 

@@ -13,6 +13,11 @@ void set_error(const char *fmt, ...);
 
 inline hipStream_t as_stream(spacap_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// CUs a caller asked the persistent grids to leave to side-stream work (spacap_sa_reserve_cus), and the device's CU count
+// (both defined in sa_mlp.hip)
+int sa_reserved_cus();
+int device_cus();
+
 #define SPACAP_REQUIRE(cond, ...)          \
   do {                                     \
     if (!(cond)) {                         \

@@ -124,26 +124,19 @@ __device__ __forceinline__ void hid1_rows(const float (*uA)[4], const float *bA,
   }
 }
 
-__global__ __launch_bounds__(256) void rel_fused_fwd_kernel(const float *__restrict__ P, const float *__restrict__ U,
+__global__ __launch_bounds__(256) void rel_fused_fwd_kernel(const float *__restrict__ P, const float *__restrict__ Um,
                                                             const float *__restrict__ b1, const float *__restrict__ W2,
                                                             const float *__restrict__ b2, const float *__restrict__ W3,
-                                                            const float *__restrict__ b3, int K, float *__restrict__ hid2,
+                                                            const float *__restrict__ b3, int B, int K, float *__restrict__ hid2,
                                                             float *__restrict__ pred) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16 *s_a = reinterpret_cast<__bf16 *>(smem_raw);                       // hid1 pieces [3][64][LDB]
   float *s_pr = reinterpret_cast<float *>(smem_raw + 3 * IMG * 2);          // layer 3 partial sums [4 waves][64][DPL]
   float *s_p = s_pr + 4 * TR * DPL;                                         // [8][64]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.y, j0 = blockIdx.x * TJ;
-  const int ichunk = ((K / TI + gridDim.z - 1) / gridDim.z) * TI, ibeg = blockIdx.z * ichunk, iend = min(K, ibeg + ichunk);
-  if (ibeg >= iend) return;
-  float uA[8][4], bA[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) uA[n][ks] = U[(((size_t)b * K + j0 + 2 * w + (ks >> 1)) * H + 4 * (ks & 1) + lg) * C + 16 * n + l15];
-    bA[n] = lg == 0 ? b1[16 * n + l15] : 0.f;
-  }
+  // this workgroup's contiguous range of tile units (unit = (scene, key block, query block), query block fastest)
+  const int NI = K / TI, NJ = K / TJ;
+  const long U = (long)B * NJ * NI, u_beg = (long)blockIdx.x * U / gridDim.x, u_end = ((long)blockIdx.x + 1) * U / gridDim.x;
   // layer 2 weights of the wave's 32 output channels as pieces: wA[t][kc] = W2[32 w + 16 t + l15][32 kc + 8 lg .. + 7]
   bf16x8 wA[2][4][3];
   float w3r[2][4];
@@ -158,61 +151,73 @@ __global__ __launch_bounds__(256) void rel_fused_fwd_kernel(const float *__restr
     bb[t] = ld4(b2 + 32 * w + 16 * t + 4 * lg);
   }
   float pp[2];
-  p_tile_request(P, b, K, ibeg, j0, pp);
-  auto pred_out = [&](int i0) {   // the four waves' layer 3 partial sums + b3 -> pred, 8 runs (one per query) of 72 floats
+  for (long u = u_beg; u < u_end;) {
+    const int grp = (int)(u / NI), ib0 = (int)(u - (long)grp * NI), ibe = (int)min((long)NI, ib0 + (u_end - u));
+    const int b = grp / NJ, j0 = (grp - b * NJ) * TJ, ibeg = ib0 * TI, iend = ibe * TI;
+    u += ibe - ib0;
+    float uA[8][4], bA[8];
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int idx = tid + 256 * e, ii = idx / (TJ * NO), off = idx - ii * (TJ * NO), j = off / NO, o = off - j * NO;
-      if (idx < TR * NO) {
-        const float *q = s_pr + (j * TI + ii) * DPL + o;
-        pred[(((size_t)b * K + i0 + ii) * K + j0) * NO + off] = ((q[0] + q[TR * DPL]) + (q[2 * TR * DPL] + q[3 * TR * DPL])) + b3[o];
-      }
+    for (int n = 0; n < 8; ++n) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) uA[n][ks] = Um[(((size_t)b * K + j0 + 2 * w + (ks >> 1)) * H + 4 * (ks & 1) + lg) * C + 16 * n + l15];
+      bA[n] = lg == 0 ? b1[16 * n + l15] : 0.f;
     }
-  };
+    p_tile_request(P, b, K, ibeg, j0, pp);
+    auto pred_out = [&](int i0) {   // the four waves' layer 3 partial sums + b3 -> pred, 8 runs (one per query) of 72 floats
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int idx = tid + 256 * e, ii = idx / (TJ * NO), off = idx - ii * (TJ * NO), j = off / NO, o = off - j * NO;
+        if (idx < TR * NO) {
+          const float *q = s_pr + (j * TI + ii) * DPL + o;
+          pred[(((size_t)b * K + i0 + ii) * K + j0) * NO + off] = ((q[0] + q[TR * DPL]) + (q[2 * TR * DPL] + q[3 * TR * DPL])) + b3[o];
+        }
+      }
+    };
 
-  for (int i0 = ibeg; i0 < iend; i0 += TI) {
-    __syncthreads();   // the previous tile's readers of s_p / s_a and writers of s_pr are done
-    p_tile_store(pp, s_p);
-    if (i0 > ibeg) pred_out(i0 - TI);
-    if (i0 + TI < iend) p_tile_request(P, b, K, i0 + TI, j0, pp);
-    __syncthreads();
-    hid1_rows<false>(uA, bA, s_p, w, l15, lg, s_a);
-    __syncthreads();
+    for (int i0 = ibeg; i0 < iend; i0 += TI) {
+      __syncthreads();   // the previous tile's readers of s_p / s_a and writers of s_pr are done
+      p_tile_store(pp, s_p);
+      if (i0 > ibeg) pred_out(i0 - TI);
+      if (i0 + TI < iend) p_tile_request(P, b, K, i0 + TI, j0, pp);
+      __syncthreads();
+      hid1_rows<false>(uA, bA, s_p, w, l15, lg, s_a);
+      __syncthreads();
 #pragma unroll 2
-    for (int mt = 0; mt < TR / 16; ++mt) {
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      for (int mt = 0; mt < TR / 16; ++mt) {
+        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        bf16x8 a[3];
-        ld_pieces(s_a + (mt * 16 + l15) * LDB + 32 * kc + 8 * lg, IMG, a);
-        acc[0] = mfma6(wA[0][kc], a, acc[0]);
-        acc[1] = mfma6(wA[1][kc], a, acc[1]);
-      }
-      const int rr = mt * 16 + l15;
-      float *hrow = hid2 + pair_row(b, K, i0, j0, rr) * C + 32 * w + 4 * lg;
-      f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a3b = {0.f, 0.f, 0.f, 0.f};
+        for (int kc = 0; kc < 4; ++kc) {
+          bf16x8 a[3];
+          ld_pieces(s_a + (mt * 16 + l15) * LDB + 32 * kc + 8 * lg, IMG, a);
+          acc[0] = mfma6(wA[0][kc], a, acc[0]);
+          acc[1] = mfma6(wA[1][kc], a, acc[1]);
+        }
+        const int rr = mt * 16 + l15;
+        float *hrow = hid2 + pair_row(b, K, i0, j0, rr) * C + 32 * w + 4 * lg;
+        f32x4 a3 = {0.f, 0.f, 0.f, 0.f}, a3b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 h = relu4(acc[t] + bb[t]);
-        st4(hrow + 16 * t, h);
-        // layer 3 straight from the registers: k = the wave's channel 32 w + 16 t + 4 lg + uu
-        a3 = MFMA16(w3r[t][0], h[0], a3);
-        a3b = MFMA16(w3r[t][1], h[1], a3b);
-        a3 = MFMA16(w3r[t][2], h[2], a3);
-        a3b = MFMA16(w3r[t][3], h[3], a3b);
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 h = relu4(acc[t] + bb[t]);
+          st4(hrow + 16 * t, h);
+          // layer 3 straight from the registers: k = the wave's channel 32 w + 16 t + 4 lg + uu
+          a3 = MFMA16(w3r[t][0], h[0], a3);
+          a3b = MFMA16(w3r[t][1], h[1], a3b);
+          a3 = MFMA16(w3r[t][2], h[2], a3);
+          a3b = MFMA16(w3r[t][3], h[3], a3b);
+        }
+        if (lg < 3) st4(&s_pr[(w * TR + rr) * DPL + 4 * lg], a3 + a3b);
       }
-      if (lg < 3) st4(&s_pr[(w * TR + rr) * DPL + 4 * lg], a3 + a3b);
     }
+    __syncthreads();
+    pred_out(iend - TI);
   }
-  __syncthreads();
-  pred_out(iend - TI);
 }
 
 __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restrict__ dpred, const float *__restrict__ hid2,
                                                             const float *__restrict__ P, const float *__restrict__ U,
                                                             const float *__restrict__ b1, const float *__restrict__ W2,
-                                                            const float *__restrict__ W3, int K, float *__restrict__ dP,
-                                                            float *__restrict__ dU, float *__restrict__ part) {
+                                                            const float *__restrict__ W3, int B, int K, int Z,
+                                                            float *__restrict__ dP, float *__restrict__ dU, float *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16 *s_h1T = reinterpret_cast<__bf16 *>(smem_raw);                  // hid1 pieces, channel-major [3][128][LDR]
   __bf16 *s_zT = s_h1T + 3 * IMGT;                                       // dz2 pieces, channel-major; the same bytes later
@@ -221,20 +226,16 @@ __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restr
   float *s_p = s_x + TR * LDT, *s_dp = s_p + H * TR;                     // [8][64], [64][DPL]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
   const int jj = tid >> 5, c4 = tid & 31;
-  const int b = blockIdx.y, j0 = blockIdx.x * TJ;
-  const int ichunk = ((K / TI + gridDim.z - 1) / gridDim.z) * TI, ibeg = blockIdx.z * ichunk, iend = min(K, ibeg + ichunk);
+  // this workgroup's contiguous range of tile units (unit = (scene, key block, query block), query block fastest)
+  const int NI = K / TI, NJ = K / TJ;
+  const long NU = (long)B * NJ * NI, u_beg = (long)blockIdx.x * NU / gridDim.x, u_end = ((long)blockIdx.x + 1) * NU / gridDim.x;
   // ---- operands that stay in registers for the whole launch ------------------------------------------------------------
-  float uA[8][4], bA[8], w3A[8][3];
-  f32x4 uP[8];
+  float bA[8], w3A[8][3];
 #pragma unroll
   for (int n = 0; n < 8; ++n) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) uA[n][ks] = U[(((size_t)b * K + j0 + 2 * w + (ks >> 1)) * H + 4 * (ks & 1) + lg) * C + 16 * n + l15];
     bA[n] = lg == 0 ? b1[16 * n + l15] : 0.f;
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) w3A[n][ks] = 4 * ks + lg < NO ? W3[(4 * ks + lg) * C + 16 * n + l15] : 0.f;
-    // dP: row (key column l15 >> 3, head l15 & 7) of U, contraction over the channels
-    uP[n] = ld4(U + (((size_t)b * K + j0 + 2 * w + (l15 >> 3)) * H + (l15 & 7)) * C + 16 * n + 4 * lg);
   }
   // dhid1 = dz2 W2 for the wave's 32 INPUT channels: wA[t][kc] = W2[32 kc + 8 lg .. + 7][32 w + 16 t + l15] as pieces
   bf16x8 wA[2][4][3];
@@ -247,20 +248,33 @@ __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restr
     }
   const bf16x8 ones = {(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
   // ---- running sums ----------------------------------------------------------------------------------------------------
-  f32x4 gw[2][8], gb2[2], g3[2], d1[2], gb3 = {0.f, 0.f, 0.f, 0.f}, du[8];
+  f32x4 gw[2][8], gb2[2], g3[2], d1[2], gb3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     gb2[t] = g3[t] = d1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 8; ++n) gw[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-#pragma unroll
-  for (int n = 0; n < 8; ++n) du[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int idx = tid; idx < TR * DPL; idx += 256) s_dp[idx] = 0.f;   // (the three pad columns stay zero)
 
   // ---- the next tile's inputs travel while the current one is worked on -------------------------------------------------
   f32x4 hp[TI];
   float pp[2], dq[3];
+  for (long u = u_beg; u < u_end;) {
+  // ---- one key block (8 key columns of one scene): the stretch of its query blocks that falls into this workgroup's range --
+  const int grp = (int)(u / NI), ib0 = (int)(u - (long)grp * NI), ibe = (int)min((long)NI, ib0 + (u_end - u));
+  const int b = grp / NJ, j0 = (grp - b * NJ) * TJ, ibeg = ib0 * TI, iend = ibe * TI;
+  u += ibe - ib0;
+  float uA[8][4];
+  f32x4 uP[8], du[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) uA[n][ks] = U[(((size_t)b * K + j0 + 2 * w + (ks >> 1)) * H + 4 * (ks & 1) + lg) * C + 16 * n + l15];
+    // dP: row (key column l15 >> 3, head l15 & 7) of U, contraction over the channels
+    uP[n] = ld4(U + (((size_t)b * K + j0 + 2 * w + (l15 >> 3)) * H + (l15 & 7)) * C + 16 * n + 4 * lg);
+    du[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   auto request = [&](int i0) {
     p_tile_request(P, b, K, i0, j0, pp);
 #pragma unroll
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restr
 #pragma unroll
     for (int ii = 0; ii < TI; ++ii) hp[ii] = ld4(hid2 + pair_row(b, K, i0, j0, jj * TI + ii) * C + 4 * c4);
   };
-  if (ibeg < iend) request(ibeg);
+  request(ibeg);
 
   for (int i0 = ibeg; i0 < iend; i0 += TI) {
     __syncthreads();   // the previous tile's readers of every LDS buffer are done
@@ -395,15 +409,26 @@ __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restr
       }
     }
   }
-  // ---- results of the whole launch --------------------------------------------------------------------------------------
-  {   // du[n][uu] = dU[key column 2 w + (lg >> 1), head 4 (lg & 1) + uu, channel 16 n + l15]
-    float *duo = dU + (size_t)blockIdx.z * gridDim.y * K * H * C + (((size_t)b * K + j0 + 2 * w + (lg >> 1)) * H + 4 * (lg & 1)) * C + l15;
+  {   // this stretch's share of dU: du[n][uu] = dU[key column 2 w + (lg >> 1), head 4 (lg & 1) + uu, channel 16 n + l15].
+      // Slot = position of this workgroup among those that share the key block; the one that ends it clears the unused slots.
+    const long first = ((long)grp * NI + 1) * gridDim.x;
+    const int slot = (int)(blockIdx.x - ((first + NU - 1) / NU - 1));
+    const size_t slab = (size_t)B * K * H * C;
+    float *duo = dU + (size_t)slot * slab + (((size_t)b * K + j0 + 2 * w + (lg >> 1)) * H + 4 * (lg & 1)) * C + l15;
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll
       for (int uu = 0; uu < 4; ++uu) duo[uu * C + 16 * n] = du[n][uu];
+    if (ibe == NI)
+      for (int z = slot + 1; z < Z; ++z)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+          for (int uu = 0; uu < 4; ++uu) duo[(size_t)(z - slot) * slab + uu * C + 16 * n] = 0.f;
   }
-  float *po = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * PART;
+  }
+  // ---- results of the whole launch --------------------------------------------------------------------------------------
+  float *po = part + (size_t)blockIdx.x * PART;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -435,10 +460,22 @@ __global__ __launch_bounds__(256) void rel_fused_bwd_kernel(const float *__restr
 constexpr size_t FWD_LDS = (size_t)3 * IMG * 2 + (size_t)(4 * TR * DPL + H * TR) * sizeof(float);
 constexpr size_t BWD_LDS = (size_t)2 * 3 * IMGT * 2 + (size_t)(TR * LDT + H * TR + TR * DPL) * sizeof(float);
 
-inline int zsplit(int B, int K) {   // query chunks per key block: enough workgroups to fill the chip
-  const int wgs = B * (K / TJ);
+// Grid: one workgroup per CU the caller has not reserved for side-stream work (spacap_sa_reserve_cus), each with a contiguous
+// range of tile units.  A grid sized to ALL CUs would leave its last workgroups waiting behind the sampling chain's (one
+// scene per CU for the first half of the step) and run them as a second round: twice the time.
+inline int grid_size(int B, int K, int per_cu) {
+  const long units = (long)B * (K / TJ) * (K / TI);
+  const long g = (long)per_cu * std::max(1, spacap::device_cus() - spacap::sa_reserved_cus());
+  return (int)std::min(units, g);
+}
+// dU slots: the largest number of workgroups whose ranges meet one key block
+inline int du_slots(int B, int K, int G) {
+  const long NI = K / TI, NU = (long)B * (K / TJ) * NI;
   int z = 1;
-  while (wgs * z < 256 && z * 2 * TI <= K) z *= 2;
+  for (long g = 0; g < (long)B * (K / TJ); ++g) {
+    const long wf = ((g * NI + 1) * G + NU - 1) / NU - 1, wl = (((g + 1) * NI) * G + NU - 1) / NU - 1;
+    z = std::max(z, (int)(wl - wf + 1));
+  }
   return z;
 }
 
@@ -447,8 +484,8 @@ inline int zsplit(int B, int K) {   // query chunks per key block: enough workgr
 extern "C" int spacap_relation_fused_supported(int H_, int K, int C_, int NO_) {
   return H_ == H && C_ == C && NO_ == NO && K >= 8 && K % 8 == 0;
 }
-extern "C" int spacap_relation_fused_zsplit(int B, int K) { return zsplit(B, K); }
-extern "C" int spacap_relation_fused_nparts(int B, int K) { return zsplit(B, K) * B * (K / TJ); }
+extern "C" int spacap_relation_fused_nparts(int B, int K) { return B > 0 && K >= 8 ? grid_size(B, K, 1) : 0; }
+extern "C" int spacap_relation_fused_zsplit(int B, int K, int nparts) { return B > 0 && K >= 8 && nparts > 0 ? du_slots(B, K, nparts) : 0; }
 extern "C" int spacap_relation_fused_part_floats(void) { return PART; }
 
 extern "C" int spacap_relation_fused_fwd_f32(const float *P, const float *U, const float *b1, const float *W2, const float *b2,
@@ -464,17 +501,16 @@ extern "C" int spacap_relation_fused_fwd_f32(const float *P, const float *U, con
     return true;
   }();
   (void)attr;
-  int z = zsplit(B, K) * 2;   // (two workgroups per CU overlap each other's phases)
-  if (z * TI > K) z = K / TI;
-  hipLaunchKernelGGL(rel_fused_fwd_kernel, dim3(K / TJ, B, z), dim3(256), FWD_LDS, spacap::as_stream(stream), P, U, b1, W2, b2, W3, b3, K,
-                     hid2, pred);
+  // (two workgroups per CU overlap each other's phases)
+  hipLaunchKernelGGL(rel_fused_fwd_kernel, dim3(grid_size(B, K, 2)), dim3(256), FWD_LDS, spacap::as_stream(stream), P, U, b1, W2, b2, W3,
+                     b3, B, K, hid2, pred);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
 
 extern "C" int spacap_relation_fused_bwd_f32(const float *dpred, const float *hid2, const float *P, const float *U, const float *b1,
-                                             const float *W2, const float *W3, int B, int K, float *dP, float *dU, float *part,
-                                             spacap_stream_t stream) {
+                                             const float *W2, const float *W3, int B, int K, int nparts, int zslots, float *dP,
+                                             float *dU, float *part, spacap_stream_t stream) {
   const char *what = "spacap_relation_fused_bwd_f32";
   SPACAP_REQUIRE(B >= 0 && K >= 8 && K % 8 == 0 && B <= 65535, "%s: (B=%d, K=%d) unsupported", what, B, K);
   if (B == 0) return SPACAP_OK;
@@ -485,8 +521,10 @@ extern "C" int spacap_relation_fused_bwd_f32(const float *dpred, const float *hi
     return true;
   }();
   (void)attr;
-  hipLaunchKernelGGL(rel_fused_bwd_kernel, dim3(K / TJ, B, zsplit(B, K)), dim3(256), BWD_LDS, spacap::as_stream(stream), dpred, hid2,
-                     P, U, b1, W2, W3, K, dP, dU, part);
+  SPACAP_REQUIRE(nparts >= 1 && nparts <= B * (K / TJ) * (K / TI) && zslots >= du_slots(B, K, nparts),
+                 "%s: (nparts=%d, zslots=%d) do not fit (B=%d, K=%d)", what, nparts, zslots, B, K);
+  hipLaunchKernelGGL(rel_fused_bwd_kernel, dim3(nparts), dim3(256), BWD_LDS, spacap::as_stream(stream), dpred, hid2, P, U, b1, W2, W3, B, K,
+                     zslots, dP, dU, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

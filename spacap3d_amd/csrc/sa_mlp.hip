@@ -1218,6 +1218,11 @@ extern "C" int spacap_gemm_rows_f32(const float *x, const float *W, long R, int 
   return SPACAP_OK;
 }
 
+namespace spacap {
+int sa_reserved_cus() { return reserved_cus(); }
+int device_cus() { return ::device_cus(); }
+}  // namespace spacap
+
 /* n CUs are left free by the forward layer kernels' persistent grids (0 <= n <= 64): set by a caller that runs other work
    (the next batch's sampling chain) beside the forward pass. */
 extern "C" int spacap_sa_reserve_cus(int n) {

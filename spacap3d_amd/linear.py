@@ -320,11 +320,13 @@ class RelationHead(Function):
         g = g.contiguous()
         with torch.cuda.device(dev):
             PW = int(lib.spacap_relation_fused_part_floats())
-            part = torch.empty(int(lib.spacap_relation_fused_nparts(B, K)), PW, dtype=torch.float32, device=dev)
+            nparts = int(lib.spacap_relation_fused_nparts(B, K))
+            zslots = int(lib.spacap_relation_fused_zsplit(B, K, nparts))
+            part = torch.empty(nparts, PW, dtype=torch.float32, device=dev)
             dP = torch.empty_like(P)
-            dU = torch.empty(int(lib.spacap_relation_fused_zsplit(B, K)), *U.shape, dtype=torch.float32, device=dev)
+            dU = torch.empty(zslots, *U.shape, dtype=torch.float32, device=dev)
             check(lib.spacap_relation_fused_bwd_f32(g.data_ptr(), hid2.data_ptr(), P.data_ptr(), U.data_ptr(), b1.data_ptr(),
-                                                    W2.data_ptr(), W3.data_ptr(), B, K, dP.data_ptr(), dU.data_ptr(),
+                                                    W2.data_ptr(), W3.data_ptr(), B, K, nparts, zslots, dP.data_ptr(), dU.data_ptr(),
                                                     part.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
                   "spacap_relation_fused_bwd_f32")
             s = sum_slabs(part, deferrable=True)

@@ -30,6 +30,8 @@ def t(fn, what, flops=None, bytes_=None):
 
 
 def main():
+    if len(sys.argv) > 2:
+        check(lib.spacap_sa_reserve_cus(int(sys.argv[2])), "reserve")   # as beside the sampling chain
     B, K, H, D = 8, 256, 8, 16
     r = lambda *s: torch.randn(*s, device=DEV)
     P, U = torch.softmax(r(B, H, K, K), -1), r(B, K, H, 128) * 0.3
@@ -41,10 +43,13 @@ def main():
     t(lambda: check(lib.spacap_relation_fused_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(),
                                                       b3.data_ptr(), B, K, hid2.data_ptr(), pred.data_ptr(), st), "f"),
       "fused forward", ffwd, R * (128 + 9 + 8) * 4.0)
-    dP, dU = torch.empty_like(P), torch.empty(int(lib.spacap_relation_fused_zsplit(B, K)), B, K, H, 128, device=DEV)
-    part = torch.empty(int(lib.spacap_relation_fused_nparts(B, K)), int(lib.spacap_relation_fused_part_floats()), device=DEV)
+    nparts = int(lib.spacap_relation_fused_nparts(B, K))
+    zs = int(lib.spacap_relation_fused_zsplit(B, K, nparts))
+    dP, dU = torch.empty_like(P), torch.empty(zs, B, K, H, 128, device=DEV)
+    part = torch.empty(nparts, int(lib.spacap_relation_fused_part_floats()), device=DEV)
     t(lambda: check(lib.spacap_relation_fused_bwd_f32(dpred.data_ptr(), hid2.data_ptr(), P.data_ptr(), U.data_ptr(), b1.data_ptr(),
-                                                      W2.data_ptr(), W3.data_ptr(), B, K, dP.data_ptr(), dU.data_ptr(), part.data_ptr(), st), "b"),
+                                                      W2.data_ptr(), W3.data_ptr(), B, K, nparts, zs, dP.data_ptr(), dU.data_ptr(),
+                                                      part.data_ptr(), st), "b"),
       "fused backward", R * (2.0 * 8 * 128 * 3 + 4.0 * 128 * 128 + 4.0 * 128 * 9), R * (128 + 9 + 16) * 4.0)
     V = r(B, H, K, D)
     lins = [torch.nn.Linear(128, 128).to(DEV), torch.nn.Linear(128, 128).to(DEV), torch.nn.Linear(128, 9).to(DEV)]

@@ -60,7 +60,7 @@ def main():
         print(f"   idle {v / 1e3 / K:7.1f} us/step between  {a}  ->  {b}")
     print("ms/step,calls/step,avg_us,kernel")
     for n, v in tot.most_common(top):
-        print(f"{v / 1e6 / K:.3f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},{n[:150]}")
+        print(f"{v / 1e6 / K:.3f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},\"{n[:150]}\"")
 
 
 if __name__ == "__main__":
