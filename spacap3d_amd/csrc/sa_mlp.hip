@@ -920,6 +920,85 @@ __global__ __launch_bounds__(256) void rows_offsets_kernel(const unsigned *__res
   off[k] = (int)lo;
 }
 
+// The same index without a sort, one launch: a workgroup of 16 waves per scene.  Wave w owns the w-th stretch of the scene's
+// rows.  (1) per-wave histograms h[w][p] (16-bit counters, two per LDS word), (2) per point: counts -> exclusive prefix over the
+// waves, totals -> exclusive scan over the points = off, (3) every wave walks its stretch in order, 64 rows at a time; a row's
+// slot is off[p] + rows of p in earlier waves + in earlier iterations of this wave + in lower lanes of this iteration (one
+// ballot per distinct point among the 64 rows).  Ascending row order within a point by construction: the result equals the
+// stable sort's.  Np <= 4096, E <= 65535 (LDS, 16-bit counters); other shapes take the radix sort below.
+constexpr int RI_WAVES = 16;
+__global__ __launch_bounds__(1024) void rows_index_kernel(const int32_t *__restrict__ idx, int Np, int E, int B,
+                                                          int *__restrict__ off, int *__restrict__ order) {
+  extern __shared__ unsigned s_ri[];
+  const int NpW = (Np + 1) / 2;
+  unsigned *h = s_ri;                                        // [16][NpW]
+  int *start = reinterpret_cast<int *>(h + RI_WAVES * NpW);  // [2 NpW]
+  int *wsum = start + 2 * NpW;                               // [1024]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.x;
+  const int32_t *ib = idx + (size_t)b * E;
+  const int seg = ((E + RI_WAVES * 64 - 1) / (RI_WAVES * 64)) * 64, e_beg = w * seg, e_end = min(E, e_beg + seg);
+  for (int i = tid; i < RI_WAVES * NpW; i += 1024) h[i] = 0u;
+  __syncthreads();
+  for (int e = e_beg + lane; e < e_end; e += 64) {
+    const int p = ib[e];
+    atomicAdd(&h[w * NpW + (p >> 1)], 1u << (16 * (p & 1)));
+  }
+  __syncthreads();
+  for (int q = tid; q < NpW; q += 1024) {   // one word = two points: counts -> prefix over the waves, totals -> start
+    unsigned a0 = 0, a1 = 0;
+    for (int v = 0; v < RI_WAVES; ++v) {
+      const unsigned c = h[v * NpW + q];
+      h[v * NpW + q] = a0 | (a1 << 16);
+      a0 += c & 0xffffu, a1 += c >> 16;
+    }
+    start[2 * q] = (int)a0, start[2 * q + 1] = (int)a1;
+  }
+  __syncthreads();
+  {   // exclusive scan of start[0 .. 2 NpW): CH consecutive entries per thread, then the 1024 partial sums
+    const int CH = (2 * NpW + 1023) / 1024, lo = min(tid * CH, 2 * NpW), hi = min(lo + CH, 2 * NpW);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += start[i];
+    wsum[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = tid >= d ? wsum[tid - d] : 0;
+      __syncthreads();
+      wsum[tid] += v;
+      __syncthreads();
+    }
+    int run = wsum[tid] - sum;
+    for (int i = lo; i < hi; ++i) {
+      const int c = start[i];
+      start[i] = run;
+      if (i < Np) off[(size_t)b * Np + i] = b * E + run;
+      run += c;
+    }
+    if (b == B - 1 && tid == 0) off[(size_t)B * Np] = B * E;
+  }
+  __syncthreads();
+  for (int e0 = e_beg; e0 < e_end; e0 += 64) {
+    const int e = e0 + lane;
+    const bool active = e < e_end;
+    const int p = active ? ib[e] : -1;
+    unsigned long long todo = __ballot(active);
+    int rank = 0, n = 0;
+    bool lead = false;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k = __builtin_amdgcn_readlane(p, leader);
+      const unsigned long long m = __ballot(p == k);
+      if (p == k) rank = __popcll(m & ((1ull << lane) - 1ull)), n = __popcll(m), lead = lane == leader;
+      todo &= ~m;
+    }
+    if (active) {
+      const unsigned word = h[w * NpW + (p >> 1)];
+      const int pos = start[p] + (int)((word >> (16 * (p & 1))) & 0xffffu) + rank;
+      order[(size_t)b * E + pos] = b * E + e;
+    }
+    if (lead) atomicAdd(&h[w * NpW + (p >> 1)], (unsigned)n << (16 * (p & 1)));
+  }
+}
+
 __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float *__restrict__ dz, const int *__restrict__ off,
                                                               const int *__restrict__ order, long K, int C,
                                                               float *__restrict__ out) {
@@ -1425,6 +1504,17 @@ extern "C" int spacap_sa_rows_index_f32(const int32_t *idx, int B, int Np, long 
   unsigned *keys_in = reinterpret_cast<unsigned *>(ws + L.keys_in), *keys_out = reinterpret_cast<unsigned *>(ws + L.keys_out);
   int *vals_in = reinterpret_cast<int *>(ws + L.vals_in), *vals_out = reinterpret_cast<int *>(ws + L.vals_out);
   int *off = reinterpret_cast<int *>(ws + L.off);
+  if (Np <= 4096 && E <= 65535 && B <= 65535) {   // one launch, no sort
+    const size_t lds = (size_t)(RI_WAVES * ((Np + 1) / 2) + 2 * ((Np + 1) / 2) + 1024) * 4;
+    static const bool attr = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rows_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return true;
+    }();
+    (void)attr;
+    hipLaunchKernelGGL(rows_index_kernel, dim3(B), dim3(1024), lds, s, idx, Np, (int)E, B, off, vals_out);
+    SPACAP_CHECK_LAUNCH(what);
+    return SPACAP_OK;
+  }
   hipLaunchKernelGGL(rows_keys_kernel, dim3(nblocks((long)L.total, 256)), dim3(256), 0, s, idx, Np, E, (long)L.total, keys_in, vals_in);
   size_t cub_bytes = L.cub_bytes;
   SPACAP_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(ws + L.cub, cub_bytes, keys_in, keys_out, vals_in, vals_out,

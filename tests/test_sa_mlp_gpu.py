@@ -164,6 +164,31 @@ def test_prebuilt_inverted_index_gives_the_same_feature_gradient():
         assert torch.equal(la.conv.weight.grad, lb.conv.weight.grad)
 
 
+@pytest.mark.parametrize("B,Np,E", [(3, 1000, 8192), (2, 4096, 65535), (1, 1, 100), (8, 2048, 32768), (2, 37, 64),
+                                    (2, 5000, 4096), (1, 300, 70000)])
+def test_rows_scatter_sums_in_ascending_row_order(B, Np, E):
+    """spacap_sa_rows_scatter_f32 (inverted index of a grouping + ordered gather-sum; the one-launch counting kernel for
+    Np <= 4096 and E <= 65535, the radix sort otherwise) against numpy's sequential ``np.add.at``: bit-identical fp32 sums,
+    i.e. every point's rows are visited in ascending order.  Groupings with long runs of one index (ball query pads with the
+    first neighbour) and with every row on one point included."""
+    from spacap3d_amd._native import check, lib
+    g = torch.Generator().manual_seed(B * 7 + Np + E)
+    idx = torch.randint(0, Np, (B, E), generator=g, dtype=torch.int32)
+    run = torch.randint(0, Np, (B, (E + 31) // 32), generator=g, dtype=torch.int32).repeat_interleave(32, 1)[:, :E]
+    idx = torch.where(torch.rand(B, E, generator=g) < 0.5, run, idx)      # padded groups: runs of one index
+    C = 8
+    dz = torch.randn(B * E, C, generator=g)
+    want = np.zeros((B * Np, C), np.float32)
+    keys = (idx.long() + torch.arange(B).view(B, 1) * Np).reshape(-1).numpy()
+    np.add.at(want, keys, dz.numpy())
+    out = torch.empty(B, Np, C, device=DEV)
+    ws = torch.empty(int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, E)), dtype=torch.uint8, device=DEV)
+    idx_d, dz_d = idx.to(DEV), dz.to(DEV)
+    check(lib.spacap_sa_rows_scatter_f32(dz_d.data_ptr(), idx_d.data_ptr(), B, Np, E, C, out.data_ptr(), ws.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "spacap_sa_rows_scatter_f32")
+    assert np.array_equal(out.cpu().numpy().reshape(B * Np, C), want)
+
+
 def test_unsupported_mlp_uses_the_per_operator_path():
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
     from spacap3d_amd import sa_mlp
