@@ -118,6 +118,13 @@ int spacap_group_max_grad_f32(const float *grad_out, const uint8_t *arg, long ro
  * (src/interpolate.cpp:14-40).  dist2 is SQUARED distance as in the reference. */
 int spacap_three_nn_f32(const float *unknown, const float *known, int B, int n, int m,
                         float *dist2, int32_t *idx, spacap_stream_t stream);
+/* The same search returning the feature-propagation modules' interpolation weights instead of the squared distances
+ * (pointnet2_modules.py:399-405: dist = sqrt(dist2); r = 1 / (dist + 1e-8); weight = r / (r0 + r1 + r2)), weight f32 [B,n,3]. */
+int spacap_three_nn_weights_f32(const float *unknown, const float *known, int B, int n, int m,
+                                float *weight, int32_t *idx, spacap_stream_t stream);
+/* out[b, j, :] = xyz[b, idx[b, j], :]: the sampled centres of a set-abstraction level (pointnet2_modules.py:232-239's
+ * gather_operation on the flipped coordinates); xyz f32 [B,N,3], idx i32 [B,m] in [0,N), out f32 [B,m,3]. */
+int spacap_gather_xyz_f32(const float *xyz, const int32_t *idx, int B, int N, int m, float *out, spacap_stream_t stream);
 /* three_interpolate(points f32[B,C,m], idx i32[B,n,3], weight f32[B,n,3]) -> f32[B,C,n]
  * (src/interpolate.cpp:42-70) */
 int spacap_three_interpolate_f32(const float *points, const int32_t *idx, const float *weight,

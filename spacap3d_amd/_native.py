@@ -42,6 +42,8 @@ SIGNATURES = {
     "spacap_group_max_f32": (_i, [_p, _l, _i, _p, _p, _p]),
     "spacap_group_max_grad_f32": (_i, [_p, _p, _l, _i, _p, _p]),
     "spacap_three_nn_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "spacap_three_nn_weights_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "spacap_gather_xyz_f32": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_grad_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_three_interpolate_grad_pm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -22,6 +22,10 @@
 
 namespace {
 
+// WEIGHTS: instead of the squared distances, the normalised inverse distances of the feature-propagation modules
+// (pointnet2_modules.py:399-405: dist = sqrt(dist2), r = 1 / (dist + 1e-8), w = r / (r0 + r1 + r2)), each operation rounded
+// as the reference's separate tensor operations round it.
+template <bool WEIGHTS>
 __global__ __launch_bounds__(64) void three_nn_kernel(const float *__restrict__ unknown_all,
                                                       const float *__restrict__ known_all, int n, int m,
                                                       float *__restrict__ dist2_all,
@@ -51,9 +55,25 @@ __global__ __launch_bounds__(64) void three_nn_kernel(const float *__restrict__ 
   if (j < n) {
     float *__restrict__ dd = dist2_all + ((size_t)b * n + j) * 3;
     int32_t *__restrict__ ii = idx_all + ((size_t)b * n + j) * 3;
-    dd[0] = best1; dd[1] = best2; dd[2] = best3;
+    if (WEIGHTS) {
+      const float r1 = 1.0f / (sqrtf(best1) + 1e-8f), r2 = 1.0f / (sqrtf(best2) + 1e-8f), r3 = 1.0f / (sqrtf(best3) + 1e-8f);
+      const float norm = (r1 + r3) + r2;   // the order torch.sum(dim=2) of a (B, n, 3) tensor adds in (four strided accumulators)
+      dd[0] = r1 / norm; dd[1] = r2 / norm; dd[2] = r3 / norm;
+    } else {
+      dd[0] = best1; dd[1] = best2; dd[2] = best3;
+    }
     ii[0] = besti1; ii[1] = besti2; ii[2] = besti3;
   }
+}
+
+// out[b, j, :] = xyz[b, idx[b, j], :] (the sampled centres of a set-abstraction level)
+__global__ __launch_bounds__(256) void gather_xyz_kernel(const float *__restrict__ xyz, const int32_t *__restrict__ idx, int N, int m,
+                                                         long total, float *__restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long b = i / m;
+  const float *p = xyz + ((size_t)b * N + idx[i]) * 3;
+  out[i * 3 + 0] = p[0], out[i * 3 + 1] = p[1], out[i * 3 + 2] = p[2];
 }
 
 constexpr int CHUNK = 8;
@@ -228,16 +248,38 @@ extern "C" int spacap_three_interpolate_grad_pm_f32(const float *grad_pm, const 
   return SPACAP_OK;
 }
 
+static int three_nn_launch(const char *what, bool weights, const float *unknown, const float *known, int B, int n, int m, float *out,
+                           int32_t *idx, spacap_stream_t stream) {
+  SPACAP_REQUIRE(B >= 0 && n >= 0 && m >= 0, "%s: bad sizes", what);
+  if (B == 0 || n == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(unknown && out && idx && (known || m == 0), "%s: null pointer", what);
+  SPACAP_REQUIRE(B <= 65535, "%s: B out of range", what);
+  dim3 grid((n + 63) / 64, B);
+  if (weights) hipLaunchKernelGGL(three_nn_kernel<true>, grid, dim3(64), 0, spacap::as_stream(stream), unknown, known, n, m, out, idx);
+  else hipLaunchKernelGGL(three_nn_kernel<false>, grid, dim3(64), 0, spacap::as_stream(stream), unknown, known, n, m, out, idx);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 extern "C" int spacap_three_nn_f32(const float *unknown, const float *known, int B, int n, int m,
                                    float *dist2, int32_t *idx, spacap_stream_t stream) {
-  SPACAP_REQUIRE(B >= 0 && n >= 0 && m >= 0, "spacap_three_nn_f32: bad sizes");
-  if (B == 0 || n == 0) return SPACAP_OK;
-  SPACAP_REQUIRE(unknown && dist2 && idx && (known || m == 0), "spacap_three_nn_f32: null pointer");
-  SPACAP_REQUIRE(B <= 65535, "spacap_three_nn_f32: B out of range");
-  dim3 grid((n + 63) / 64, B);
-  hipLaunchKernelGGL(three_nn_kernel, grid, dim3(64), 0, spacap::as_stream(stream), unknown, known, n, m,
-                     dist2, idx);
-  SPACAP_CHECK_LAUNCH("spacap_three_nn_f32");
+  return three_nn_launch("spacap_three_nn_f32", false, unknown, known, B, n, m, dist2, idx, stream);
+}
+
+extern "C" int spacap_three_nn_weights_f32(const float *unknown, const float *known, int B, int n, int m,
+                                           float *weight, int32_t *idx, spacap_stream_t stream) {
+  return three_nn_launch("spacap_three_nn_weights_f32", true, unknown, known, B, n, m, weight, idx, stream);
+}
+
+extern "C" int spacap_gather_xyz_f32(const float *xyz, const int32_t *idx, int B, int N, int m, float *out, spacap_stream_t stream) {
+  const char *what = "spacap_gather_xyz_f32";
+  SPACAP_REQUIRE(B >= 0 && N >= 0 && m >= 0, "%s: bad sizes", what);
+  const long total = (long)B * m;
+  if (total == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(xyz && idx && out && N > 0, "%s: null pointer", what);
+  hipLaunchKernelGGL(gather_xyz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, spacap::as_stream(stream), xyz, idx, N, m,
+                     total, out);
+  SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
 

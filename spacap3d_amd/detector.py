@@ -44,6 +44,14 @@ SA_RADII = (0.2, 0.4, 0.8, 1.2)       # backbone_module.py:30,39,48,57
 SA_NSAMPLES = (64, 32, 16, 16)        # backbone_module.py:31,40,49,58
 
 
+def _centres(xyz, inds):
+    """xyz[b, inds[b, j], :]: one launch on the GPU (no index conversion), torch.gather elsewhere."""
+    if xyz.is_cuda and not xyz.requires_grad and inds.dtype == torch.int32:
+        from . import ext
+        return ext.gather_xyz(xyz.contiguous(), inds.contiguous())
+    return torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+
+
 def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPLES):
     """Everything in the backbone that depends on the input coordinates only, as a flat tuple of 12 (+7 on the GPU) tensors:
     the four sampling index sets (``sampling_pyramid``), the four ball-query groupings of the SA modules
@@ -56,7 +64,7 @@ def geometry_pyramid(xyz, npoints=SA_NPOINTS, radii=SA_RADII, nsamples=SA_NSAMPL
     cur = xyz
     for n, r, ns in zip(npoints, radii, nsamples):
         inds = pu.furthest_point_sample(cur, n)
-        new_xyz = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+        new_xyz = _centres(cur, inds)
         idx_all.append(pu.ball_query(r, ns, cur, new_xyz))
         inds_all.append(inds)
         xyzs.append(new_xyz)
@@ -121,7 +129,7 @@ class Pointnet2Backbone(nn.Module):
             cur = xyz
             for n in SA_NPOINTS:
                 inds = pu.furthest_point_sample(cur, n)
-                cur = torch.gather(cur, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+                cur = _centres(cur, inds)
                 ev = torch.cuda.Event()
                 ev.record(side)
                 levels.append((inds, cur, ev))

@@ -105,6 +105,35 @@ def three_nn(unknowns, knows):
     return [dist2, idx]
 
 
+def three_nn_weights(unknowns, knows):
+    """(idx, weight) of the three nearest known points with the feature-propagation modules' normalised inverse-distance
+    weights (pointnet2_modules.py:399-405) from one launch."""
+    _chk_contig(unknowns, "unknowns"); _chk_contig(knows, "knows")
+    _chk_float(unknowns, "unknowns"); _chk_float(knows, "knows")
+    _chk_gpu(unknowns, "unknowns"); _chk_gpu(knows, "knows", unknowns)
+    B, n, _ = unknowns.shape
+    m = knows.shape[1]
+    with torch.cuda.device(unknowns.device):
+        idx = torch.empty(B, n, 3, dtype=torch.int32, device=unknowns.device)
+        weight = torch.empty(B, n, 3, dtype=torch.float32, device=unknowns.device)
+        check(lib.spacap_three_nn_weights_f32(unknowns.data_ptr(), knows.data_ptr(), B, n, m, weight.data_ptr(),
+                                              idx.data_ptr(), _stream(unknowns)), "three_nn_weights")
+    return idx, weight
+
+
+def gather_xyz(xyz, idx):
+    """xyz (B,N,3) float32, idx (B,m) int32 -> (B,m,3): the coordinates of the sampled points."""
+    _chk_contig(xyz, "xyz"); _chk_contig(idx, "idx")
+    _chk_float(xyz, "xyz"); _chk_int(idx, "idx")
+    _chk_gpu(xyz, "xyz"); _chk_gpu(idx, "idx", xyz)
+    B, N, _ = xyz.shape
+    m = idx.shape[1]
+    with torch.cuda.device(xyz.device):
+        out = torch.empty(B, m, 3, dtype=torch.float32, device=xyz.device)
+        check(lib.spacap_gather_xyz_f32(xyz.data_ptr(), idx.data_ptr(), B, N, m, out.data_ptr(), _stream(xyz)), "gather_xyz")
+    return out
+
+
 def three_interpolate(points, idx, weight):
     _chk_contig(points, "points"); _chk_contig(idx, "idx"); _chk_contig(weight, "weight")
     _chk_float(points, "points"); _chk_int(idx, "idx"); _chk_float(weight, "weight")

@@ -111,7 +111,11 @@ class PointnetSAModuleVotes(nn.Module):
         elif fused is not None and xyz.is_cuda:
             # centres as a row gather of the (B,N,3) coordinates (same values as gather_operation on the transposed
             # copy, :239-241, without the two transposes)
-            new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
+            if not xyz.requires_grad and inds.dtype == torch.int32:
+                from . import ext
+                new_xyz = ext.gather_xyz(xyz.contiguous(), inds.contiguous())
+            else:
+                new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3))
         else:
             xyz_flipped = xyz.transpose(1, 2).contiguous()
             new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous()
@@ -150,6 +154,9 @@ class PointnetFPModule(nn.Module):
     @staticmethod
     def neighbours(unknown, known):
         """(idx, weight) of the three nearest known points and their normalised inverse distances (:399-405)."""
+        if unknown.is_cuda and not (unknown.requires_grad or known.requires_grad):
+            from . import ext
+            return ext.three_nn_weights(unknown.contiguous(), known.contiguous())   # search + weights in one launch
         dist, idx = pointnet2_utils.three_nn(unknown, known)
         dist_recip = 1.0 / (dist + 1e-8)
         norm = torch.sum(dist_recip, dim=2, keepdim=True)

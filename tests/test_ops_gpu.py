@@ -217,6 +217,33 @@ def test_three_nn_bit_exact(hip_ext, oracle_ext, n, m):
     assert torch.equal(d_got.cpu(), d_want)  # includes +inf slots when m < 3
 
 
+@pytest.mark.parametrize("n,m", [(512, 256), (1024, 512), (100, 3), (300, 1000)])
+def test_three_nn_weights_equal_the_tensor_composition(hip_ext, n, m):
+    """ext.three_nn_weights (search + normalised inverse-distance weights in one launch, csrc/interpolate.hip) against the
+    reference's separate tensor operations on the search result (pointnet2_modules.py:399-405): identical indices and
+    bit-identical weights, a point coinciding with a known point (distance 0) included."""
+    from spacap3d_amd import ext
+    g = torch.Generator().manual_seed(n + m)
+    unknown = torch.rand(2, n, 3, generator=g).to(DEV)
+    known = torch.rand(2, m, 3, generator=g).to(DEV)
+    unknown[:, 5] = known[:, 1]
+    d2, idx = hip_ext.three_nn(unknown, known)
+    r = 1.0 / (torch.sqrt(d2) + 1e-8)
+    want = r / torch.sum(r, dim=2, keepdim=True)
+    i_got, w_got = ext.three_nn_weights(unknown, known)
+    assert torch.equal(i_got, idx) and torch.equal(w_got, want)
+
+
+def test_gather_xyz_is_a_row_gather(hip_ext):
+    from spacap3d_amd import ext
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.randn(3, 500, 3, generator=g).to(DEV)
+    idx = torch.randint(0, 500, (3, 77), generator=g, dtype=torch.int32).to(DEV)
+    want = torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(ext.gather_xyz(xyz, idx), want)
+    assert ext.gather_xyz(xyz, idx[:, :0].contiguous()).shape == (3, 0, 3)
+
+
 @pytest.mark.parametrize("C,m,n", [(256, 256, 512), (256, 512, 1024), (2, 4, 2), (33, 50, 77)])
 def test_three_interpolate_and_grad(hip_ext, oracle_ext, C, m, n):
     g = torch.Generator().manual_seed(C + m + n)
