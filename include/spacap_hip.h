@@ -279,6 +279,25 @@ int spacap_relation_fused_bwd_f32(const float *dpred, const float *hid2, const f
                                   const float *W2, const float *W3, int B, int K, int nparts, int zslots, float *dP,
                                   float *dU, float *part, spacap_stream_t stream);
 
+/* ---- decoder input of the captioner's training step (replaces models/transformer_captioner.py:350-367, 246-249, 129-137,
+ * 150-161, 193-199 as separate tensor operations) ---------------------------------------------------------------------------
+ * xyz f32 [B,K,3] proposal centres, ref f32 [B,3] referred object's centre, src / memory f32 [B,K,D] proposal features and
+ * encoder output (memory may be NULL), tok i64 [B,T] label tokens, emb f32 [V,D], pe f32 [>= T-2, D]; L = T - 1.
+ *   idx i64 [B] = nearest proposal (squared distance, first minimum), dist f32 [B], good u8 [B] = dist > -1,
+ *   pred f32 [1] = sum(dist * good) / max(1, sum good);
+ *   x0 f32 [B,L,D]: row 0 = src[b,idx] + memory[b,idx], row 1+t = dropout_p(emb[tok[b,1+t]] * sqrt(D) + pe[t]);
+ *   mask u8 [B,L,L] = tok[b,k] > 0 and k <= q.
+ * counter i32 [1] must be zero before the first call and is left zero.  Dropout: counter hash of (seed, *seed_dev, element). */
+int spacap_caption_prep_fwd_f32(const float *xyz, const float *ref, const float *src, const float *memory,
+                                const int64_t *tok, const float *emb, const float *pe, int B, int K, int D, int T, int V,
+                                float p, uint64_t seed, const uint64_t *seed_dev, float *x0, uint8_t *mask, int64_t *idx,
+                                float *dist, uint8_t *good, float *pred, int32_t *counter, spacap_stream_t stream);
+/* g f32 [B,L,D] -> d_rows f32 [B,K,D] (the gradient of src and of memory: row idx[b] = g[b,0], zero elsewhere; may be NULL)
+ * and d_emb f32 [V,D] (dense, summed in (scene, position) order). */
+int spacap_caption_prep_bwd_f32(const float *g, const int64_t *tok, const int64_t *idx, int B, int K, int D, int T, int V,
+                                float p, uint64_t seed, const uint64_t *seed_dev, float *d_rows, float *d_emb,
+                                spacap_stream_t stream);
+
 /* ---- LayerNorm of the Transformer (replaces models/transformer_captioner.py:102-113) ----------- */
 
 /* y = a * (x - mean) / (std_unbiased + eps) + b over the last dimension; x,y f32 [rows, D] dense, a,b f32 [D];

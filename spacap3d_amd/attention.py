@@ -47,6 +47,8 @@ def _prep_mask_uncached(mask, B, Lq, Lk):
         assert m.size(1) == 1, "per-head masks are not used by the reference"
         m = m[:, 0]
     assert m.dim() == 3 and m.size(-1) == Lk and m.size(1) in (1, Lq)
+    if m.dtype == torch.uint8 and m.size(0) == B and m.is_contiguous():   # already in the kernels' form (caption_prep)
+        return m, m.stride(0), (0 if m.size(1) == 1 else m.stride(1))
     m = (m != 0).to(torch.uint8)
     if m.size(0) != B:
         m = m.expand(B, -1, -1)

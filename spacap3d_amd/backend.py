@@ -47,6 +47,8 @@ class HipBackend:
         self.conv1x1 = _lin.conv1x1
         self.relation_tail = _lin.relation_tail
         self.relation_head = _lin.relation_head
+        from . import caption_prep as _cp
+        self.caption_prep = _cp.caption_prep
         from . import tf_layer as _tf
         self.tf_stack = _tf
         from . import sa_mlp as _sa

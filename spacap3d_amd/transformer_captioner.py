@@ -466,21 +466,39 @@ class TransformerDecoderModel(nn.Module):
         if self.token_proj is not None:
             src = _linear(src, self.token_proj)
         src_pos = self._src_pos(ep)
-        _, _, target_ious, idx = nn_distance(ep["aggregated_vote_xyz"], ep["ref_center_label"].unsqueeze(1))
-        ep["match_idx"] = idx.squeeze(1)
-        ref_obj_feature = torch.gather(src, 1, idx.repeat(1, src.size(-1)).unsqueeze(1))
-        seq, seq_mask = self._prepare_feature(ep["lang_label"])
+        prep = getattr(ops(), "caption_prep", None) if (src.is_cuda and self.early_guide and self.model.encoder is not None) else None
         src_mask = ep["bbox_mask"].unsqueeze(1)
-        memory = None
-        if self.model.encoder is not None:
+        x0 = None
+        if prep is not None:
+            # encoder first, then nearest proposal + object indicator + token embedding + positional encoding + dropout + mask
+            # as one launch (csrc/caption_prep.hip) and the decoder stack on its output
             memory = self.model.encode(src, src_pos, src_mask)
             if self.check_relation:
-                self._relation_head(ep)  # reads the last encoder layer only: a side-stream branch beside the decoder
-        out = self.model(src=src, tgt=seq, src_mask=src_mask, tgt_mask=seq_mask,
-                         obj_indicator=ref_obj_feature, src_pos=src_pos,
-                         obj_idx=idx if self.use_transformer_encoder else None, memory=memory)
-        out = out[:, 1:, :] if self.early_guide else out
-        good = (target_ious > -1).squeeze(1)
+                self._relation_head(ep)
+            te = self.model.tgt_embed
+            got = prep(ep["aggregated_vote_xyz"], ep["ref_center_label"], src, memory, ep["lang_label"], te[0], te[1])
+            if got is not None:
+                x0, m8, idx1, dist, good, pred_ious = got
+                ep["match_idx"] = idx1
+                out = self.model.decoder(x0, None, None, m8)[:, 1:, :]
+        if x0 is None:
+            _, _, target_ious, idx = nn_distance(ep["aggregated_vote_xyz"], ep["ref_center_label"].unsqueeze(1))
+            ep["match_idx"] = idx.squeeze(1)
+            ref_obj_feature = torch.gather(src, 1, idx.repeat(1, src.size(-1)).unsqueeze(1))
+            seq, seq_mask = self._prepare_feature(ep["lang_label"])
+            if prep is None:
+                memory = None
+                if self.model.encoder is not None:
+                    memory = self.model.encode(src, src_pos, src_mask)
+                    if self.check_relation:
+                        self._relation_head(ep)  # reads the last encoder layer only
+            out = self.model(src=src, tgt=seq, src_mask=src_mask, tgt_mask=seq_mask,
+                             obj_indicator=ref_obj_feature, src_pos=src_pos,
+                             obj_idx=idx if self.use_transformer_encoder else None, memory=memory)
+            out = out[:, 1:, :] if self.early_guide else out
+            good = (target_ious > -1).squeeze(1)
+            # mean over the good boxes without a host sync (the reference branches on .sum() > 0, :385)
+            pred_ious = (target_ious.squeeze(1) * good).sum() / good.sum().clamp(min=1)
         fused = getattr(ops(), "caption_head_loss", None) if (out.is_cuda and self.training and "lang_ids" in ep) else None
         if fused is not None and ep["lang_ids"].shape[1] >= out.shape[1] + 1:
             # vocabulary projection, then log-softmax + the caption loss / accuracy in one op (fused_losses.CaptionHeadLoss);
@@ -489,9 +507,7 @@ class TransformerDecoderModel(nn.Module):
             ep["_cap_loss"] = (cl, ca)
         else:
             ep["lang_cap"] = self.model.generator(out)
-        # mean over the good boxes without a host sync (the reference branches on .sum() > 0, :385)
-        n_good = good.sum()
-        ep["pred_ious"] = (target_ious.squeeze(1) * good).sum() / n_good.clamp(min=1)
+        ep["pred_ious"] = pred_ious
         ep["good_bbox_masks"] = good
         if self.check_relation and "relation_pred" not in ep:
             self._relation_head(ep)

@@ -1,0 +1,124 @@
+"""caption_prep (csrc/caption_prep.hip): the captioner's decoder input for a training step in one launch each way, against the
+tensor operations it replaces (models/transformer_captioner.py:350-367, 246-249, 129-137, 150-161, 193-199)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _modules(D, V, p):
+    from spacap3d_amd.transformer_captioner import Embeddings, PositionalEncoding
+    torch.manual_seed(0)
+    emb = Embeddings(D, V).to(DEV)
+    pos = PositionalEncoding(D, p).to(DEV)
+    return emb, pos
+
+
+def _inputs(B, K, D, T, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.randn(B, K, 3, generator=g)
+    ref = xyz[torch.arange(B), torch.randint(0, K, (B,), generator=g)] + 0.01 * torch.randn(B, 3, generator=g)
+    src, mem = torch.randn(B, K, D, generator=g), torch.randn(B, K, D, generator=g)
+    tok = torch.randint(1, V, (B, T), generator=g)
+    for b in range(B):
+        if T > 2:
+            tok[b, int(torch.randint(2, T, (1,), generator=g)):] = 0     # padding after the sentence
+    return [t.to(DEV) for t in (xyz, ref, src, mem, tok)]
+
+
+def _composed(xyz, ref, src, mem, tok, emb, pos):
+    """The reference's operations (early-guide mode with the encoder)."""
+    from spacap3d_amd.loss_helper import nn_distance
+    from spacap3d_amd.transformer_captioner import subsequent_mask
+    _, _, dist, idx = nn_distance(xyz, ref.unsqueeze(1))
+    ind = torch.gather(src, 1, idx.repeat(1, src.size(-1)).unsqueeze(1))
+    ind = ind + torch.gather(mem, 1, idx.repeat(1, mem.size(-1)).unsqueeze(1))
+    seq = tok[:, :-1]
+    mask = (seq > 0).unsqueeze(-2) & subsequent_mask(seq.size(-1), device=seq.device)
+    x = torch.cat((ind, pos(emb(seq[:, 1:]))), dim=1)
+    good = (dist > -1).squeeze(1)
+    pred = (dist.squeeze(1) * good).sum() / good.sum().clamp(min=1)
+    return x, mask, idx.squeeze(1), dist.squeeze(1), good, pred
+
+
+@pytest.mark.parametrize("B,K,D,T,V", [(8, 256, 128, 32, 500), (3, 40, 128, 7, 37), (2, 256, 512, 32, 100), (1, 5, 16, 2, 3)])
+def test_matches_the_tensor_operations_without_dropout(B, K, D, T, V):
+    from spacap3d_amd.caption_prep import caption_prep
+    emb, pos = _modules(D, V, 0.0)
+    xyz, ref, src, mem, tok = _inputs(B, K, D, T, V, B + K)
+    sa, ma = src.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    want = _composed(xyz, ref, sa, ma, tok, emb, pos)
+    w = torch.randn_like(want[0])
+    (want[0] * w).sum().backward()
+    ge = emb.lut.weight.grad.clone()
+    emb.lut.weight.grad = None
+    sb, mb = src.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+    got = caption_prep(xyz, ref, sb, mb, tok, emb, pos)
+    assert got is not None
+    assert torch.equal(got[0], want[0])                       # every element: same operations in the same order
+    assert got[1].dtype == torch.uint8 and torch.equal(got[1].bool(), want[1].expand(B, -1, -1))
+    assert torch.equal(got[2], want[2]) and torch.equal(got[3], want[3]) and torch.equal(got[4], want[4])
+    assert abs(float(got[5]) - float(want[5])) <= 1e-6 * max(1.0, abs(float(want[5])))
+    (got[0] * w).sum().backward()
+    assert torch.equal(sb.grad, sa.grad) and torch.equal(mb.grad, ma.grad)
+    # (the padding token's row adds up hundreds of terms in another order than the library's sort-based kernel)
+    assert float((emb.lut.weight.grad - ge).abs().max()) <= 2e-6 * float(ge.abs().max())
+
+
+def test_dropout_keeps_scaled_values_and_the_backward_uses_the_same_mask():
+    from spacap3d_amd.caption_prep import caption_prep
+    B, K, D, T, V, p = 8, 256, 128, 32, 300, 0.1
+    emb, pos = _modules(D, V, p)
+    pos.train()
+    xyz, ref, src, mem, tok = _inputs(B, K, D, T, V, 5)
+    x0, _, idx, *_ = caption_prep(xyz, ref, src, mem, tok, emb, pos)
+    plain = emb(tok[:, 1:-1]) + pos.pe[:, :T - 2]
+    rows = x0[:, 1:]
+    kept = rows != 0
+    assert abs(float((~kept).float().mean()) - p) < 0.01
+    assert torch.allclose(rows[kept], (plain / (1 - p))[kept], rtol=1e-6, atol=1e-7)
+    assert torch.equal(x0[:, 0], src[torch.arange(B), idx] + mem[torch.arange(B), idx])     # the indicator is not dropped
+    # a second call draws another mask; within one call the backward regenerates the forward's
+    x1 = caption_prep(xyz, ref, src, mem, tok, emb, pos)[0]
+    assert not torch.equal(x1 != 0, x0 != 0)
+    x2, *_ = caption_prep(xyz, ref, src, mem, tok, emb, pos)
+    w = torch.randn_like(x2)
+    (x2 * w).sum().backward()
+    k2 = (x2[:, 1:] != 0).float()
+    want = torch.zeros_like(emb.lut.weight)
+    want.index_add_(0, tok[:, 1:-1].reshape(-1), (w[:, 1:] * k2 / (1 - p) * math.sqrt(D)).reshape(-1, D))
+    assert float((emb.lut.weight.grad - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_the_training_step_takes_it(monkeypatch):
+    """forward_train with and without the op: same proposal match, same decoder output, same parameter gradients (dropout off)."""
+    from spacap3d_amd import backend
+    from spacap3d_amd import synthetic as S
+    from spacap3d_amd.engine import synthetic_batch
+    from spacap3d_amd.loss_helper import get_scene_cap_loss
+    from spacap3d_amd.spacapnet import build_default
+    torch.manual_seed(0)
+    model = build_default().to(DEV).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    data = synthetic_batch(2, 8000, DEV, seed=7)
+    outs = []
+    for use in (True, False):
+        if not use:
+            monkeypatch.setattr(backend.ops(), "caption_prep", None, raising=False)
+        model.zero_grad(set_to_none=True)
+        d = get_scene_cap_loss(model(dict(data)), use_relation=True, mean_size_arr=S.mean_size_arr().numpy())
+        d["loss"].backward()
+        outs.append((d["match_idx"].clone(), d["lang_cap"].detach().clone(), d["pred_ious"].detach().clone(),
+                     {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    a, b = outs
+    assert torch.equal(a[0], b[0])
+    assert torch.allclose(a[1], b[1], rtol=1e-4, atol=1e-5) and torch.allclose(a[2], b[2], rtol=1e-6, atol=1e-7)
+    assert a[3].keys() == b[3].keys()
+    scale = max(float(v.abs().max()) for v in b[3].values())
+    for n in a[3]:
+        assert float((a[3][n] - b[3][n]).abs().max()) <= 2e-5 * max(float(b[3][n].abs().max()), 1e-3 * scale), n
