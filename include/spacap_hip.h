@@ -679,6 +679,12 @@ int spacap_tf_gemm_f32(const float *a, const float *W, long R, int K, int N, int
 int spacap_tf_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int K, int N, float *out,
                              spacap_stream_t stream);
 
+/* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
+int spacap_stream_delay(int microseconds, spacap_stream_t stream);
+
+/* Lab only (tools/lab/step_stamps.py): writes the device's 100 MHz wall clock into *slot when the stream reaches it. */
+int spacap_lab_stamp(uint64_t *slot, spacap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

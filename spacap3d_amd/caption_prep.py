@@ -69,8 +69,9 @@ def caption_prep(xyz, ref, src, memory, tok, embed, pos):
     apply (CPU tensors, other dtypes, a table shorter than the sequence)."""
     T = tok.shape[1]
     if not src.is_cuda or src.dtype != torch.float32 or tok.dtype != torch.int64 or T < 2 or pos.pe.shape[1] < T - 2 or \
-            embed.lut.weight.shape[1] != src.shape[-1] or xyz.requires_grad:
+            embed.lut.weight.shape[1] != src.shape[-1]:
         return None
+    xyz = xyz.detach()   # the match is an arg-min and the distance only feeds the reported ``pred_ious``: no gradient path
     p = float(pos.dropout.p) if pos.dropout.training else 0.0
     x0, mask, idx, dist, good, pred = CaptionPrep.apply(xyz, ref, src, memory, tok, embed.lut.weight, pos.pe[0], p,
                                                         _next_seed() if p > 0.0 else 0)

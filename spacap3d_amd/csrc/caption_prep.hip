@@ -56,11 +56,24 @@ struct PrepArgs {
   int *counter;
 };
 
+// grid (L, B): block (0, b) finds scene b's proposal and writes the indicator row, the mask and the per-scene scalars; block
+// (row, b) one embedded token row.  Two dependent loads deep at most: the launch is a few microseconds of latency.
 __global__ __launch_bounds__(256) void cap_prep_fwd_kernel(PrepArgs a) {
   __shared__ float s_d[256];
   __shared__ int s_k[256];
   __shared__ int s_last;
-  const int b = blockIdx.x, tid = threadIdx.x, L = a.T - 1, D = a.D;
+  const int row = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, L = a.T - 1, D = a.D;
+  if (row > 0) {
+    long long t = a.tok[(size_t)b * a.T + row];
+    t = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
+    const DropSeed sd = make_seed(a.seed, a.seed_dev);
+    for (int c = tid; c < D; c += 256) {
+      float v = a.emb[(size_t)t * D + c] * a.sqrt_d + a.pe[(size_t)(row - 1) * D + c];
+      const bool keep = a.thresh == 0u || hash32((unsigned long long)((size_t)b * L + row) * D + c, sd) >= a.thresh;
+      a.x0[((size_t)b * L + row) * D + c] = keep ? v * a.scale : 0.f;
+    }
+    return;
+  }
   // ---- nearest proposal: d = ((x - rx)^2 + (z - rz)^2) + (y - ry)^2, the order torch.sum(dim=-1) adds three terms in ----
   const float rx = a.ref[b * 3 + 0], ry = a.ref[b * 3 + 1], rz = a.ref[b * 3 + 2];
   float best = INFINITY;
@@ -87,28 +100,16 @@ __global__ __launch_bounds__(256) void cap_prep_fwd_kernel(PrepArgs a) {
     a.dist[b] = s_d[0];
     a.good[b] = s_d[0] > -1.f;
   }
-  // ---- rows of the decoder input ----
-  const DropSeed sd = make_seed(a.seed, a.seed_dev);
-  for (int e = tid; e < L * D; e += 256) {
-    const int row = e / D, c = e - row * D;
-    float v;
-    if (row == 0) {
-      v = a.src[((size_t)b * a.K + kb) * D + c];
-      if (a.memory) v += a.memory[((size_t)b * a.K + kb) * D + c];
-    } else {
-      long long t = a.tok[(size_t)b * a.T + row];
-      t = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
-      v = a.emb[(size_t)t * D + c] * a.sqrt_d + a.pe[(size_t)(row - 1) * D + c];
-      const bool keep = a.thresh == 0u || hash32((unsigned long long)((size_t)b * L + row) * D + c, sd) >= a.thresh;
-      v = keep ? v * a.scale : 0.f;
-    }
-    a.x0[((size_t)b * L + row) * D + c] = v;
+  for (int c = tid; c < D; c += 256) {
+    float v = a.src[((size_t)b * a.K + kb) * D + c];
+    if (a.memory) v += a.memory[((size_t)b * a.K + kb) * D + c];
+    a.x0[((size_t)b * L) * D + c] = v;
   }
   for (int e = tid; e < L * L; e += 256) {
     const int q = e / L, k = e - q * L;
     a.mask[(size_t)b * L * L + e] = (a.tok[(size_t)b * a.T + k] > 0 && k <= q) ? 1 : 0;
   }
-  // ---- the last workgroup adds the scenes up in order ----
+  // ---- the last scene block adds the scenes up in order ----
   __threadfence();
   if (tid == 0) s_last = atomicAdd(a.counter, 1) == a.B - 1;
   __syncthreads();
@@ -149,21 +150,54 @@ __global__ __launch_bounds__(128) void cap_prep_bwd_kernel(PrepBwdArgs a) {
     }
     return;
   }
-  const int v = blockIdx.x;
+  // the positions that hold this row's token, found once by the block (B (L - 1) token ids, a few hundred), then summed in order
+  const int v = blockIdx.x, NP = a.B * (L - 1);
+  __shared__ int s_pos[1024];
+  __shared__ int s_n;
   const DropSeed sd = make_seed(a.seed, a.seed_dev);
-  for (int c = tid; c < D; c += 128) {
-    float acc = 0.f;
-    for (int b = 0; b < a.B; ++b)
-      for (int row = 1; row < L; ++row) {
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int base = 0; base < NP; base += 1024) {
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    // ordered compaction: thread tid scans its 8 consecutive positions, ranks come from a running count per 128-wide pass
+    for (int pass = 0; pass < 8; ++pass) {
+      const int i = base + pass * 128 + tid;
+      bool hit = false;
+      if (i < NP) {
+        const int b = i / (L - 1), row = 1 + i - b * (L - 1);
         long long t = a.tok[(size_t)b * a.T + row];
         t = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
-        if (t != v) continue;
-        const size_t e = ((size_t)b * L + row) * D + c;
-        const bool keep = a.thresh == 0u || hash32((unsigned long long)e, sd) >= a.thresh;
-        if (keep) acc += (a.g[e] * a.scale) * a.sqrt_d;
+        hit = t == v;
       }
-    a.d_emb[(size_t)v * D + c] = acc;
+      const unsigned long long m = __ballot(hit);
+      __shared__ int s_w[2];
+      if ((tid & 63) == 0) s_w[tid >> 6] = __popcll(m);
+      __syncthreads();
+      if (hit) s_pos[s_n + (tid >= 64 ? s_w[0] : 0) + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = i;
+      __syncthreads();
+      if (tid == 0) s_n += s_w[0] + s_w[1];
+      __syncthreads();
+    }
+    const int n = s_n;
+    for (int q = 0; q < n; ++q) {
+      const int i = s_pos[q], b = i / (L - 1), row = 1 + i - b * (L - 1);
+      const size_t e0 = ((size_t)b * L + row) * D;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = tid + 128 * j;
+        if (c < D) {
+          const bool keep = a.thresh == 0u || hash32((unsigned long long)(e0 + c), sd) >= a.thresh;
+          if (keep) acc[j] += (a.g[e0 + c] * a.scale) * a.sqrt_d;
+        }
+      }
+    }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (tid + 128 * j < D) a.d_emb[(size_t)v * D + tid + 128 * j] = acc[j];
 }
 
 }  // namespace
@@ -183,7 +217,8 @@ extern "C" int spacap_caption_prep_fwd_f32(const float *xyz, const float *ref, c
   a.sqrt_d = (float)sqrt((double)D);
   a.seed = seed, a.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   a.x0 = x0, a.mask = mask, a.good = good, a.idx = reinterpret_cast<long long *>(idx), a.dist = dist, a.pred = pred, a.counter = counter;
-  hipLaunchKernelGGL(cap_prep_fwd_kernel, dim3(B), dim3(256), 0, spacap::as_stream(stream), a);
+  SPACAP_REQUIRE(B <= 65535, "%s: B out of range", what);
+  hipLaunchKernelGGL(cap_prep_fwd_kernel, dim3(T - 1, B), dim3(256), 0, spacap::as_stream(stream), a);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -196,6 +231,7 @@ extern "C" int spacap_caption_prep_bwd_f32(const float *g, const int64_t *tok, c
   SPACAP_REQUIRE(B >= 0 && K >= 1 && D >= 1 && T >= 2 && V >= 1 && drop_params(p, a.thresh, a.scale), "%s: bad arguments", what);
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(g && tok && idx && d_emb, "%s: null pointer", what);
+  SPACAP_REQUIRE(D <= 1024, "%s: D=%d unsupported (at most 1024)", what, D);
   a.g = g, a.tok = reinterpret_cast<const long long *>(tok), a.idx = reinterpret_cast<const long long *>(idx);
   a.B = B, a.K = K, a.D = D, a.T = T, a.V = V, a.with_rows = d_rows != nullptr;
   a.sqrt_d = (float)sqrt((double)D);

@@ -358,3 +358,30 @@ extern "C" int spacap_l2norm_rows_bwd_f32(const float *g, const float *y, const 
   SPACAP_CHECK_LAUNCH("spacap_l2norm_rows_bwd_f32");
   return SPACAP_OK;
 }
+
+// ---- a pause on a stream: one wave spins on the 100 MHz wall clock (engine.py: the side-stream pyramid must not be released
+// by the same event as the step's graph) ------------------------------------------------------------------------------------
+namespace {
+__global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+extern "C" int spacap_stream_delay(int microseconds, spacap_stream_t stream) {
+  SPACAP_REQUIRE(microseconds >= 0 && microseconds <= 100000, "spacap_stream_delay: %d us out of range", microseconds);
+  if (microseconds == 0) return SPACAP_OK;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, spacap::as_stream(stream), (unsigned long long)microseconds * 100ull);
+  SPACAP_CHECK_LAUNCH("spacap_stream_delay");
+  return SPACAP_OK;
+}
+
+// ---- lab: device timestamps inside a captured step (tools/lab/step_stamps.py) --------------------------------------------
+namespace {
+__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }   // s_memrealtime: 100 MHz
+}  // namespace
+extern "C" int spacap_lab_stamp(uint64_t *slot, spacap_stream_t stream) {
+  SPACAP_REQUIRE(slot, "spacap_lab_stamp: null pointer");
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, spacap::as_stream(stream), reinterpret_cast<unsigned long long *>(slot));
+  SPACAP_CHECK_LAUNCH("spacap_lab_stamp");
+  return SPACAP_OK;
+}

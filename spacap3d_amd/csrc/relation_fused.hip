@@ -465,7 +465,8 @@ constexpr size_t BWD_LDS = (size_t)2 * 3 * IMGT * 2 + (size_t)(TR * LDT + H * TR
 // scene per CU for the first half of the step) and run them as a second round: twice the time.
 inline int grid_size(int B, int K, int per_cu) {
   const long units = (long)B * (K / TJ) * (K / TI);
-  const long g = (long)per_cu * std::max(1, spacap::device_cus() - spacap::sa_reserved_cus());
+  // (with two workgroups per CU the dispatcher needs slack beyond the occupied CUs themselves: sa_mlp.hip, fwd_resident)
+  const long g = (long)per_cu * std::max(1, spacap::device_cus() - spacap::sa_reserved_cus() * (per_cu > 1 ? 3 : 1));
   return (int)std::min(units, g);
 }
 // dU slots: the largest number of workgroups whose ranges meet one key block

@@ -26,6 +26,7 @@ class Trainer:
         self.optimizer = None
         self.side_stream = None
         self.prefetch_geometry = True   # False: prefetch the sampling indices only (sampling_pyramid)
+        self.prefetch_skew_us = 20      # pause of the side stream before the pyramid's graph (see prefetch)
         self.graph = None          # captured hipGraph of one training step (see enable_graph)
         self.graph_error = None
         self._static = None
@@ -89,6 +90,14 @@ class Trainer:
                 self.side_stream.wait_stream(cur)
             with torch.cuda.stream(self.side_stream), torch.no_grad():
                 self._prefetch_in.copy_(pc[..., :3], non_blocking=True)
+                # The pyramid and the step's graph are released by the same event (the copy into the static buffers).  When
+                # both become runnable at the same instant the step takes 8.63 ms instead of 8.11 (cfg2, same box, bench.py;
+                # pauses of 5 .. 200 us all give 8.10 - 8.13, a pause on the main stream instead does the same), so the side
+                # stream pauses first.
+                skew = int(self.prefetch_skew_us)
+                if skew > 0:
+                    from ._native import check, lib
+                    check(lib.spacap_stream_delay(skew, self.side_stream.cuda_stream), "spacap_stream_delay")
                 self._prefetch_graph_obj.replay()
                 ev = torch.cuda.Event()
                 ev.record(self.side_stream)

@@ -107,8 +107,13 @@ def test_the_training_step_takes_it(monkeypatch):
             m.p = 0.0
     data = synthetic_batch(2, 8000, DEV, seed=7)
     outs = []
+    from spacap3d_amd import caption_prep as cp
+    calls = []
+    orig = cp.CaptionPrep.apply
+    monkeypatch.setattr(cp.CaptionPrep, "apply", lambda *a: (calls.append(1), orig(*a))[1])
     for use in (True, False):
         if not use:
+            assert calls, "the op did not run inside the model"
             monkeypatch.setattr(backend.ops(), "caption_prep", None, raising=False)
         model.zero_grad(set_to_none=True)
         d = get_scene_cap_loss(model(dict(data)), use_relation=True, mean_size_arr=S.mean_size_arr().numpy())

@@ -1,0 +1,128 @@
+"""Lab: where the time of a pipelined, graph-replayed training step goes -- device timestamps (100 MHz wall clock) written by
+one-thread kernels captured into the step at phase boundaries, forward and backward (an identity autograd node stamps when
+the backward passes it).  Unlike a rocprofv3 kernel trace this does not serialise the side-stream sampling chain.
+    python tools/lab/step_stamps.py [steps]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from spacap3d_amd import synthetic as S  # noqa: E402
+from spacap3d_amd._native import check, lib  # noqa: E402
+from spacap3d_amd.engine import Trainer, synthetic_batch  # noqa: E402
+from spacap3d_amd.spacapnet import build_default  # noqa: E402
+
+DEV = torch.device("cuda:0")
+NAMES = []
+BUF = torch.zeros(64, dtype=torch.int64, device=DEV)
+
+
+def stamp(name):
+    if name not in NAMES:
+        NAMES.append(name)
+    i = NAMES.index(name)
+    check(lib.spacap_lab_stamp(BUF.data_ptr() + 8 * i, torch.cuda.current_stream(DEV).cuda_stream), "stamp")
+
+
+class Mark(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        stamp("f:" + name)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        stamp("b:" + ctx.name)
+        return g, None
+
+
+def hook(x, name):
+    """Stamps without an autograd node of their own (HOOKS=1): a forward stamp and a tensor hook for the backward."""
+    if not os.environ.get("HOOKS"):
+        return Mark.apply(x, name)
+    stamp("f:" + name)
+    if x.requires_grad:
+        x.register_hook(lambda g: stamp("b:" + name))
+    return x
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    torch.manual_seed(0)
+    model = build_default().to(DEV).train()
+    # phase boundaries: wrap the sub-modules' forwards
+    bb, vg, pr, cap = model.backbone_net, model.vgen, model.proposal, model.caption
+    f_bb = bb.forward
+
+    def bb_forward(d):
+        stamp("f:start")
+        d = f_bb(d)
+        d["fp2_features"] = hook(d["fp2_features"], "backbone")
+        return d
+    if os.environ.get("NO_MARKS"):
+        bb_forward = f_bb
+    bb.forward = bb_forward
+    f_pr = pr.forward
+
+    def pr_forward(xyz, features, d):
+        d = f_pr(xyz, features, d)
+        d["aggregated_vote_features"] = hook(d["aggregated_vote_features"], "proposal")
+        return d
+    if not os.environ.get("NO_MARKS"):
+        pr.forward = pr_forward
+    enc = cap.model.encode
+
+    def encode(*a, **k):
+        return hook(enc(*a, **k), "encoder")
+    if not os.environ.get("NO_MARKS"):
+        cap.model.encode = encode
+    rel = cap._relation_head
+
+    def relation(ep):
+        rel(ep)
+        ep["relation_pred"] = hook(ep["relation_pred"], "relation")
+    if not os.environ.get("NO_MARKS"):
+        cap._relation_head = relation
+    dec = cap.model.decoder.forward
+
+    def decoder(*a, **k):
+        return hook(dec(*a, **k), "decoder")
+    if not os.environ.get("NO_MARKS"):
+        cap.model.decoder.forward = decoder
+    tr = Trainer(model, S.mean_size_arr().numpy())
+    f_loss = tr.loss
+
+    def loss(d):
+        out = f_loss(d)
+        stamp("f:loss")
+        return out
+    if not os.environ.get("NO_MARKS"):
+        tr.loss = loss
+    data = synthetic_batch(8, 40000, DEV, seed=1000)
+    tr.step(data, next_data=data)
+    assert tr.enable_graph(data), tr.graph_error
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(10):
+        tr.step(data, next_data=data)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        tr.step(data, next_data=data)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{e0.elapsed_time(e1) / steps:.3f} ms/step over {steps} steps")
+    if os.environ.get("NO_MARKS"):
+        return
+    t = BUF.cpu().tolist()
+    rows = sorted((t[i], n) for i, n in enumerate(NAMES))
+    t0 = rows[0][0]
+    prev = t0
+    for v, n in rows:
+        print(f"  {n:14s} at {(v - t0) / 100.0:8.1f} us   (+{(v - prev) / 100.0:7.1f})")
+        prev = v
+
+
+if __name__ == "__main__":
+    main()
