@@ -12,21 +12,20 @@ head on, attention dropout 0.1 as in the reference) -- fp32, inputs resident in 
 are sharded by rank (weak scaling); rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      the dominant kernel of the step's critical path: the largest shared-MLP GEMM (SA2 layer 3, 262 144 rows,
-                128 -> 256 channels; that kernel family is the largest block of main-stream time).  Default implementation:
-                `sa_mid_fwd_bf3s_kernel` -- fp32 results from bf16 matrix instructions, every fp32 product as 6 exact
-                bf16 products with fp32 accumulation (SPACAP_SA_F32MFMA=1 selects the fp32-MFMA
-                kernel, whose line is kept under profiles/ as well).
-                achieved = algorithmic flops 2*cin*cout*R / its average launch duration, measured live with HIP
-                events around back-to-back launches through the C ABI on the launch stream right after the timed steps
-                (inside the step the kernel sits in a replayed hipGraph, where events cannot bracket it; the in-step
-                duration is in the committed rocprofv3 trace under profiles/, `profiled_us`).  peak = 157.3 TFLOP/s
-                (fp32 MFMA).  traffic = HBM bytes per launch from the tracked rocprofv3 --pmc passes
-                (profiles/rNN_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_parse.py) next to the algorithmic
-                4*R*(cin+cout).
-  roofline_more the same object for the largest data-gradient GEMM (SA2 layer 3, 256 -> 128, split-bf16 streaming kernel), for an HBM-bound layer (SA1 layer 2, 64 -> 64 on 1 048 576 rows) and for the SA1
-                furthest-point sampling, which is neither: an on-chip latency chain (bound "latency", us per round;
-                `in_step_us` = its duration on the prefetch side stream inside the timed steps, from events).
+  roofline      the kernel function with the largest summed duration on the step's own stream (profiles/*_timed_window_kernels.csv):
+                `rel_fused_bwd_kernel`, the relation head's backward on 524 288 proposal pairs in one launch
+                (csrc/relation_fused.hip).  launch_us = its duration INSIDE eager training steps run right after the timed
+                region (HIP events on the step's stream around the C-ABI call, the next batch's sampling chain beside it);
+                achieved = algorithmic flops / launch_us against the ceiling of the implemented arithmetic (the 128 x 128
+                products as split-bf16: 6 bf16 MFMA products per fp32 product, 2 500 / 6 TFLOP/s; the per-key and 9-wide
+                products as fp32 MFMA, 157.3 TFLOP/s; ceiling = flops / time of each part at its own peak); arithmetic
+                intensity 129 flop/B, above the ridge: bound "mfma".  traffic = HBM bytes per launch from the tracked
+                rocprofv3 --pmc passes (profiles/rNN_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_parse.py).
+  roofline_more the same object for: the largest shared-MLP forward layer (SA2 layer 3, 262 144 rows, 128 -> 256, streaming
+                split-bf16 kernel, HBM-bound, in-step duration as above), the relation head's forward, the largest
+                data-gradient GEMM (SA2 layer 3), an HBM-bound layer (SA1 layer 2, 64 -> 64 on 1 048 576 rows), the encoder's
+                feed-forward block, and the SA1 furthest-point sampling, which is neither: an on-chip latency chain (bound
+                "latency", us per round).
   step          algorithmic flops of the whole training step and the resulting fraction of the fp32-MFMA peak.
   drop_in       scenes/s when the caller invokes the model unchanged (no Trainer-level pipelining: furthest-point
                 sampling, ball queries and interpolation weights computed inside the step).
@@ -355,17 +354,20 @@ def main():
     n_params, allreduce_bytes = sum(p.numel() for p in model.parameters()), trainer.bucket.nbytes
 
     # -- the roofline kernel's duration INSIDE a step (beside the side-stream sampling chain, with the step's grid) ----------
-    in_step = None
+    in_step = in_step_rel = None
     if world == 1 and nxt is not None and not args.ablate and not args.no_in_step and (per_gpu, cfg["n_points"]) == (8, 40000):
+        import spacap3d_amd.linear as lin
         import spacap3d_amd.sa_mlp as sam
         R2_ = per_gpu * 1024 * 32
         keep_graph, trainer.graph = trainer.graph, None     # a few EAGER steps: same kernels, events can bracket them
-        with InStepTimer(sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)) as ist:
+        with InStepTimer(sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)) as ist, \
+                InStepTimer(lin, "spacap_relation_fused_bwd_f32", lambda a: True) as irel:
             for _ in range(8):
                 trainer.step(data, next_data=nxt)
             torch.cuda.synchronize()
         if ist.events:
             in_step = {"us": ist.mean_us(), "launches": len(ist.events)}
+        in_step_rel = {"us": irel.mean_us(), "launches": len(irel.events)} if irel.events else None
         trainer.graph = keep_graph
 
     # -- inference forward (greedy decoding) -------------------------------------------------------------------------------
@@ -410,24 +412,44 @@ def main():
         # the layer kernels are timed with their full grid (nothing runs beside them here); the step launches the forward
         # ones with `reserved_cus` CUs left to the sampling chain: that launch is timed as well
         KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
-        c_mfma = KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3")
-        iso_us = KC.time_case(c_mfma)
         # `roofline` = the kernel function with the largest summed duration on the step's own stream (window table under
-        # profiles/: sa_mid_fwd_bf3s_kernel<128, .., pooled>, four launches per step), at its largest launch (SA2 layer 3),
-        # priced with the duration it has INSIDE the step and against the roof that binds the implemented arithmetic
-        roof = KC.roofline_entry(c_mfma, in_step["us"] if in_step else iso_us, pmc)
-        roof["launch_us_isolated_full_grid"] = iso_us
-        if in_step:
-            roof["in_step_launches_timed"] = in_step["launches"]
+        # profiles/: rel_fused_bwd_kernel, one launch per step), priced with the duration it has INSIDE the step and against
+        # the roof that binds the implemented arithmetic (its 128 x 128 products as split-bf16, the rest as fp32 MFMA)
+        how_tail = ("launch_us = mean duration of this launch INSIDE {n} eager training steps run right after the timed region (HIP "
+                    "events on the step's stream around the C-ABI call; the sampling chain of the next batch runs beside it on the "
+                    "side stream and the grid leaves " + str(reserved_cus) + " CUs to it, as in the replayed step -- compare the "
+                    "kernel's row in profiles/*_step_timeline.txt); launch_us_isolated_*: 20 back-to-back launches with nothing "
+                    "beside them; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+        c_rel = KC.rel_fused(B, cfg["proposals"], 1, dev)
+        iso_rel = KC.time_case(c_rel)
+        roof = KC.roofline_entry(c_rel, in_step_rel["us"] if in_step_rel else iso_rel, pmc)
+        roof["launch_us_isolated_full_grid"] = iso_rel
+        if in_step_rel:
+            roof["in_step_launches_timed"] = in_step_rel["launches"]
         if reserved_cus:
             KC.check(KC.lib.spacap_sa_reserve_cus(reserved_cus), "spacap_sa_reserve_cus")
-            roof["launch_us_isolated_with_the_steps_grid"] = KC.time_case(c_mfma)
+            c_rel2 = KC.rel_fused(B, cfg["proposals"], 1, dev)     # (the grid is fixed when the buffers are sized)
+            roof["launch_us_isolated_with_the_steps_grid"] = KC.time_case(c_rel2)
+            del c_rel2
             KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
-        roof["how"] = ("launch_us = mean duration of this launch INSIDE " + (str(in_step["launches"]) if in_step else "0") + " eager training steps run right "
-                       "after the timed region (HIP events on the step's stream around the C-ABI call; the sampling chain of the next "
-                       "batch runs beside it on the side stream and the forward grid leaves " + str(reserved_cus) + " CUs to it, as in the "
-                       "replayed step -- compare the kernel's row in profiles/*_step_timeline.txt); launch_us_isolated_*: 20 back-to-back "
-                       "launches with nothing beside them; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+        roof["how"] = how_tail.format(n=in_step_rel["launches"] if in_step_rel else 0)
+        del c_rel
+        c_relf = KC.rel_fused(B, cfg["proposals"], 0, dev)
+        roof_relf = KC.roofline_entry(c_relf, KC.time_case(c_relf), pmc)
+        del c_relf
+        # the shared-MLP layer kernel with the largest summed duration (sa_mid_fwd_bf3s_kernel<128, .., pooled>, four launches
+        # per step) at its largest launch (SA2 layer 3): HBM-bound as split-bf16
+        c_mfma = KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3")
+        iso_us = KC.time_case(c_mfma)
+        roof_sa = KC.roofline_entry(c_mfma, in_step["us"] if in_step else iso_us, pmc)
+        roof_sa["launch_us_isolated_full_grid"] = iso_us
+        if in_step:
+            roof_sa["in_step_launches_timed"] = in_step["launches"]
+        if reserved_cus:
+            KC.check(KC.lib.spacap_sa_reserve_cus(reserved_cus), "spacap_sa_reserve_cus")
+            roof_sa["launch_us_isolated_with_the_steps_grid"] = KC.time_case(c_mfma)
+            KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
+        roof_sa["how"] = how_tail.format(n=in_step["launches"] if in_step else 0)
         del c_mfma
         c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
         roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)
@@ -476,7 +498,7 @@ def main():
                        "sa_forward_gemm": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if os.environ.get("SPACAP_SA_F32MFMA", "0") not in ("", "0") else
                                            "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
-            "roofline": roof, "roofline_more": [roof_dg, roof_hbm, roof_ffn, roof_fps],
+            "roofline": roof, "roofline_more": [roof_sa, roof_relf, roof_dg, roof_hbm, roof_ffn, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
                      "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
             "ops": ops, "final_loss": loss_val,

@@ -93,17 +93,43 @@ def sa_wgrad(R, ck, cp, pooled, S, dev, label):
                 what=f"{label}: dW = dz^T relu(bn(z_prev)) per row slab, {R} rows")
 
 
-def rel_tail_fwd(R, dev):
-    h1, W2, b2 = _rand(R, 128, dev=dev).relu_(), _rand(128, 128, dev=dev) * 0.1, _rand(128, dev=dev) * 0.1
-    W3, b3 = _rand(9, 128, dev=dev) * 0.1, _rand(9, dev=dev) * 0.1
+def rel_fused(B, K, mode, dev):
+    """The relation head as one launch each way (csrc/relation_fused.hip) on B * K * K proposal pairs."""
+    H = 8
+    P, U = torch.softmax(_rand(B, H, K, K, dev=dev), -1), _rand(B, K, H, 128, dev=dev) * 0.3
+    b1, W2, b2 = _rand(128, dev=dev) * 0.1, _rand(128, 128, dev=dev) * 0.1, _rand(128, dev=dev) * 0.1
+    W3, b3 = _rand(9, 128, dev=dev) * 0.1, _rand(9, dev=dev)
+    R = B * K * K
     hid2, pred = torch.empty(R, 128, dtype=torch.float32, device=dev), torch.empty(R, 9, dtype=torch.float32, device=dev)
+    check(lib.spacap_relation_fused_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(),
+                                            b3.data_ptr(), B, K, hid2.data_ptr(), pred.data_ptr(), _st(dev)), "rel_fused_fwd")
+    if mode == 0:
+        def run():
+            check(lib.spacap_relation_fused_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(),
+                                                    W3.data_ptr(), b3.data_ptr(), B, K, hid2.data_ptr(), pred.data_ptr(), _st(dev)),
+                  "rel_fused_fwd")
+        return dict(name=f"rel_fused_fwd B={B} K={K} (relation head, {R} pairs)", kernel="rel_fused_fwd_kernel", run=run,
+                    flops=2.0 * R * (8 * 128 + 128 * 128 + 128 * 9), flops_split=2.0 * R * 128 * 128,
+                    bytes=4.0 * R * (8 + 128 + 9), bf16_products=6,
+                    keep=(P, U, b1, W2, b2, W3, b3, hid2, pred),
+                    what="pair feature + Linear-ReLU-Linear-ReLU-Linear in one launch: reads P (8 values per pair), writes hid2 and "
+                         "pred; the 128 x 128 layer as split-bf16, the per-key and 9-wide products as fp32 MFMA")
+    dpred = _rand(R, 9, dev=dev)
+    nparts = int(lib.spacap_relation_fused_nparts(B, K))
+    zs = int(lib.spacap_relation_fused_zsplit(B, K, nparts))
+    dP, dU = torch.empty_like(P), torch.empty(zs, B, K, H, 128, dtype=torch.float32, device=dev)
+    part = torch.empty(nparts, int(lib.spacap_relation_fused_part_floats()), dtype=torch.float32, device=dev)
 
     def run():
-        check(lib.spacap_rel_tail_fwd_f32(h1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(), b3.data_ptr(), R,
-                                          hid2.data_ptr(), pred.data_ptr(), _st(dev)), "rel_tail_fwd")
-    return dict(name=f"rel_tail_fwd R={R} (relation head layers 2+3)", kernel="sa_mid_fwd_kernel<128, 2, true>", run=run,
-                flops=2.0 * R * (128 * 128 + 128 * 9), bytes=4.0 * R * (128 + 128 + 9), keep=(h1, W2, b2, W3, b3, hid2, pred),
-                what="relation head: hid2 = relu(W2 hid1 + b2) stored, pred = W3 hid2 + b3, 524 288 pair rows")
+        check(lib.spacap_relation_fused_bwd_f32(dpred.data_ptr(), hid2.data_ptr(), P.data_ptr(), U.data_ptr(), b1.data_ptr(),
+                                                W2.data_ptr(), W3.data_ptr(), B, K, nparts, zs, dP.data_ptr(), dU.data_ptr(),
+                                                part.data_ptr(), _st(dev)), "rel_fused_bwd")
+    return dict(name=f"rel_fused_bwd B={B} K={K} (relation head, {R} pairs)", kernel="rel_fused_bwd_kernel", run=run,
+                flops=2.0 * R * (3 * 8 * 128 + 2 * 128 * 128 + 3 * 128 * 9), flops_split=2.0 * R * 2 * 128 * 128,
+                bytes=4.0 * R * (128 + 9 + 8 + 8), bf16_products=6,
+                keep=(P, U, b1, W2, W3, hid2, dpred, dP, dU, part),
+                what="reads hid2, dpred and P, recomputes hid1, writes dP; dU and the parameter sums stay on chip until the end "
+                     "(dhid1 and dW2 as split-bf16)")
 
 
 def mha_fwd(B, h, L, dk, dev, need_p):
@@ -174,7 +200,8 @@ def cases(dev, B=8):
         lambda: sa_wgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
         lambda: sa_wgrad(R2, 128, 128, False, 32, dev, "SA2 layer 2"),
         lambda: sa_wgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
-        lambda: rel_tail_fwd(B * 256 * 256, dev),
+        lambda: rel_fused(B, 256, 0, dev),
+        lambda: rel_fused(B, 256, 1, dev),
         lambda: mha_fwd(B, 8, 256, 16, dev, True),
         lambda: tf_ffn(B * 256, 2048, 0, dev),
         lambda: tf_ffn(B * 256, 2048, 1, dev),
@@ -205,6 +232,11 @@ def roofline_entry(case, us, pmc=None):
     fp32-equivalent flop rate stays in the entry as a secondary figure.  FPS is a latency chain (on-chip resident)."""
     split = bool(case.get("bf16_products"))
     ceiling = PEAK_MFMA_BF16_TFLOPS / case["bf16_products"] if split else PEAK_MFMA_F32_TFLOPS
+    if split and case.get("flops_split") is not None:
+        # mixed kernels (relation head): `flops_split` of the flops as split-bf16, the rest as fp32 MFMA -- the ceiling is
+        # total flops / (time of each part at its own peak)
+        fs = case["flops_split"]
+        ceiling = case["flops"] / (fs / ceiling + (case["flops"] - fs) / PEAK_MFMA_F32_TFLOPS)
     if "rounds" in case:
         ent = dict(bound="latency", kernel=case["name"], achieved=us / case["rounds"], peak=None, unit="us/round", frac=None,
                    streamed_model_GBs=case["bytes"] / us * 1e-3, streamed_model_frac_of_hbm=case["bytes"] / us * 1e-3 / PEAK_HBM_GBS)
@@ -225,7 +257,7 @@ def roofline_entry(case, us, pmc=None):
         # fp32 accumulation (csrc/sa_bf3.inc).  `achieved` stays the ALGORITHMIC fp32 flops of the layer / time and `peak`
         # the fp32-MFMA peak it replaces; the matrix pipe itself executes 6x those flops in bf16:
         ent["implementation"] = "split-bf16: 6 bf16 MFMA products per fp32 product, fp32 accumulate (fp32-equivalent result)"
-        ent["mfma_bf16_TFLOPs"] = case["bf16_products"] * case["flops"] / us * 1e-6
+        ent["mfma_bf16_TFLOPs"] = case["bf16_products"] * case.get("flops_split", case["flops"]) / us * 1e-6
         ent["mfma_bf16_frac_of_peak"] = ent["mfma_bf16_TFLOPs"] / PEAK_MFMA_BF16_TFLOPS
     rec = (pmc or {}).get(case["name"])
     ent["traffic"] = rec.get("hbm_bytes") if rec else None

@@ -59,6 +59,9 @@ def main():
     def bb_forward(d):
         stamp("f:start")
         d = f_bb(d)
+        for k in ("sa1_features", "sa2_features", "sa3_features", "sa4_features"):
+            if d[k].requires_grad:
+                d[k].register_hook(lambda g, k=k: stamp("b:" + k[:3]))
         d["fp2_features"] = hook(d["fp2_features"], "backbone")
         return d
     if os.environ.get("NO_MARKS"):
@@ -100,6 +103,26 @@ def main():
         return out
     if not os.environ.get("NO_MARKS"):
         tr.loss = loss
+        f_opt = tr._optimizer_step
+
+        def opt(src):
+            stamp("b:done (deferred weight gradients flushed)")
+            f_opt(src)
+            stamp("opt:done")
+        tr._optimizer_step = opt
+        from spacap3d_amd import _native
+        f_dq = _native.deferred_slab_sums
+
+        import contextlib
+
+        @contextlib.contextmanager
+        def dq():
+            with f_dq() as q:
+                yield q
+                stamp("b:autograd done")
+        import spacap3d_amd.engine as E
+        if hasattr(E, "deferred_slab_sums"):
+            E.deferred_slab_sums = dq
     data = synthetic_batch(8, 40000, DEV, seed=1000)
     tr.step(data, next_data=data)
     assert tr.enable_graph(data), tr.graph_error
@@ -120,7 +143,7 @@ def main():
     t0 = rows[0][0]
     prev = t0
     for v, n in rows:
-        print(f"  {n:14s} at {(v - t0) / 100.0:8.1f} us   (+{(v - prev) / 100.0:7.1f})")
+        print(f"  {n:46s} at {(v - t0) / 100.0:8.1f} us   (+{(v - prev) / 100.0:7.1f})")
         prev = v
 
 
