@@ -15,7 +15,7 @@ from spacap3d_amd.spacapnet import build_default  # noqa: E402
 
 DEV = torch.device("cuda:0")
 NAMES = []
-BUF = torch.zeros(64, dtype=torch.int64, device=DEV)
+BUF = torch.zeros(4096, dtype=torch.int64, device=DEV)
 
 
 def stamp(name):
@@ -48,7 +48,29 @@ def hook(x, name):
     return x
 
 
+def stamp_every_call():
+    """CALLS=1: a stamp in front of every C-ABI call of the step (names numbered in call order): the duration of each of this
+    library's kernels as it runs beside the side stream (plus whatever tensor operations follow it)."""
+    from spacap3d_amd import _native
+    count = [0]
+    for name in _native.SIGNATURES:
+        if name.startswith(("spacap_lab", "spacap_sa_reserve", "spacap_stream_delay")) or "supported" in name or "nparts" in name \
+                or "slabs" in name or "zsplit" in name or "_parts" in name or "workspace" in name or "floats" in name or "isplit" in name \
+                or "blocks" in name:
+            continue
+        fn = getattr(lib, name)
+
+        def wrapped(*a, fn=fn, name=name):
+            if torch.cuda.is_current_stream_capturing():
+                count[0] += 1
+                stamp(f"{count[0]:04d} {name[7:]}")
+            return fn(*a)
+        setattr(lib, name, wrapped)
+
+
 def main():
+    if os.environ.get("CALLS"):
+        stamp_every_call()
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     torch.manual_seed(0)
     model = build_default().to(DEV).train()
@@ -145,6 +167,16 @@ def main():
     for v, n in rows:
         print(f"  {n:46s} at {(v - t0) / 100.0:8.1f} us   (+{(v - prev) / 100.0:7.1f})")
         prev = v
+    if os.environ.get("CALLS"):   # time from each call to the next stamp, summed per entry point
+        import collections
+        tot, cnt = collections.Counter(), collections.Counter()
+        for (v, n), (v2, _) in zip(rows, rows[1:]):
+            key = n.split(" ", 1)[1] if n[:4].isdigit() else n
+            tot[key] += (v2 - v) / 100.0
+            cnt[key] += 1
+        print("--- per entry point: us until the next stamp (the kernel itself + tensor operations that follow it)")
+        for k, v in tot.most_common(40):
+            print(f"  {k:46s} {v:8.1f} us  {cnt[k]:3d} calls")
 
 
 if __name__ == "__main__":
