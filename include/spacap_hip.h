@@ -679,6 +679,15 @@ int spacap_tf_gemm_f32(const float *a, const float *W, long R, int K, int N, int
 int spacap_tf_dgrad_mask_f32(const float *g, const float *W, const float *y, float scale, long R, int K, int N, float *out,
                              spacap_stream_t stream);
 
+/* 1x1 convolutions on channel-major tensors (nn.Conv1d / nn.Conv2d with kernel size 1: models/voting_module.py:33-60,
+ * models/proposal_module.py:41-55, lib/pointnet2/pytorch_utils.py:11-36, models/transformer_captioner.py:251-258), N = points
+ * per scene, a multiple of 64 (spacap_conv1x1_cm_supported).  W f32 [CO,CI] dense.
+ *   mode 0 (forward):        out[b,co,n] = sum_ci W[co,ci] in[b,ci,n] + bias[co]   in [B,CI,N], out [B,CO,N], bias f32 [CO] or NULL
+ *   mode 1 (input gradient): out[b,ci,n] = sum_co W[co,ci] in[b,co,n]              in [B,CO,N], out [B,CI,N] */
+int spacap_conv1x1_cm_supported(int CI, int CO, long N);
+int spacap_conv1x1_cm_f32(int mode, const float *W, const float *in, const float *bias, int B, int CI, int CO, long N,
+                          float *out, spacap_stream_t stream);
+
 /* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
 int spacap_stream_delay(int microseconds, spacap_stream_t stream);
 

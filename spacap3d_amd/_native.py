@@ -70,6 +70,8 @@ SIGNATURES = {
     "spacap_relation_fused_bwd_f32": (_i, [_p] * 7 + [_i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_caption_prep_fwd_f32": (_i, [_p] * 7 + [_i] * 5 + [_f, _u64, _p] + [_p] * 7 + [_p]),
     "spacap_caption_prep_bwd_f32": (_i, [_p] * 3 + [_i] * 5 + [_f, _u64, _p, _p, _p, _p]),
+    "spacap_conv1x1_cm_supported": (_i, [_i, _i, _l]),
+    "spacap_conv1x1_cm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
     "spacap_lab_stamp": (_i, [_p, _p]),
     "spacap_stream_delay": (_i, [_i, _p]),
     "spacap_sa_nparts": (_i, []),

@@ -187,6 +187,10 @@ class Conv1x1(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if USE_OWN_CONV:
+            y = conv1x1_cm(0, weight, x, bias, weight.shape[0])
+            if y is not None:
+                return y
         return F.conv2d(x, weight, bias) if x.dim() == 4 else F.conv1d(x, weight, bias)
 
     @staticmethod
@@ -198,13 +202,45 @@ class Conv1x1(Function):
         g = g.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
+            dx = conv1x1_cm(1, weight, g, None, CI) if USE_OWN_CONV else None
+            if dx is None:
+                dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
+                                                         [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
+                                                         [True, False, False])[0]
+        if int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N)):
+            part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True)
+            dw = sum_slabs(part, deferrable=True).view_as(weight)
+        else:   # output widths without a slab kernel (the 259- / 97-wide heads): the library's weight gradient
+            dw = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
                                                      [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
-                                                     [True, False, False])[0]
-        part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True)
-        dw = sum_slabs(part, deferrable=True).view_as(weight)
+                                                     [False, True, False])[1]
         db = g.sum(dim=[0] + list(range(2, g.dim()))) if ctx.has_bias else None
         return dx, dw, db
+
+
+# The library's own forward / input-gradient kernel for these convolutions (csrc/conv1x1.hip) is built and gated
+# (tests/test_attention_gpu.py::test_conv1x1_channel_major_kernel) but NOT on the default path: isolated it takes 6 - 16 us
+# where the library call takes 20 (29 vs 21 at 768 -> 256 channels), inside the replayed step the difference did not show
+# (8.30 vs 8.27 ms, tools/lab/conv_cm_bench.py), and its different summation order moves the chaotic 5-step trajectory
+# gate (tests/test_engine_gpu.py) past its 5 % bar at step 3.
+USE_OWN_CONV = False
+
+
+def conv1x1_cm(mode, weight, t, bias, M):
+    """The library's own channel-major kernel (csrc/conv1x1.hip): forward (mode 0) or input gradient (mode 1) of a 1x1
+    convolution on ``t`` (B, C, N[, 1]) contiguous; ``None`` for shapes it does not take (N not a multiple of 64)."""
+    B, C = t.shape[0], t.shape[1]
+    N = t.numel() // max(B * C, 1)
+    CO, CI = weight.shape[0], weight.shape[1]
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and weight.is_contiguous() and B > 0 and
+            lib.spacap_conv1x1_cm_supported(CI, CO, N)) or t.data_ptr() % 16:
+        return None
+    with torch.cuda.device(t.device):
+        out = torch.empty((B, M) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
+        check(lib.spacap_conv1x1_cm_f32(mode, weight.data_ptr(), t.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        B, CI, CO, N, out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream),
+              "spacap_conv1x1_cm_f32")
+    return out
 
 
 def conv1x1(x, conv):

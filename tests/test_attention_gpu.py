@@ -268,7 +268,7 @@ def test_small_row_linears_take_the_row_panel_kernel_and_keep_their_gradients():
 
 
 @pytest.mark.parametrize("B,CO,CI,N,dims", [(8, 256, 256, 1024, 3), (8, 256, 512, 512, 4), (2, 128, 128, 32, 3), (3, 256, 128, 96, 4),
-                                             (1, 384, 256, 2048, 3)])
+                                             (1, 384, 256, 2048, 3), (8, 256, 768, 512, 4), (8, 128, 128, 256, 3)])
 def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
     """linear.Conv1x1 (1x1 Conv1d / Conv2d on channel-major tensors: vote net, feature-propagation MLPs): output and
     the three gradients against float64 autograd of the same convolution."""
@@ -294,6 +294,27 @@ def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
     assert conv1x1(torch.zeros(2, CI, 33, device=DEV), torch.nn.Conv1d(CI, CO, 1).to(DEV)) is None   # N not a multiple of 32
     with torch.no_grad():
         assert conv1x1(xg, conv) is None
+
+
+@pytest.mark.parametrize("B,CO,CI,N", [(8, 256, 256, 1024), (2, 259, 256, 64), (3, 97, 128, 256), (1, 256, 770, 128), (2, 5, 3, 64),
+                                        (1, 130, 37, 192)])
+def test_conv1x1_channel_major_kernel(B, CO, CI, N):
+    """spacap_conv1x1_cm_f32 (csrc/conv1x1.hip): forward with bias and input gradient of a 1x1 convolution on channel-major
+    tensors against float64 einsums, with row (output / input channel) and contraction tails that are not multiples of the tile."""
+    from spacap3d_amd._native import check, lib
+    g = torch.Generator().manual_seed(CO * N + CI)
+    W, b = torch.randn(CO, CI, generator=g) * 0.1, torch.randn(CO, generator=g)
+    x, gy = torch.randn(B, CI, N, generator=g), torch.randn(B, CO, N, generator=g)
+    Wd, bd, xd, gd = W.to(DEV), b.to(DEV), x.to(DEV), gy.to(DEV)
+    y, dx = torch.empty(B, CO, N, device=DEV), torch.empty(B, CI, N, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.spacap_conv1x1_cm_supported(CI, CO, N) == 1 and lib.spacap_conv1x1_cm_supported(CI, CO, N + 1) == 0
+    check(lib.spacap_conv1x1_cm_f32(0, Wd.data_ptr(), xd.data_ptr(), bd.data_ptr(), B, CI, CO, N, y.data_ptr(), st), "fwd")
+    check(lib.spacap_conv1x1_cm_f32(1, Wd.data_ptr(), gd.data_ptr(), None, B, CI, CO, N, dx.data_ptr(), st), "dgrad")
+    want_y = torch.einsum("oc,bcn->bon", W.double(), x.double()) + b.double().view(1, -1, 1)
+    want_dx = torch.einsum("oc,bon->bcn", W.double(), gy.double())
+    assert float((y.double().cpu() - want_y).abs().max()) < 2e-6 * float(want_y.abs().max())
+    assert float((dx.double().cpu() - want_dx).abs().max()) < 2e-6 * float(want_dx.abs().max())
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 64, 128), (1, 50, 50, 128), (8192, 128), (77, 128), (1, 128)])
