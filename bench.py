@@ -451,7 +451,7 @@ def main():
             KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
         roof_sa["how"] = how_tail.format(n=in_step["launches"] if in_step else 0)
         del c_mfma
-        c_hbm = KC.sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2")
+        c_hbm = KC.sa_mid_fwd_l1in(R1, dev, "SA1 layer 2")
         roof_hbm = KC.roofline_entry(c_hbm, KC.time_case(c_hbm), pmc)
         del c_hbm
         c_dg = KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3")

@@ -383,6 +383,22 @@ int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const float *coef, 
                            const float *st_p, const float *feat, const float *xyz, const float *new_xyz,
                            const int32_t *idx, float rdiv, int B, int Np, int N, int S, int CK, int CP, double *part,
                            float *part_l1, spacap_stream_t stream);
+/* The SA1 family without z1 in HBM (first layer: 3 relative coordinates + at most one inline feature, no point features;
+ * C1 = C2 = 64; lib/pointnet2/pointnet2_modules.py:241-259 with pytorch_utils.py:11-36).  spacap_sa_l1_stats_f32 is
+ * spacap_sa_l1_fwd_f32 without the z1 store: the BatchNorm sums in `part` and rel4 f32 [R,4] = each grouped row's inputs
+ * (x, y, z relative to the centre / rdiv, inline feature or 0).  The *_l1in_* entries are spacap_sa_mid_fwd_f32 /
+ * spacap_sa_wgrad_f32 / spacap_sa_dgrad_l1_f32 with z_prev = W1 in rebuilt from rel4 (W1 f32 [64, ldw], has_feat: column 3
+ * is used) with the statistics pass's own arithmetic, bit for bit. */
+int spacap_sa_l1_stats_f32(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, const float *W1,
+                           int ldw, float rdiv, int B, int Np, int N, int S, int C1, float *rel4, double *part,
+                           spacap_stream_t stream);
+int spacap_sa_mid_fwd_l1in_f32(const float *rel4, const float *W1, int ldw, int has_feat, const float *st_in, const float *W,
+                               long R, float *zout, double *part, spacap_stream_t stream);
+int spacap_sa_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *rel4, const float *W1, int ldw,
+                             int has_feat, const float *st_p, long R, float *partW, spacap_stream_t stream);
+int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *rel4,
+                             const float *W1, int ldw, int has_feat, const float *st_p, int B, int N, int S, double *part,
+                             float *part_l1, spacap_stream_t stream);
 /* partW f32 [spacap_sa_wgrad_slabs(R,CK,CP,arg != NULL), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
 int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *zp, const float *st_p, long R, int CK, int CP, float *partW,

@@ -72,6 +72,10 @@ SIGNATURES = {
     "spacap_caption_prep_bwd_f32": (_i, [_p] * 3 + [_i] * 5 + [_f, _u64, _p, _p, _p, _p]),
     "spacap_conv1x1_cm_supported": (_i, [_i, _i, _l]),
     "spacap_conv1x1_cm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
+    "spacap_sa_l1_stats_f32": (_i, [_p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_mid_fwd_l1in_f32": (_i, [_p, _p, _i, _i, _p, _p, _l, _p, _p, _p]),
+    "spacap_sa_wgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p]),
+    "spacap_sa_dgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
     "spacap_lab_stamp": (_i, [_p, _p]),
     "spacap_stream_delay": (_i, [_i, _p]),
     "spacap_sa_nparts": (_i, []),

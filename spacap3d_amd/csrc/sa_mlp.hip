@@ -47,12 +47,39 @@ __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4
 // ---- layer 1 forward --------------------------------------------------------------------------------------
 // z1[r, :] = Y[b, idx[r], :] + W1[:, 0:3] rel(r) + W1[:, 3] feat[b, idx[r]]      (Y and feat optional)
 // rel(r) = (xyz[b, idx[r]] - new_xyz[b, n]) / rdiv
+// First-layer pre-activation of one grouped row for four channels: z = wx rx + wy ry + wz rz (+ wf f), every operation rounded
+// separately and in this order.  ONE definition for the statistics pass and for every pass that rebuilds z1 from the row's four
+// inputs instead of reading it back (L1In): the values must agree bit for bit.
+__device__ __forceinline__ f32x4 l1_row(f32x4 wx, f32x4 wy, f32x4 wz, f32x4 wf, f32x4 in, bool has_feat) {
+  f32x4 z;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    z[u] = __fadd_rn(__fadd_rn(__fmul_rn(wx[u], in[0]), __fmul_rn(wy[u], in[1])), __fmul_rn(wz[u], in[2]));
+    if (has_feat) z[u] = __fadd_rn(z[u], __fmul_rn(wf[u], in[3]));
+  }
+  return z;
+}
+// z_prev = the first layer's pre-activation rebuilt from rel4 [R][4] (relative x, y, z, inline feature) and W1 [C][ldw]
+struct L1In {
+  const float *W1;
+  int ldw, has_feat;
+};
+__device__ __forceinline__ void l1_weights(const L1In &li, int c0, f32x4 &wx, f32x4 &wy, f32x4 &wz, f32x4 &wf) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float *w = li.W1 + (size_t)(c0 + u) * li.ldw;
+    wx[u] = w[0], wy[u] = w[1], wz[u] = w[2];
+    wf[u] = li.has_feat ? w[3] : 0.f;
+  }
+}
+
 template <int C1>
 __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict__ Y, const float *__restrict__ feat,
                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                         const int32_t *__restrict__ idx, const float *__restrict__ W1,
                                                         int ldw, float rdiv, int Np, int N, int S, long R,
-                                                        float *__restrict__ z1, double *__restrict__ part) {
+                                                        float *__restrict__ z1, double *__restrict__ part,
+                                                        float *__restrict__ rel4 = nullptr) {
   constexpr int C4 = C1 / 4, RP = 256 / C4;
   __shared__ float s_red[2][RP][C1];
   const int tid = threadIdx.x, c4 = tid % C4, rs = tid / C4;
@@ -77,9 +104,9 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
   auto row_z = [&](long rr, int p, long b) {
     const long g = rr / S;
     const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)g * 3;
-    const float rx = (q[0] - c[0]) / rdiv, ry = (q[1] - c[1]) / rdiv, rz = (q[2] - c[2]) / rdiv;
-    f32x4 z = wx * rx + wy * ry + wz * rz;
-    if (feat) z += wf * feat[(size_t)b * Np + p];
+    const f32x4 in = {(q[0] - c[0]) / rdiv, (q[1] - c[1]) / rdiv, (q[2] - c[2]) / rdiv, feat ? feat[(size_t)b * Np + p] : 0.f};
+    if (rel4 && c4 == 0) st4(rel4 + (size_t)rr * 4, in);   // the row's four inputs: what the later passes rebuild z1 from
+    f32x4 z = l1_row(wx, wy, wz, wf, in, feat != nullptr);
     if (Y) z += ld4(Y + ((size_t)b * Np + p) * C1 + c4 * 4);
     return z;
   };
@@ -94,7 +121,7 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
     for (int k = 0; k < UR; ++k) z[k] = row_z(r + k * G, p[k], b[k]);
 #pragma unroll
     for (int k = 0; k < UR; ++k) {
-      st4(z1 + (size_t)(r + k * G) * C1 + c4 * 4, z[k]);
+      if (z1) st4(z1 + (size_t)(r + k * G) * C1 + c4 * 4, z[k]);
       sum += z[k];
       sq += z[k] * z[k];
     }
@@ -104,7 +131,7 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
     long b;
     row_in(r, p, b);
     const f32x4 z = row_z(r, p, b);
-    st4(z1 + (size_t)r * C1 + c4 * 4, z);
+    if (z1) st4(z1 + (size_t)r * C1 + c4 * 4, z);
     sum += z;
     sq += z * z;
   }
@@ -205,7 +232,8 @@ struct TailArgs {
 template <int CIN, int NT, bool TAIL = false, int TMT = 64>
 __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict__ zin, const float *__restrict__ st_in,
                                                          const float *__restrict__ W, int Cout, long R,
-                                                         float *__restrict__ zout, double *__restrict__ part, TailArgs ta) {
+                                                         float *__restrict__ zout, double *__restrict__ part, TailArgs ta,
+                                                         L1In li = L1In{nullptr, 0, 0}) {
   // LD = CIN + 8 (== 8 mod 64 words) together with the K order below makes every ds_read_b128 of the B operand
   // conflict-free: MFMA step s of lane group lg (= lane / 16) uses channel kperm(s, lg); the four steps 4q..4q+3 of
   // a lane are 4 consecutive words, lg 0/1 (and 2/3) interleave in 4-word chunks, lg 0,1 own the first half of the
@@ -258,10 +286,12 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
     for (int i = 0; i < NV; ++i) {
       long grow = t * TMT + r0 + i * RSTEP;
       grow = grow < R ? grow : R - 1;
-      const float *src = zin + (size_t)grow * CIN + c4 * 4;
+      const float *src = li.W1 ? zin + (size_t)grow * 4 : zin + (size_t)grow * CIN + c4 * 4;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(pre[i]) : "v"(src) : "memory");
     }
   };
+  f32x4 l1x = {0.f, 0.f, 0.f, 0.f}, l1y = l1x, l1z = l1x, l1f = l1x;
+  if (li.W1) l1_weights(li, c4 * 4, l1x, l1y, l1z, l1f);
   auto wait_prefetch = [&](bool stores_pending) {
     if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -278,8 +308,9 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
       for (int i = 0; i < NV; ++i) {
         const int row = r0 + i * RSTEP;
         f32x4 a;
+        const f32x4 zv = li.W1 ? l1_row(l1x, l1y, l1z, l1f, pre[i], li.has_feat != 0) : pre[i];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = TAIL ? pre[i][u] : fmaxf((pre[i][u] - mean[u]) * sc[u] + be[u], 0.f);
+        for (int u = 0; u < 4; ++u) a[u] = TAIL ? zv[u] : fmaxf((zv[u] - mean[u]) * sc[u] + be[u], 0.f);
         if (!FULL && row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
         st4(&s_a[row * LD + c4 * 4], a);
       }
@@ -515,6 +546,8 @@ struct L1Args {
   float rdiv;
   int Np, N, S;
   float *part;  // [NPART][COB*8 + 4]
+  const float *rel4;   // optional: the rows' inputs as the statistics pass stored them; then z_prev is rebuilt, not read (zp unused)
+  L1In li;
 };
 
 template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS, bool L1 = false>
@@ -550,6 +583,8 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
   const long ntiles = (R + TM - 1) / TM, nfull = R / TM;
   float *s_rel = smem + (ALIAS ? TM * LD : TM * LD + TM * LDO);  // [TM][4] first-layer inputs of the tile's rows (L1)
   f32x4 q1[L1 ? 4 : 1], q3[L1 ? 4 : 1], q2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 l1x = {0.f, 0.f, 0.f, 0.f}, l1y = l1x, l1z = l1x, l1f = l1x;
+  if (L1 && L.rel4) l1_weights(L.li, cbb + o4 * 4, l1x, l1y, l1z, l1f);
   if (L1) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) q1[u] = q3[u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -607,7 +642,9 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     if (L1 && tid < TM) {
       f32x4 in = {0.f, 0.f, 0.f, 0.f};
       const long grow = row0 + tid;
-      if (FULL || grow < R) {
+      if ((FULL || grow < R) && L.rel4) {
+        in = ld4(L.rel4 + (size_t)grow * 4);
+      } else if (FULL || grow < R) {
         const long b = grow / ((long)L.N * L.S), gi = grow / L.S;
         const int p = L.idx[grow];
         const float *q = L.xyz + ((size_t)b * L.Np + p) * 3, *c = L.new_xyz + (size_t)gi * 3;
@@ -647,7 +684,9 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
       if (FULL || row0 + row < R) {
         const size_t o = (size_t)(row0 + row) * CP + cbb + o4 * 4;
         const f32x4 da = ld4(&s_o[row * LDO + o4 * 4]);
-        const f32x4 z = ld4(zp + o);
+        f32x4 z;
+        if (L1 && L.rel4) z = l1_row(l1x, l1y, l1z, l1f, ld4(&s_rel[row * 4]), L.li.has_feat != 0);
+        else z = ld4(zp + o);
         f32x4 d;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -736,7 +775,7 @@ template <int CKB, int CP, bool POOLED>
 __global__ __launch_bounds__(256) void sa_wgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
                                                        const float *__restrict__ zk, const float *__restrict__ coef, int CK,
                                                        const float *__restrict__ zp, const float *__restrict__ st_p, long R,
-                                                       float *__restrict__ partW) {
+                                                       float *__restrict__ partW, L1In li = L1In{nullptr, 0, 0}) {
   constexpr int LDZ = CKB + 16, LDA = CP + 16;
   constexpr int MT = CKB / 64, NTT = CP / 16;           // m-tiles per wave, n-tiles
   constexpr int Z4 = CKB / 4, A4 = CP / 4;
@@ -785,9 +824,11 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(const float *__restrict__
     for (int i = 0; i < NVA; ++i) {
       long grow = row0 + ar0 + i * RA;
       grow = grow < R ? grow : R - 1;
-      ra[i] = ld4(zp + (size_t)grow * CP + a4 * 4);
+      ra[i] = li.W1 ? ld4(zp + (size_t)grow * 4) : ld4(zp + (size_t)grow * CP + a4 * 4);
     }
   };
+  f32x4 l1x = {0.f, 0.f, 0.f, 0.f}, l1y = l1x, l1z = l1x, l1f = l1x;
+  if (li.W1) l1_weights(li, a4 * 4, l1x, l1y, l1z, l1f);
   if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const long row0 = t * TW;
@@ -809,8 +850,9 @@ __global__ __launch_bounds__(256) void sa_wgrad_kernel(const float *__restrict__
     for (int i = 0; i < NVA; ++i) {
       const int row = ar0 + i * RA;
       f32x4 a;
+      const f32x4 zv = li.W1 ? l1_row(l1x, l1y, l1z, l1f, ra[i], li.has_feat != 0) : ra[i];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = fmaxf((ra[i][u] - pm[u]) * ps[u] + pb[u], 0.f);
+      for (int u = 0; u < 4; ++u) a[u] = fmaxf((zv[u] - pm[u]) * ps[u] + pb[u], 0.f);
       if (row0 + row >= R) a = f32x4{0.f, 0.f, 0.f, 0.f};
       st4(&s_a[row * LDA + a4 * 4], a);
     }
@@ -1162,6 +1204,49 @@ extern "C" int spacap_sa_l1_fwd_f32(const float *Y, const float *feat, const flo
   return SPACAP_OK;
 }
 
+// The same pass WITHOUT the z1 store: the BatchNorm sums of the first layer and rel4 [R][4] = each grouped row's four inputs
+// (relative x, y, z / rdiv, inline feature or 0).  The later passes rebuild z1 from rel4 and W1 (spacap_sa_*_l1in_f32): 16 bytes
+// per row instead of 4 C1 written once and read three times.  Modules whose first layer also has point features (Y) keep z1.
+extern "C" int spacap_sa_l1_stats_f32(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, const float *W1,
+                                      int ldw, float rdiv, int B, int Np, int N, int S, int C1, float *rel4, double *part,
+                                      spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_stats_f32";
+  SPACAP_REQUIRE(B >= 1 && Np >= 1 && N >= 1 && S >= 1 && S <= 255, "%s: bad sizes", what);
+  SPACAP_REQUIRE(C1 == 64, "%s: C1=%d unsupported", what, C1);
+  SPACAP_REQUIRE(xyz && new_xyz && idx && W1 && rel4 && part && ldw >= (feat ? 4 : 3) && rdiv > 0.f, "%s: bad arguments", what);
+  const long R = (long)B * N * S;
+  hipLaunchKernelGGL((sa_l1_fwd_kernel<64>), dim3(NPART), dim3(256), 0, spacap::as_stream(stream), (const float *)nullptr, feat, xyz,
+                     new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, (float *)nullptr, part, rel4);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// Second layer (64 -> 64) reading rel4 instead of z1: z2 = relu(bn1(W1 in)) W2^T, BatchNorm sums of z2 in `part`
+extern "C" int spacap_sa_mid_fwd_l1in_f32(const float *rel4, const float *W1, int ldw, int has_feat, const float *st_in, const float *W,
+                                          long R, float *zout, double *part, spacap_stream_t stream) {
+  const char *what = "spacap_sa_mid_fwd_l1in_f32";
+  SPACAP_REQUIRE(rel4 && W1 && st_in && W && zout && part && R >= 1 && ldw >= (has_feat ? 4 : 3), "%s: bad arguments", what);
+  const size_t lds = (size_t)TM * ((64 + 8) + (64 + 4)) * sizeof(float);
+  const long tiles = (R + TM - 1) / TM;
+  static const int res = resident_blocks(sa_mid_fwd_kernel<64, 1, false>, lds);
+  hipLaunchKernelGGL((sa_mid_fwd_kernel<64, 1, false>), dim3(grid_rows(res, 1, tiles), 1), dim3(256), lds, spacap::as_stream(stream),
+                     rel4, st_in, W, 64, R, zout, part, TailArgs{}, L1In{W1, ldw, has_feat});
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// Weight gradient of the second layer (64 x 64, dense) with a_prev = relu(bn1(W1 in)) rebuilt from rel4
+extern "C" int spacap_sa_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *rel4, const float *W1, int ldw,
+                                        int has_feat, const float *st_p, long R, float *partW, spacap_stream_t stream) {
+  const char *what = "spacap_sa_wgrad_l1in_f32";
+  SPACAP_REQUIRE(dy && zk && coef && rel4 && W1 && st_p && partW && R >= 1 && ldw >= (has_feat ? 4 : 3), "%s: bad arguments", what);
+  const int nslab = spacap_sa_wgrad_slabs(R, 64, 64, 0);
+  hipLaunchKernelGGL((sa_wgrad_kernel<64, 64, false>), dim3(nslab, 1), dim3(256), 0, spacap::as_stream(stream), dy, (const uint8_t *)nullptr,
+                     0, zk, coef, 64, rel4, st_p, R, partW, L1In{W1, ldw, has_feat});
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 extern "C" int spacap_sa_bn_finalize_f32(const double *part, int C, long count, float eps, float momentum,
                                          const float *gamma, const float *beta, float *running_mean,
                                          float *running_var, float *stats, spacap_stream_t stream) {
@@ -1440,9 +1525,26 @@ extern "C" int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const fl
   hipStream_t s = spacap::as_stream(stream);
   const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
   static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
-  L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1};
+  L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1, nullptr, L1In{nullptr, 0, 0}};
   hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(res, 1, (R + TM - 1) / TM), 1),
                      dim3(256), lds, s, dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, CP, zp, st_p, R, (float *)nullptr, part, L);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// spacap_sa_dgrad_l1_f32 with the rows' inputs read from rel4 and z1 rebuilt from them (nothing of size R x 64 is read but dy, zk)
+extern "C" int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *rel4,
+                                        const float *W1, int ldw, int has_feat, const float *st_p, int B, int N, int S, double *part,
+                                        float *part_l1, spacap_stream_t stream) {
+  const char *what = "spacap_sa_dgrad_l1in_f32";
+  SPACAP_REQUIRE(dy && zk && coef && Wk && rel4 && W1 && st_p && part && part_l1 && ldw >= (has_feat ? 4 : 3), "%s: bad arguments", what);
+  const long R = (long)B * N * S;
+  const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
+  static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
+  L1Args L{nullptr, nullptr, nullptr, nullptr, 1.f, 1, N, S, part_l1, rel4, L1In{W1, ldw, has_feat}};
+  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(res, 1, (R + TM - 1) / TM), 1),
+                     dim3(256), lds, spacap::as_stream(stream), dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, 64, (const float *)nullptr,
+                     st_p, R, (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

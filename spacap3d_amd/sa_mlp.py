@@ -13,6 +13,10 @@ from .layout import ChannelMajorOf, point_major_of
 from ._native import check, lib, sum_slabs
 
 
+# SA1-shaped modules (no point features, 64 -> 64 -> ...): do not store the first layer's pre-activation (see _SAMLP.forward)
+RECOMPUTE_Z1 = True
+
+
 def _ptr(t):
     return t.data_ptr() if t is not None else None
 
@@ -42,7 +46,11 @@ class _SAMLP(Function):
         with torch.cuda.device(dev):
             part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
             stats = [torch.empty(c, 4, **f32) for c in (C1, C2, C3)]
-            z1 = torch.empty(R, C1, **f32)
+            # SA1 (no point features, 64 -> 64): z1 never exists in HBM; the statistics pass leaves the rows' four inputs
+            # (16 bytes per row) and every later pass rebuilds z1 from them (csrc/sa_mlp.hip: L1In)
+            recompute = RECOMPUTE_Z1 and Y is None and C1 == 64 and C2 == 64 and not (xyz.requires_grad or new_xyz.requires_grad)
+            has_feat = int(feat is not None)
+            z1 = torch.empty(R, 4 if recompute else C1, **f32)
             z2 = torch.empty(R, C2, **f32)
             z3 = torch.empty(R, C3, **f32)
 
@@ -58,12 +66,21 @@ class _SAMLP(Function):
                                                     _ptr(bn.running_var if track else None), stats[k].data_ptr(), st),
                       "spacap_sa_bn_finalize_f32")
 
-            check(lib.spacap_sa_l1_fwd_f32(_ptr(Y), _ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
-                                           W1c.data_ptr(), W1c.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(),
-                                           part.data_ptr(), st), "spacap_sa_l1_fwd_f32")
-            finalize(0, C1, g1, b1)
-            check(lib.spacap_sa_mid_fwd_f32(z1.data_ptr(), stats[0].data_ptr(), W2c.data_ptr(), R, C1, C2, z2.data_ptr(),
-                                            part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
+            if recompute:
+                check(lib.spacap_sa_l1_stats_f32(_ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), W1c.data_ptr(),
+                                                 W1c.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(), part.data_ptr(), st),
+                      "spacap_sa_l1_stats_f32")
+                finalize(0, C1, g1, b1)
+                check(lib.spacap_sa_mid_fwd_l1in_f32(z1.data_ptr(), W1c.data_ptr(), W1c.shape[1], has_feat, stats[0].data_ptr(),
+                                                     W2c.data_ptr(), R, z2.data_ptr(), part.data_ptr(), st),
+                      "spacap_sa_mid_fwd_l1in_f32")
+            else:
+                check(lib.spacap_sa_l1_fwd_f32(_ptr(Y), _ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+                                               W1c.data_ptr(), W1c.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(),
+                                               part.data_ptr(), st), "spacap_sa_l1_fwd_f32")
+                finalize(0, C1, g1, b1)
+                check(lib.spacap_sa_mid_fwd_f32(z1.data_ptr(), stats[0].data_ptr(), W2c.data_ptr(), R, C1, C2, z2.data_ptr(),
+                                                part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
             finalize(1, C2, g2, b2)
             out = torch.empty(B, N, C3, **f32)
             arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
@@ -91,6 +108,7 @@ class _SAMLP(Function):
         ctx.rdiv = float(rdiv)
         ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
         ctx.has_Y = Y is not None
+        ctx.recompute = recompute     # z1 in the saved tuple is then rel4 (R, 4)
         ctx.need_xyz = xyz.requires_grad or new_xyz.requires_grad
         return out
 
@@ -133,18 +151,29 @@ class _SAMLP(Function):
             finalize(1, C2, st2)
             # layer 2
             pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)
-            check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
-                                          st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+            has_feat = int(feat is not None)
+            if ctx.recompute:
+                check(lib.spacap_sa_wgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(), W1.data_ptr(),
+                                                   W1.shape[1], has_feat, st1.data_ptr(), R, pw.data_ptr(), st),
+                      "spacap_sa_wgrad_l1in_f32")
+            else:
+                check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
+                                              st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
             dW2 = sum_slabs(pw, deferrable=True)
             fuse_l1 = (not ctx.has_Y) and (not ctx.need_xyz) and C1 == 64 and C2 == 64
             if fuse_l1:
                 # SA1: the first layer's weight gradient comes out of this kernel's epilogue as three sums
                 # (csrc/sa_mlp.hip, L1Args); dy1 is never written and the first-layer backward pass is skipped
                 pl1 = torch.empty(nparts, C1 * 8 + 4, **f32)
-                check(lib.spacap_sa_dgrad_l1_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
-                                                 z1.data_ptr(), st1.data_ptr(), _ptr(feat), xyz.data_ptr(),
-                                                 new_xyz.data_ptr(), idx.data_ptr(), ctx.rdiv, B, Np, N, S, C2, C1,
-                                                 part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1_f32")
+                if ctx.recompute:
+                    check(lib.spacap_sa_dgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
+                                                       z1.data_ptr(), W1.data_ptr(), W1.shape[1], has_feat, st1.data_ptr(), B, N, S,
+                                                       part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1in_f32")
+                else:
+                    check(lib.spacap_sa_dgrad_l1_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
+                                                     z1.data_ptr(), st1.data_ptr(), _ptr(feat), xyz.data_ptr(),
+                                                     new_xyz.data_ptr(), idx.data_ptr(), ctx.rdiv, B, Np, N, S, C2, C1,
+                                                     part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1_f32")
                 del dy2
                 finalize(0, C1, st1)
                 P = pl1.double().sum(0)

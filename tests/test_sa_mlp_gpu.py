@@ -189,6 +189,37 @@ def test_rows_scatter_sums_in_ascending_row_order(B, Np, E):
     assert np.array_equal(out.cpu().numpy().reshape(B * Np, C), want)
 
 
+@pytest.mark.parametrize("C,npoint,nsample,n", [(1, 512, 64, 6000), (0, 200, 32, 3000), (1, 77, 16, 1000)])
+def test_first_layer_rebuilt_instead_of_stored(C, npoint, nsample, n, monkeypatch):
+    """SA1-shaped modules (3 relative coordinates + at most one inline feature, 64 -> 64 -> 128): with sa_mlp.RECOMPUTE_Z1 the
+    first layer's pre-activation is never written -- the statistics pass leaves 16 bytes per row and the second layer, its weight
+    gradient and the fused first-layer backward rebuild z1 with the same arithmetic.  Outputs, BatchNorm buffers and every
+    gradient must equal the stored-z1 path bit for bit (row counts that are not multiples of the tiles included)."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd import sa_mlp
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(11)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=0.3, nsample=nsample, mlp=[C, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    pc = S.scene_batch(2, n, use_height=C == 1, seed=4).to(DEV)
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous() if C else None
+    inds = pu.furthest_point_sample(xyz, npoint)
+    res = []
+    for mod, flag in ((sa, True), (sb, False)):
+        monkeypatch.setattr(sa_mlp, "RECOMPUTE_Z1", flag)
+        _, out, _ = mod(xyz, feats, inds)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        (out * w).sum().backward()
+        res.append(out)
+    assert torch.equal(res[0], res[1])
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+        assert torch.equal(pa.grad, pb.grad), na
+    for (na, ba), (nb, bb) in zip(sa.named_buffers(), sb.named_buffers()):
+        assert torch.equal(ba, bb), na
+
+
 def test_unsupported_mlp_uses_the_per_operator_path():
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
     from spacap3d_amd import sa_mlp

@@ -54,6 +54,20 @@ def sa_mid_fwd(R, cin, cout, dev, label):
                 what=f"{label}: z_out = relu(bn(z_in)) W^T + batch statistics of z_out, {R} rows, {cin} -> {cout} channels")
 
 
+def sa_mid_fwd_l1in(R, dev, label):
+    """SA1 layer 2 as the step runs it since round 3: z1 rebuilt from the rows' four inputs (16 B per row) instead of read."""
+    rel4, W1, st, W = _rand(R, 4, dev=dev), _rand(64, 4, dev=dev), _stats(64, dev), _rand(64, 64, dev=dev) * 0.1
+    zout, part = torch.empty(R, 64, dtype=torch.float32, device=dev), _part(64, dev)
+
+    def run():
+        check(lib.spacap_sa_mid_fwd_l1in_f32(rel4.data_ptr(), W1.data_ptr(), 4, 1, st.data_ptr(), W.data_ptr(), R, zout.data_ptr(),
+                                             part.data_ptr(), _st(dev)), "sa_mid_fwd_l1in")
+    return dict(name=f"sa_mid_fwd 64->64 R={R} ({label}, z1 rebuilt)", kernel="sa_mid_fwd", run=run, bf16_products=0,
+                flops=2.0 * 64 * 64 * R, bytes=4.0 * R * (4 + 64), keep=(rel4, W1, st, W, zout, part),
+                what=f"{label}: z2 = relu(bn(W1 in)) W2^T + batch statistics, {R} rows; reads 16 B per row (the row's inputs), "
+                     "writes z2: z1 (268 MB at SA1) is neither written nor read")
+
+
 def sa_dgrad(R, ck, cp, pooled, S, dev, label):
     G = R // S
     dy = _rand(G if pooled else R, ck, dev=dev)
@@ -193,6 +207,7 @@ def cases(dev, B=8):
         lambda: sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3"),
         lambda: sa_mid_fwd(R2, 128, 128, dev, "SA2 layer 2"),
         lambda: sa_mid_fwd(R1, 64, 64, dev, "SA1 layer 2"),
+        lambda: sa_mid_fwd_l1in(R1, dev, "SA1 layer 2"),
         lambda: sa_mid_fwd(R1, 64, 128, dev, "SA1 layer 3"),
         lambda: sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
         lambda: sa_dgrad(R2, 128, 128, False, 32, dev, "SA2 layer 2"),
