@@ -5,10 +5,14 @@ boxes, with no per-item host work on the points.
 
 Mirror of ``ScannetReferenceDataset`` (lib/dataset.py:247-531) for the ScanRefer training path: ``use_height`` /
 ``use_normal`` / ``use_color`` / ``use_multiview`` / ``augment`` / ``use_relation``, output channels in the reference's
-order xyz, [rgb], [normal], [multiview 128], [height] (:309-333).  Colour keeps the reference's quirk: its
+order xyz, [rgb], [normal], [multiview 128], [height] (:309-333).  Colour: the reference's
 ``point_cloud[:, 3:6] = (point_cloud[:, 3:6] - MEAN_COLOR_RGB) / 256.0`` writes through a VIEW into the cached scene
-(:312-315), so a scene's colours are normalised once more on every access; here the per-scene colour tensor in HBM is
-re-normalised in place per visit, item by item (float64 arithmetic, float32 store, as numpy does).  Multiview rows
+(:312-315), so a scene's colours are normalised once more on every access -- within one DataLoader worker and one epoch,
+because its workers are re-forked from an unmodified parent every epoch.  ``color_renorm="once"`` (the default) normalises a
+scene's colours once, when it is added; ``color_renorm="per_access"`` reproduces the quirk (the per-scene colour tensor in HBM
+is re-normalised in place per visit, item by item: float64 arithmetic, float32 store, as numpy does) for parity with the
+reference's items, and ``reset_colors()`` restores the loaded colours (call it at epoch start to get the reference's per-epoch
+reset instead of colours that collapse towards -mean / 256 for the rest of training).  Multiview rows
 (``enet_feats_maxpool.hdf5``: N x 128 float32 per scene, :321-328) are handed over per scene and stay resident: all
 1 513 scenes are ~116 GB of the 288 GB.
 Same keys, dtypes and shapes as the reference's ``data_dict`` with a leading batch dimension (what its DataLoader's
@@ -47,7 +51,10 @@ def _rot(axis, t):
 class DeviceSceneDataset:
     def __init__(self, device, mean_size_arr, nyu40id2class, raw2label=None, num_points=40000, use_height=True,
                  use_normal=False, augment=True, use_relation=True, max_instances=1024, use_color=False,
-                 use_multiview=False):
+                 use_multiview=False, color_renorm="once"):
+        if color_renorm not in ("once", "per_access"):
+            raise ValueError("color_renorm must be 'once' or 'per_access'")
+        self.color_renorm = color_renorm
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("CPU not supported")
@@ -74,6 +81,18 @@ class DeviceSceneDataset:
         self._scenes = []       # per scene: the big per-vertex tensors (kept alive here; the kernels get pointers)
         self._items = []
         self._tables = None     # stacked per-scene / per-item label tables, built lazily by _finalize()
+
+    def _loaded_color(self, vert):
+        col = torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(self.device)
+        if self.use_color and self.color_renorm == "once":   # (without use_color the reference never normalises: pcl_color stays raw)
+            col = ((col.double() - self._mean_rgb) / 256.0).float()
+        return col
+
+    def reset_colors(self):
+        """``color_renorm="per_access"``: back to the colours as loaded (the reference's state at the start of every epoch)."""
+        if self.color_renorm == "per_access":
+            for sc in self._scenes:
+                sc["color"].copy_(sc["color0"])
 
     # ---- loading -----------------------------------------------------------------------------------------------
     def add_scene(self, scene_id, vert, ins, sem, bbox, x=None, y=None, z=None, multiview=None):
@@ -104,7 +123,7 @@ class DeviceSceneDataset:
         self._scene_index[scene_id] = len(self._scenes)
         self._scenes.append({
             "feat": torch.as_tensor(np.ascontiguousarray(pc, dtype=np.float32)).to(d),
-            "color": torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(d),
+            "color": self._loaded_color(vert), "color0": torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(d),
             "ins": torch.as_tensor(np.asarray(ins).astype(np.int32)).to(d),
             "isobj": torch.as_tensor(np.isin(np.asarray(sem), NYU40IDS).astype(np.uint8)).to(d),
             "n": int(vert.shape[0]), "nb": nb, "box8": box8, "rel": rel,
@@ -241,7 +260,7 @@ class DeviceSceneDataset:
         with torch.cuda.device(dev):
             ptrs = t["ptrs"][sidx].t().contiguous()                                        # (5,B) device pointers
             color_ptrs = ptrs[3]
-            if self.use_color:
+            if self.use_color and self.color_renorm == "per_access":
                 # the reference normalises the CACHED colours of the scene on every access (see the module docstring):
                 # visit the items in order; an item whose scene comes up again later in this batch keeps a snapshot
                 order = [int(i) for i in indices]

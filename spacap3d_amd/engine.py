@@ -176,7 +176,11 @@ class Trainer:
                 bns += [l for l in m.proposal if isinstance(l, torch.nn.BatchNorm1d)]
             elif isinstance(m, PositionalEncodingLearned):
                 bns.append(m.position_embedding_head[1])
-        bns = [b for b in bns if b.track_running_stats and b.num_batches_tracked is not None and b.momentum is not None]
+        # ... and only those the discovery pass of _setup actually saw on the fused path: a layer that fell back to the stock
+        # nn.BatchNorm (unsupported widths, a backend without the fused op) increments its own buffer and would count twice
+        from .fused_bn import FUSED_SEEN
+        bns = [b for b in bns if b.track_running_stats and b.num_batches_tracked is not None and b.momentum is not None
+               and b in FUSED_SEEN]
         if not bns or not bns[0].num_batches_tracked.is_cuda:
             return
         flat = torch.stack([b.num_batches_tracked.detach() for b in bns]).contiguous()
@@ -391,7 +395,14 @@ class Trainer:
             for mod in self.model.modules():
                 if hasattr(mod, "attn") and hasattr(mod, "keep_value"):
                     mod.attn, mod.value = None, None
-            self._capture(static, warmup=0)
+            try:
+                self._capture(static, warmup=0)
+            except Exception as e:  # noqa: BLE001 -- as in enable_graph: a failed capture means "stay eager", not a dead Trainer
+                self.graph, self._static, self._static_loss, self._recapture = None, None, None, False
+                import traceback
+                self.graph_error = f"{type(e).__name__}: {str(e)[:300]}\n" + "".join(traceback.format_tb(e.__traceback__)[-6:])
+                torch.cuda.synchronize(data_dict["point_clouds"].device)
+                return self.step(data_dict, next_data)
         pre = data_dict.pop("_fps_prefetch", None)
         static_pyr = self._static.get("fps_pyramid")
         dsts, srcs = [], []

@@ -83,10 +83,17 @@ class BNReLU(Function):
         return dz, dg, db, None, None, None, None, None
 
 
+# BatchNorm modules whose training forward went through the fused ops (i.e. through bump_counter): only those may hand their
+# counter to a training engine -- a layer on the stock nn.BatchNorm fallback increments its own buffer
+import weakref
+FUSED_SEEN = weakref.WeakSet()
+
+
 def bump_counter(bn):
     """bn.num_batches_tracked += 1 -- unless a training engine has taken the counter over (the buffer then carries the
     attribute ``_spacap_deferred``: engine.Trainer._adopt_bn_counters bumps all of them with one add per step instead
     of one tiny launch per layer; with momentum set the counter never enters the arithmetic)."""
+    FUSED_SEEN.add(bn)
     t = bn.num_batches_tracked
     if bn.track_running_stats and t is not None and not getattr(t, "_spacap_deferred", False):
         t.add_(1)

@@ -110,7 +110,7 @@ def _device_dataset_feats(fx, num_points, **kw):
     from tests.test_scene_pipeline import multiview_rows
     ds = DeviceSceneDataset(DEV, fx["mean_size_arr"], dict(zip(fx["nyu40id2class_keys"].tolist(), fx["nyu40id2class_vals"].tolist())),
                             dict(zip(fx["raw2label_names"].tolist(), fx["raw2label_vals"].tolist())), num_points=num_points,
-                            max_instances=64, **kw)
+                            max_instances=64, color_renorm="per_access", **kw)   # (the fixture holds the reference's items, quirk included)
     for sid in fx["scene_ids"].tolist():
         v = fx[f"{sid}/vert"]
         ds.add_scene(sid, v, fx[f"{sid}/ins"], fx[f"{sid}/sem"], fx[f"{sid}/bbox"], fx[f"{sid}/x"], fx[f"{sid}/y"], fx[f"{sid}/z"],
@@ -168,3 +168,26 @@ def test_a_batch_that_repeats_a_scene_sees_successive_colour_states():
         assert np.array_equal(d["pcl_color"][b].cpu().numpy(), want["pcl_color"]), (b, i)
     a, c = d["pcl_color"][0].std(0).max(), d["pcl_color"][2].std(0).max()
     assert float(a) > 100 * float(c) > 0
+
+
+def test_colours_normalised_once_by_default_and_resettable_in_the_parity_mode():
+    """with ``color_renorm="once"`` two visits of a scene return the same colours, (raw - mean) / 256; the
+    parity mode normalises once more per visit and ``reset_colors()`` restores the loaded state."""
+    fx, _ = load_fixture()
+    kw = dict(use_color=True, use_normal=True, use_multiview=False)
+    ds = _device_dataset_feats(fx, 2000, **kw)
+    ds.color_renorm = "once"          # rebuild the colour tensors the way the default does
+    for sc in ds._scenes:
+        sc["color"].copy_(((sc["color0"].double() - ds._mean_rgb) / 256.0).float())
+    g = torch.Generator(device=DEV).manual_seed(1)
+    draws = ds.draw([0], g)
+    a = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
+    b = ds.batch([0], draws=draws)["point_clouds"][..., 3:6]
+    assert torch.equal(a, b) and float(a.abs().max()) <= 1.0
+    ds.color_renorm = "per_access"
+    c = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
+    assert not torch.equal(a, c)                       # normalised a second time
+    ds.reset_colors()
+    d = ds.batch([0], draws=draws)["point_clouds"][..., 3:6]
+    assert torch.equal(d, a)                           # loaded colours, normalised once by this visit
+
