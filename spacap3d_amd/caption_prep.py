@@ -43,6 +43,7 @@ class CaptionPrep(Function):
         ctx.save_for_backward(tok, idx)
         ctx.dims = (B, K, D, T, V, float(p), int(seed), memory is not None)
         ctx.mark_non_differentiable(mask, idx, dist, good, pred)
+        ctx.set_materialize_grads(False)   # no zero tensors for the five index / scalar outputs' gradients
         return x0, mask, idx, dist, good, pred
 
     @staticmethod

@@ -152,6 +152,7 @@ class CaptionHeadLoss(Function):
                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_cap_loss_fwd_f32")
         ctx.save_for_backward(logp, ids, g8, out)
         ctx.mark_non_differentiable(logp)
+        ctx.set_materialize_grads(False)   # no zero tensor for the log-probabilities' gradient
         return logp, out
 
     @staticmethod
@@ -244,6 +245,7 @@ class LossTail(Function):
                                                torch.cuda.current_stream(dev).cuda_stream), "spacap_loss_tail_fwd_f32")
         ctx.has_rel = rel is not None
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # no zero tensor for the log entries' gradient
         return loss, out
 
     @staticmethod
