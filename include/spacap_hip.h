@@ -383,6 +383,10 @@ int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const float *coef, 
                            const float *st_p, const float *feat, const float *xyz, const float *new_xyz,
                            const int32_t *idx, float rdiv, int B, int Np, int N, int S, int CK, int CP, double *part,
                            float *part_l1, spacap_stream_t stream);
+/* dW1 of spacap_sa_dgrad_l1[in]_f32's three sums: part_l1 f32 [nparts, C1*8+4], coef f32 [C1,4] (g, k0, k1 of layer 1) ->
+ * dW1 f32 [C1, ldw] (ldw <= 4 columns: relative x, y, z, inline feature), partials added in double. */
+int spacap_sa_l1_dw_f32(const float *part_l1, int nparts, const float *coef, int C1, int ldw, float *dW1, spacap_stream_t stream);
+
 /* The SA1 family without z1 in HBM (first layer: 3 relative coordinates + at most one inline feature, no point features;
  * C1 = C2 = 64; lib/pointnet2/pointnet2_modules.py:241-259 with pytorch_utils.py:11-36).  spacap_sa_l1_stats_f32 is
  * spacap_sa_l1_fwd_f32 without the z1 store: the BatchNorm sums in `part` and rel4 f32 [R,4] = each grouped row's inputs

@@ -1549,6 +1549,37 @@ extern "C" int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const 
   return SPACAP_OK;
 }
 
+// dW1 of the fused first-layer backward from its three sums (L1Args): part_l1 [nparts][C1 * 8 + 4] = per workgroup
+// (S1 [C1][4] | S3 [C1][4]) interleaved per channel as [c][2][4], then S2 [4]; coef [C1][4] = (g, k0, k1, .) of layer 1:
+//   dW1[c][d] = g[c] S1[c][d] + k0[c] S2[d] - k1[c] S3[c][d],  sums over the partials in double, d < ldw columns written.
+namespace {
+__global__ __launch_bounds__(1024) void sa_l1_dw_kernel(const float *__restrict__ part_l1, int nparts, const float *__restrict__ coef,
+                                                        int C1, int ldw, float *__restrict__ dW1) {
+  extern __shared__ double s_sum[];   // [C1 * 8 + 4]
+  const int n = C1 * 8 + 4;
+  for (int e = threadIdx.x; e < n; e += 1024) {
+    double a = 0.0;
+    for (int p = 0; p < nparts; ++p) a += (double)part_l1[(size_t)p * n + e];
+    s_sum[e] = a;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < C1 * ldw; e += 1024) {
+    const int c = e / ldw, d = e - c * ldw;
+    const double g = coef[c * 4 + 0], k0 = coef[c * 4 + 1], k1 = coef[c * 4 + 2];
+    dW1[e] = (float)(g * s_sum[(c * 2 + 0) * 4 + d] + k0 * s_sum[C1 * 8 + d] - k1 * s_sum[(c * 2 + 1) * 4 + d]);
+  }
+}
+}  // namespace
+extern "C" int spacap_sa_l1_dw_f32(const float *part_l1, int nparts, const float *coef, int C1, int ldw, float *dW1,
+                                   spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_dw_f32";
+  SPACAP_REQUIRE(part_l1 && coef && dW1 && nparts >= 1 && C1 >= 1 && C1 <= 512 && ldw >= 1 && ldw <= 4, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_l1_dw_kernel, dim3(1), dim3(1024), (size_t)(C1 * 8 + 4) * sizeof(double), spacap::as_stream(stream), part_l1,
+                     nparts, coef, C1, ldw, dW1);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // partW: [spacap_sa_wgrad_slabs(R,CK,CP,pooled)][CK][CP] partial weight gradients, summed by the caller in slab order
 extern "C" int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                                    const float *zp, const float *st_p, long R, int CK, int CP, float *partW,

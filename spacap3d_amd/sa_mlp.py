@@ -176,11 +176,9 @@ class _SAMLP(Function):
                                                      part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1_f32")
                 del dy2
                 finalize(0, C1, st1)
-                P = pl1.double().sum(0)
-                S13 = P[:C1 * 8].view(C1, 2, 4)
-                cf = coef[0].double()
-                dW1 = (cf[:, 0:1] * S13[:, 0] + cf[:, 1:2] * P[C1 * 8:].view(1, 4) - cf[:, 2:3] * S13[:, 1]).float()
-                dW1 = dW1[:, :W1.shape[1]].contiguous()
+                dW1 = torch.empty(C1, W1.shape[1], **f32)     # = g S1 + k0 S2 - k1 S3 from the kernel's three sums, one launch
+                check(lib.spacap_sa_l1_dw_f32(pl1.data_ptr(), nparts, coef[0].data_ptr(), C1, W1.shape[1], dW1.data_ptr(), st),
+                      "spacap_sa_l1_dw_f32")
                 return (None, None, None, None, None, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
             dy1 = torch.empty(R, C1, **f32)
             check(lib.spacap_sa_dgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
