@@ -708,6 +708,15 @@ int spacap_conv1x1_cm_supported(int CI, int CO, long N);
 int spacap_conv1x1_cm_f32(int mode, const float *W, const float *in, const float *bias, int B, int CI, int CO, long N,
                           float *out, spacap_stream_t stream);
 
+/* Votes from the voting module's last convolution (models/voting_module.py:49-60, vote_factor 1): net f32 [B, 3+C, N]
+ * channel-major, seed_xyz f32 [B,N,3], seed_feat f32 [B,C,N] -> vote_xyz f32 [B,N,3] = seed_xyz + net[:, 0:3]^T and
+ * vote_feat f32 [B,N,C] (point-major) = seed_feat^T + net[:, 3:]^T.  Backward: g_xyz [B,N,3] / g_feat [B,N,C] (either may
+ * be NULL = zero) -> d_net f32 [B, 3+C, N] and d_seed f32 [B,C,N] (= d_net[:, 3:]; may be NULL). */
+int spacap_vote_assemble_fwd_f32(const float *net, const float *seed_xyz, const float *seed_feat, int B, int C, int N,
+                                 float *vote_xyz, float *vote_feat, spacap_stream_t stream);
+int spacap_vote_assemble_bwd_f32(const float *g_xyz, const float *g_feat, int B, int C, int N, float *d_net, float *d_seed,
+                                 spacap_stream_t stream);
+
 /* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
 int spacap_stream_delay(int microseconds, spacap_stream_t stream);
 

@@ -38,6 +38,7 @@ class HipBackend:
         self.loss_tail = _fl.loss_tail
         self.proposal_decode = _fl.proposal_decode
         self.l2norm_rows = _fl.l2norm_rows
+        self.vote_assemble = _fl.vote_assemble
         from . import fused_dropout as _fd
         self.relu_dropout = _fd.relu_dropout
         self.dropout_add = _fd.dropout_add

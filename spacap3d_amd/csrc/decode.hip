@@ -136,3 +136,85 @@ extern "C" int spacap_proposal_decode_bwd_f32(const float *g_nt, const float *g_
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ---- votes from the voting module's last convolution (models/voting_module.py:49-60) ---------------------------------------
+// net f32 [B, 3 + C, N] (channel-major conv output, vote_factor 1), seed_xyz f32 [B, N, 3], seed_features f32 [B, C, N] ->
+//   vote_xyz [B, N, 3] = seed_xyz + net[:, 0:3]^T,   vote_features [B, N, C] (point-major) = seed_features^T + net[:, 3:]^T
+// As tensor operations: a transposed view, two slices, two broadcast adds, two contiguous copies forward, and slice / add /
+// transpose copies with zero fills in the backward.  32 x 32 tiles through LDS, reads coalesced over n, writes over c.
+namespace {
+__global__ __launch_bounds__(256) void vote_assemble_fwd_kernel(const float *__restrict__ net, const float *__restrict__ seed_xyz,
+                                                                const float *__restrict__ seed_feat, int C, int N,
+                                                                float *__restrict__ vote_xyz, float *__restrict__ vote_feat) {
+  __shared__ float s[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float *nb = net + (size_t)b * (3 + C) * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, n = n0 + tx;
+    s[ty + 8 * i][tx] = (c < C && n < N) ? seed_feat[((size_t)b * C + c) * N + n] + nb[(size_t)(3 + c) * N + n] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, c = c0 + tx;
+    if (n < N && c < C) vote_feat[((size_t)b * N + n) * C + c] = s[tx][ty + 8 * i];
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 96) {
+    const int n = n0 + threadIdx.x / 3, k = threadIdx.x % 3;
+    if (n < N) vote_xyz[((size_t)b * N + n) * 3 + k] = seed_xyz[((size_t)b * N + n) * 3 + k] + nb[(size_t)k * N + n];
+  }
+}
+
+// d net [B, 3 + C, N] and d seed_features [B, C, N] (= d net[:, 3:]) from g_xyz [B, N, 3] (may be null: zeros) and g_feat [B, N, C]
+__global__ __launch_bounds__(256) void vote_assemble_bwd_kernel(const float *__restrict__ g_xyz, const float *__restrict__ g_feat,
+                                                                int C, int N, float *__restrict__ d_net, float *__restrict__ d_seed) {
+  __shared__ float s[32][33];
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float *nb = d_net + (size_t)b * (3 + C) * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + 8 * i, c = c0 + tx;
+    s[ty + 8 * i][tx] = (n < N && c < C && g_feat) ? g_feat[((size_t)b * N + n) * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, n = n0 + tx;
+    if (c < C && n < N) {
+      const float v = s[tx][ty + 8 * i];
+      nb[(size_t)(3 + c) * N + n] = v;
+      if (d_seed) d_seed[((size_t)b * C + c) * N + n] = v;
+    }
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 96) {
+    const int k = threadIdx.x >> 5, n = n0 + (threadIdx.x & 31);
+    if (n < N) nb[(size_t)k * N + n] = g_xyz ? g_xyz[((size_t)b * N + n) * 3 + k] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int spacap_vote_assemble_fwd_f32(const float *net, const float *seed_xyz, const float *seed_feat, int B, int C, int N,
+                                            float *vote_xyz, float *vote_feat, spacap_stream_t stream) {
+  const char *what = "spacap_vote_assemble_fwd_f32";
+  SPACAP_REQUIRE(B >= 0 && C >= 1 && N >= 1 && B <= 65535, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(net && seed_xyz && seed_feat && vote_xyz && vote_feat, "%s: null pointer", what);
+  hipLaunchKernelGGL(vote_assemble_fwd_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0, spacap::as_stream(stream), net,
+                     seed_xyz, seed_feat, C, N, vote_xyz, vote_feat);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_vote_assemble_bwd_f32(const float *g_xyz, const float *g_feat, int B, int C, int N, float *d_net, float *d_seed,
+                                            spacap_stream_t stream) {
+  const char *what = "spacap_vote_assemble_bwd_f32";
+  SPACAP_REQUIRE(B >= 0 && C >= 1 && N >= 1 && B <= 65535, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(d_net, "%s: null pointer", what);
+  hipLaunchKernelGGL(vote_assemble_bwd_kernel, dim3((N + 31) / 32, (C + 31) / 32, B), dim3(256), 0, spacap::as_stream(stream), g_xyz,
+                     g_feat, C, N, d_net, d_seed);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+

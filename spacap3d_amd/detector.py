@@ -196,6 +196,11 @@ def _conv(conv, x, training):
     return conv(x) if y is None else y
 
 
+def _ops():
+    from .backend import ops
+    return ops()
+
+
 class VotingModule(nn.Module):
     """Conv1d 256->256->256->(3+256)*vote_factor with BN+ReLU on the first two, residual votes
     (voting_module.py:28-61)."""
@@ -217,6 +222,11 @@ class VotingModule(nn.Module):
         net = _bn_relu(self.bn1, _conv(self.conv1, seed_features, self.training), self.training)
         net = _bn_relu(self.bn2, _conv(self.conv2, net, self.training), self.training)
         net = self.conv3(net)
+        fused = getattr(_ops(), "vote_assemble", None) if (self.training and net.is_cuda and self.vote_factor == 1) else None
+        if fused is not None:
+            # seed + offset for coordinates and features, features straight into point-major layout: one launch each way
+            vote_xyz, pm = fused(net, seed_xyz, seed_features)
+            return vote_xyz, ChannelMajorOf.wrap(pm)
         net = net.transpose(2, 1).view(B, num_seed, self.vote_factor, 3 + self.out_dim)
         vote_xyz = (seed_xyz.unsqueeze(2) + net[:, :, :, 0:3]).contiguous().view(B, num_vote, 3)
         vote_features = seed_features.transpose(2, 1).unsqueeze(2) + net[:, :, :, 3:]

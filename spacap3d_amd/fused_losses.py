@@ -297,3 +297,44 @@ class L2NormRows(Function):
 
 def l2norm_rows(x):
     return L2NormRows.apply(x)
+
+
+class VoteAssemble(Function):
+    """vote_xyz, vote_features (point-major) from the voting module's last convolution, one launch each way
+    (csrc/decode.hip: vote_assemble_*; models/voting_module.py:49-60 with vote_factor 1)."""
+
+    @staticmethod
+    def forward(ctx, net, seed_xyz, seed_features):
+        B, CH, N = net.shape
+        C = CH - 3
+        dev = net.device
+        net, seed_xyz, seed_features = net.contiguous(), seed_xyz.contiguous(), seed_features.contiguous()
+        with torch.cuda.device(dev):
+            vx = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+            vf = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+            check(lib.spacap_vote_assemble_fwd_f32(net.data_ptr(), seed_xyz.data_ptr(), seed_features.data_ptr(), B, C, N,
+                                                   vx.data_ptr(), vf.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_vote_assemble_fwd_f32")
+        ctx.dims = (B, C, N)
+        ctx.set_materialize_grads(False)
+        return vx, vf
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_feat):
+        B, C, N = ctx.dims
+        ref = g_feat if g_feat is not None else g_xyz
+        dev = ref.device
+        gx = g_xyz.contiguous() if g_xyz is not None else None
+        gf = g_feat.contiguous() if g_feat is not None else None
+        with torch.cuda.device(dev):
+            d_net = torch.empty(B, 3 + C, N, dtype=torch.float32, device=dev)
+            d_seed = torch.empty(B, C, N, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+            check(lib.spacap_vote_assemble_bwd_f32(gx.data_ptr() if gx is not None else None, gf.data_ptr() if gf is not None else None,
+                                                   B, C, N, d_net.data_ptr(), d_seed.data_ptr() if d_seed is not None else None,
+                                                   torch.cuda.current_stream(dev).cuda_stream), "spacap_vote_assemble_bwd_f32")
+        return d_net, (gx if ctx.needs_input_grad[1] else None), d_seed
+
+
+def vote_assemble(net, seed_xyz, seed_features):
+    return VoteAssemble.apply(net, seed_xyz, seed_features)
+

@@ -125,3 +125,31 @@ def test_proposal_decode_matches_the_composition(B, K, NH):
     (ntb * w[0]).sum().add((cb * w[1]).sum()).add((hb * w[2]).sum()).add((sb * w[3]).sum()).backward()
     assert float((na.grad - nb.grad).abs().max()) <= 1e-6 * float(nb.grad.abs().max())
     assert torch.equal(aa.grad, ab.grad)
+
+
+@pytest.mark.parametrize("B,C,N", [(8, 256, 1024), (2, 100, 77), (1, 256, 33)])
+def test_vote_assemble_matches_the_tensor_operations(B, C, N):
+    """fused_losses.vote_assemble (csrc/decode.hip) against the voting module's own lines (models/voting_module.py:49-60):
+    vote_xyz and the point-major vote features bit for bit, and the gradients of the convolution output and of the seed
+    features (exact: every element has one contribution)."""
+    from spacap3d_amd.fused_losses import vote_assemble
+    g = torch.Generator().manual_seed(B + C + N)
+    net = torch.randn(B, 3 + C, N, generator=g).to(DEV)
+    sx = torch.randn(B, N, 3, generator=g).to(DEV)
+    sf = torch.randn(B, C, N, generator=g).to(DEV)
+    wx, wf = torch.randn(B, N, 3, generator=g).to(DEV), torch.randn(B, N, C, generator=g).to(DEV)
+    na, fa = net.clone().requires_grad_(True), sf.clone().requires_grad_(True)
+    t = na.transpose(2, 1).view(B, N, 1, 3 + C)
+    want_x = (sx.unsqueeze(2) + t[:, :, :, 0:3]).contiguous().view(B, N, 3)
+    want_f = (fa.transpose(2, 1).unsqueeze(2) + t[:, :, :, 3:]).contiguous().view(B, N, C)
+    ((want_x * wx).sum() + (want_f * wf).sum()).backward()
+    nb, fb = net.clone().requires_grad_(True), sf.clone().requires_grad_(True)
+    got_x, got_f = vote_assemble(nb, sx, fb)
+    assert torch.equal(got_x, want_x) and torch.equal(got_f, want_f)
+    ((got_x * wx).sum() + (got_f * wf).sum()).backward()
+    assert torch.equal(nb.grad, na.grad) and torch.equal(fb.grad, fa.grad)
+    # only one of the two outputs used
+    nc = net.clone().requires_grad_(True)
+    (vote_assemble(nc, sx, sf)[1] * wf).sum().backward()
+    assert torch.equal(nc.grad[:, 3:], na.grad[:, 3:]) and float(nc.grad[:, :3].abs().max()) == 0.0
+
