@@ -1895,9 +1895,9 @@ __device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, 
     const int n0 = t * KT;
 #pragma unroll
     for (int i = 0; i < CB / 32; ++i) {
-      const int c = c0 + 32 * i;
-      st4(&s_g[c * LDK + k4 * 4], ld4(gb + (size_t)c * N + n0 + k4 * 4));
-      st4(&s_x[c * LDK + k4 * 4], ld4(xb + (size_t)c * N + n0 + k4 * 4));
+      const int c = c0 + 32 * i;   // (channels past the end re-read the last one: their products are never stored)
+      st4(&s_g[c * LDK + k4 * 4], ld4(gb + (size_t)min(c, CO - 1 - co0) * N + n0 + k4 * 4));
+      st4(&s_x[c * LDK + k4 * 4], ld4(xb + (size_t)min(c, CI - 1 - ci0) * N + n0 + k4 * 4));
     }
     __syncthreads();
 #pragma unroll
@@ -1920,8 +1920,10 @@ __device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, 
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        o[(size_t)(co0 + (w * 2 + m) * 16 + 4 * lg + u) * CI + ci0 + n * 16 + l15] = acc[m][n][u];
+      for (int u = 0; u < 4; ++u) {
+        const int row = co0 + (w * 2 + m) * 16 + 4 * lg + u, col = ci0 + n * 16 + l15;
+        if (row < CO && col < CI) o[(size_t)row * CI + col] = acc[m][n][u];
+      }
 }
 
 __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(const float *__restrict__ g, const float *__restrict__ x, int CO,
@@ -1952,7 +1954,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_batched_kernel(const ConvTa
 }
 
 inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
-  const long yz = (long)(CO / 128) * (CI / 128), tiles = N / 32;
+  const long yz = (long)((CO + 127) / 128) * ((CI + 127) / 128), tiles = N / 32;
   long n = 512 / (yz * B), cap = (4L << 20) / ((long)CO * CI * B);
   if (n > cap) n = cap;
   if (n > tiles) n = tiles;
@@ -1962,7 +1964,7 @@ inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
 
 // number of partial results (= B x point ranges) for a (B, CO, CI, N) problem; 0 when the shape has no kernel
 extern "C" int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N) {
-  if (B < 1 || N < 32 || N % 32 || CO < 128 || CI < 128 || CO % 128 || CI % 128) return 0;
+  if (B < 1 || N < 32 || N % 32 || CO < 1 || CI < 1) return 0;   // (any widths: 128 x 128 tiles with clamped tails)
   return B * conv1x1_nsplit(B, CO, CI, N);
 }
 
@@ -1995,8 +1997,8 @@ extern "C" int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const flo
                      N[i], nslabs[i]);
       ConvJob &J = T.job[T.njobs++];
       J.g = g[i], J.x = x[i], J.part = part[i], J.CO = CO[i], J.CI = CI[i], J.N = N[i];
-      J.nsplit = nslabs[i] / B[i], J.gx = nslabs[i], J.gy = CO[i] / 128, J.block0 = (int)blocks, J.pad = 0;
-      blocks += (long)nslabs[i] * (CO[i] / 128) * (CI[i] / 128);
+      J.nsplit = nslabs[i] / B[i], J.gx = nslabs[i], J.gy = (CO[i] + 127) / 128, J.block0 = (int)blocks, J.pad = 0;
+      blocks += (long)nslabs[i] * ((CO[i] + 127) / 128) * ((CI[i] + 127) / 128);
       SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
     }
     hipLaunchKernelGGL(conv1x1_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
@@ -2012,7 +2014,7 @@ extern "C" int spacap_conv1x1_wgrad_f32(const float *g, const float *x, int B, i
   const int nslab = spacap_conv1x1_wgrad_slabs(B, CO, CI, N);
   SPACAP_REQUIRE(nslab > 0, "%s: (B=%d, CO=%d, CI=%d, N=%d) unsupported", what, B, CO, CI, N);
   SPACAP_REQUIRE(g && x && part, "%s: null pointer", what);
-  hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nslab, CO / 128, CI / 128), dim3(256), 0, spacap::as_stream(stream), g, x, CO, CI,
+  hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nslab, (CO + 127) / 128, (CI + 127) / 128), dim3(256), 0, spacap::as_stream(stream), g, x, CO, CI,
                      N, nslab / B, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;

@@ -221,7 +221,7 @@ class VotingModule(nn.Module):
         num_vote = num_seed * self.vote_factor
         net = _bn_relu(self.bn1, _conv(self.conv1, seed_features, self.training), self.training)
         net = _bn_relu(self.bn2, _conv(self.conv2, net, self.training), self.training)
-        net = self.conv3(net)
+        net = _conv(self.conv3, net, self.training)
         fused = getattr(_ops(), "vote_assemble", None) if (self.training and net.is_cuda and self.vote_factor == 1) else None
         if fused is not None:
             # seed + offset for coordinates and features, features straight into point-major layout: one launch each way

@@ -255,7 +255,12 @@ class PositionalEncodingLearned(nn.Module):
         h = self.position_embedding_head
         t = xyz.transpose(1, 2).contiguous()
         if self.training and t.is_cuda and getattr(ops(), "bn_relu_train", None) is not None:
-            t = h[3](ops().bn_relu_train(h[0](t), h[1]))       # Conv1d -> [BatchNorm1d -> ReLU as one fused op] -> Conv1d
+            conv = getattr(ops(), "conv1x1", None)
+
+            def c(m, v):   # 1x1 convolution whose weight gradient joins the step's deferred batch (linear.Conv1x1)
+                y = conv(v, m) if conv is not None else None
+                return m(v) if y is None else y
+            t = c(h[3], ops().bn_relu_train(c(h[0], t), h[1]))   # Conv1d -> [BatchNorm1d -> ReLU as one fused op] -> Conv1d
         else:
             t = h(t)
         return x + t.transpose(1, 2).contiguous()

@@ -268,7 +268,8 @@ def test_small_row_linears_take_the_row_panel_kernel_and_keep_their_gradients():
 
 
 @pytest.mark.parametrize("B,CO,CI,N,dims", [(8, 256, 256, 1024, 3), (8, 256, 512, 512, 4), (2, 128, 128, 32, 3), (3, 256, 128, 96, 4),
-                                             (1, 384, 256, 2048, 3), (8, 256, 768, 512, 4), (8, 128, 128, 256, 3)])
+                                             (1, 384, 256, 2048, 3), (8, 256, 768, 512, 4), (8, 128, 128, 256, 3),
+                                             (8, 259, 256, 1024, 3), (8, 97, 128, 256, 3), (8, 128, 3, 256, 3), (2, 130, 200, 64, 3)])
 def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
     """linear.Conv1x1 (1x1 Conv1d / Conv2d on channel-major tensors: vote net, feature-propagation MLPs): output and
     the three gradients against float64 autograd of the same convolution."""
