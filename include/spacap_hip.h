@@ -717,6 +717,10 @@ int spacap_vote_assemble_fwd_f32(const float *net, const float *seed_xyz, const 
 int spacap_vote_assemble_bwd_f32(const float *g_xyz, const float *g_feat, int B, int C, int N, float *d_net, float *d_seed,
                                  spacap_stream_t stream);
 
+/* njobs device-to-device copies (dst[i] <- src[i], nbytes[i] bytes, non-overlapping) in one launch per 120 jobs; the three
+ * arrays are HOST arrays, read before the call returns. */
+int spacap_copy_batched(const void *const *src, void *const *dst, const long *nbytes, int njobs, spacap_stream_t stream);
+
 /* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
 int spacap_stream_delay(int microseconds, spacap_stream_t stream);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     "spacap_sa_l1_dw_f32": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "spacap_vote_assemble_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "spacap_vote_assemble_bwd_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
+    "spacap_copy_batched": (_i, [_p, _p, _p, _i, _p]),
     "spacap_lab_stamp": (_i, [_p, _p]),
     "spacap_stream_delay": (_i, [_i, _p]),
     "spacap_sa_nparts": (_i, []),
@@ -396,3 +397,25 @@ def conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=False):
         check(lib.spacap_conv1x1_wgrad_f32(g.data_ptr(), x.data_ptr(), B, CO, CI, N, part.data_ptr(),
                                            torch.cuda.current_stream(g.device).cuda_stream), "spacap_conv1x1_wgrad_f32")
     return part
+
+
+def copy_batched(dsts, srcs):
+    """``dst.copy_(src)`` for lists of contiguous same-shape, same-dtype CUDA tensors on one device as ONE launch
+    (csrc/elementwise.hip: copy_batched_kernel); falls back to torch._foreach_copy_ for anything else."""
+    import torch
+    ok = len(dsts) == len(srcs) and len(dsts) > 0 and all(
+        d.is_cuda and s.is_cuda and d.device == s.device and d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous()
+        and s.is_contiguous() for d, s in zip(dsts, srcs))
+    if not ok:
+        if dsts:
+            torch._foreach_copy_(list(dsts), list(srcs), non_blocking=True)
+        return
+    n = len(dsts)
+    PA, LA = ctypes.c_void_p * n, ctypes.c_long * n
+    src = PA(*[s.data_ptr() for s in srcs])
+    dst = PA(*[d.data_ptr() for d in dsts])
+    nb = LA(*[d.numel() * d.element_size() for d in dsts])
+    dev = dsts[0].device
+    with torch.cuda.device(dev):
+        check(lib.spacap_copy_batched(src, dst, nb, n, torch.cuda.current_stream(dev).cuda_stream), "spacap_copy_batched")
+

@@ -359,6 +359,64 @@ extern "C" int spacap_l2norm_rows_bwd_f32(const float *g, const float *y, const 
   return SPACAP_OK;
 }
 
+// ---- many small device-to-device copies in one launch -----------------------------------------------------------------------
+// The step copies the batch and the prefetched pyramid into its static buffers (~30 tensors of four dtypes) and packs ~170
+// gradient tensors into the flat bucket; as multi-tensor library copies these are 4 + 4 launches of ~20 us each.  Job table by
+// value in the kernel arguments (hipGraph-capturable as it is); a workgroup finds its job by binary search over the first-block
+// prefix and moves 16 KB: 16-byte pieces when source, destination and size allow, bytes otherwise.
+namespace {
+constexpr int CPJ_MAX = 120;
+constexpr long CPJ_BLOCK_BYTES = 16384;
+struct CopyJob {
+  const char *src;
+  char *dst;
+  long nbytes;
+  int block0, vec;
+};
+struct CopyTable {
+  int njobs, pad;
+  CopyJob job[CPJ_MAX];
+};
+__global__ __launch_bounds__(256) void copy_batched_kernel(const CopyTable T) {
+  int lo = 0, hi = T.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.job[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const CopyJob J = T.job[lo];
+  const long beg = (long)((int)blockIdx.x - J.block0) * CPJ_BLOCK_BYTES, end = min(J.nbytes, beg + CPJ_BLOCK_BYTES);
+  if (J.vec) {
+    for (long o = beg + 16 * threadIdx.x; o < end; o += 16 * 256)
+      *reinterpret_cast<f32x4 *>(J.dst + o) = *reinterpret_cast<const f32x4 *>(J.src + o);
+  } else {
+    for (long o = beg + threadIdx.x; o < end; o += 256) J.dst[o] = J.src[o];
+  }
+}
+}  // namespace
+extern "C" int spacap_copy_batched(const void *const *src, void *const *dst, const long *nbytes, int njobs, spacap_stream_t stream) {
+  const char *what = "spacap_copy_batched";
+  SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (src && dst && nbytes)), "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  int i = 0;
+  while (i < njobs) {
+    CopyTable T;
+    T.njobs = 0, T.pad = 0;
+    long blocks = 0;
+    for (; i < njobs && T.njobs < CPJ_MAX; ++i) {
+      SPACAP_REQUIRE(nbytes[i] >= 0 && (nbytes[i] == 0 || (src[i] && dst[i])), "%s: job %d: null pointer or negative size", what, i);
+      if (nbytes[i] == 0) continue;
+      CopyJob &J = T.job[T.njobs++];
+      J.src = static_cast<const char *>(src[i]), J.dst = static_cast<char *>(dst[i]), J.nbytes = nbytes[i], J.block0 = (int)blocks;
+      J.vec = ((reinterpret_cast<uintptr_t>(src[i]) | reinterpret_cast<uintptr_t>(dst[i]) | (uintptr_t)nbytes[i]) & 15) == 0;
+      blocks += (nbytes[i] + CPJ_BLOCK_BYTES - 1) / CPJ_BLOCK_BYTES;
+      SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
+    }
+    if (T.njobs) hipLaunchKernelGGL(copy_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // ---- a pause on a stream: one wave spins on the 100 MHz wall clock (engine.py: the side-stream pyramid must not be released
 // by the same event as the step's graph) ------------------------------------------------------------------------------------
 namespace {

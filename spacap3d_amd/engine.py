@@ -431,9 +431,17 @@ class Trainer:
             if k != "fps_pyramid" and k in data_dict and data_dict[k] is not dst:
                 dsts.append(dst)
                 srcs.append(data_dict[k])
-        if dsts:   # the batch and its pyramid into the graph's static buffers: one multi-tensor copy per dtype, not ~32 launches
+        if dsts:   # the batch and its pyramid into the graph's static buffers: ONE launch (the library's multi-tensor copy
+            # needs one ~20 us launch per dtype); tensors that differ in dtype / layout from their buffer go the library's way
+            same = [(d, s_) for d, s_ in zip(dsts, srcs) if d.dtype == s_.dtype and d.shape == s_.shape and s_.is_contiguous()
+                    and d.is_contiguous()]
+            rest = [(d, s_) for d, s_ in zip(dsts, srcs) if not (d.dtype == s_.dtype and d.shape == s_.shape and s_.is_contiguous()
+                                                                and d.is_contiguous())]
+            if same:
+                from ._native import copy_batched
+                copy_batched([d for d, _ in same], [s_ for _, s_ in same])
             groups = {}
-            for dst, src in zip(dsts, srcs):
+            for dst, src in rest:
                 g = groups.setdefault((dst.dtype, src.dtype), ([], []))
                 g[0].append(dst)
                 g[1].append(src)
