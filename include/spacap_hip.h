@@ -565,10 +565,13 @@ int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N);
 int spacap_conv1x1_wgrad_f32(const float *g, const float *x, int B, int CO, int CI, int N, float *part,
                              spacap_stream_t stream);
 /* Several of them in ONE launch (end of a backward pass); HOST arrays, job table by value, nslabs[i] =
- * spacap_conv1x1_wgrad_slabs_batched(...) (or any multiple of B[i] that divides the point tiles). */
+ * spacap_conv1x1_wgrad_slabs_batched(...) (or any multiple of B[i] that divides the point tiles).  with_bias (may be NULL):
+ * where with_bias[i] != 0 the partial row of job i is [CO*CI | CO rounded up to 4] and its tail receives the bias gradient
+ * db[co] = sum over the slab's points of g[b,co,:] (padding zero). */
 int spacap_conv1x1_wgrad_slabs_batched(int B, int CO, int CI, int N);
 int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const float *const *x, const int *B, const int *CO, const int *CI,
-                                     const int *N, const int *nslabs, float *const *part, int njobs, spacap_stream_t stream);
+                                     const int *N, const int *nslabs, const int *with_bias, float *const *part, int njobs,
+                                     spacap_stream_t stream);
 
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with

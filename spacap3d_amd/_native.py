@@ -135,7 +135,7 @@ SIGNATURES = {
     "spacap_conv1x1_wgrad_slabs": (_i, [_i, _i, _i, _i]),
     "spacap_conv1x1_wgrad_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_conv1x1_wgrad_slabs_batched": (_i, [_i, _i, _i, _i]),
-    "spacap_conv1x1_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "spacap_conv1x1_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "spacap_linear_rows_supported": (_i, [_l, _i, _i]),
     "spacap_linear_rows_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
@@ -272,7 +272,8 @@ class deferred_slab_sums:
                         arr(ctypes.c_void_p, [j[0].data_ptr() for j in group]), arr(ctypes.c_void_p, [j[1].data_ptr() for j in group]),
                         arr(ctypes.c_int, [j[2][0] for j in group]), arr(ctypes.c_int, [j[2][1] for j in group]),
                         arr(ctypes.c_int, [j[2][2] for j in group]), arr(ctypes.c_int, [j[2][3] for j in group]),
-                        arr(ctypes.c_int, [j[3].shape[0] for j in group]), arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]),
+                        arr(ctypes.c_int, [j[3].shape[0] for j in group]), arr(ctypes.c_int, [int(j[4]) for j in group]),
+                        arr(ctypes.c_void_p, [j[3].data_ptr() for j in group]),
                         k, torch.cuda.current_stream(dev).cuda_stream), "spacap_conv1x1_wgrad_batched_f32")
 
     def run_sums(self):
@@ -382,15 +383,17 @@ def linear_wgrad_partials(g2, x2, with_bias, deferrable=False):
     return part
 
 
-def conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=False):
+def conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=False, with_bias=False):
     """Per-slab partials (nslab, CO*CI) of the weight gradient of a 1x1 convolution on channel-major g (B,CO,N...) and
-    x (B,CI,N...); queued inside a ``deferred_slab_sums`` block with ``deferrable=True`` (see linear_wgrad_partials)."""
+    x (B,CI,N...); queued inside a ``deferred_slab_sums`` block with ``deferrable=True`` (see linear_wgrad_partials).
+    ``with_bias`` (only honoured when the job is queued; check the row length): rows are (CO*CI + CO rounded up to 4) and the
+    tail holds the bias gradient's partial sums."""
     import torch
     with torch.cuda.device(g.device):
         if deferrable and _DEFERRED is not None:
             nb = int(lib.spacap_conv1x1_wgrad_slabs_batched(B, CO, CI, N))
-            part = torch.empty(nb, CO * CI, dtype=torch.float32, device=g.device)
-            _DEFERRED.conv_jobs.append((g, x, (B, CO, CI, N), part))
+            part = torch.empty(nb, CO * CI + (((CO + 3) // 4) * 4 if with_bias else 0), dtype=torch.float32, device=g.device)
+            _DEFERRED.conv_jobs.append((g, x, (B, CO, CI, N), part, bool(with_bias)))
             return part
         nslab = int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N))
         part = torch.empty(nslab, CO * CI, dtype=torch.float32, device=g.device)

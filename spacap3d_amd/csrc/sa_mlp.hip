@@ -1875,8 +1875,11 @@ extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const floa
 // (contiguous along n), each (scene, point range) slab accumulates a 128 x 128 block by MFMA and writes a partial
 // result; the caller adds the slabs in order (spacap_sum_slabs_f32).
 namespace {
+// with_bias: the partial row is [CO * CI | CO rounded up to 4] and its tail receives db[co] = sum over the slab's points of g
+// (a column of ones beside x; written by the workgroups of the first input-channel block)
 __device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, const float *__restrict__ x, int CO, int CI,
-                                                   int N, int nsplit, float *__restrict__ part, int bx, int by, int bz) {
+                                                   int N, int nsplit, float *__restrict__ part, int bx, int by, int bz,
+                                                   int with_bias = 0) {
   constexpr int CB = 128, KT = 32, LDK = KT + 4;
   __shared__ __attribute__((aligned(16))) float s_g[CB * LDK];
   __shared__ __attribute__((aligned(16))) float s_x[CB * LDK];
@@ -1891,6 +1894,8 @@ __device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, 
   for (int m = 0; m < 2; ++m)
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const bool wb = with_bias && bz == 0;
   for (int t = t_begin; t < t_end; ++t) {
     const int n0 = t * KT;
 #pragma unroll
@@ -1911,10 +1916,23 @@ __device__ __forceinline__ void conv1x1_wgrad_body(const float *__restrict__ g, 
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[m][n] = MFMA16(af[m], bb, acc[m][n]);
       }
+      if (wb) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) accb[m] = MFMA16(af[m], 1.0f, accb[m]);
+      }
     }
     __syncthreads();
   }
-  float *o = part + (size_t)bx * ((size_t)CO * CI);
+  float *o = part + (size_t)bx * ((size_t)CO * CI + (with_bias ? (size_t)((CO + 3) & ~3) : 0));
+  if (wb && l15 == 0) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = co0 + (w * 2 + m) * 16 + 4 * lg + u;
+        if (row < ((CO + 3) & ~3)) o[(size_t)CO * CI + row] = row < CO ? accb[m][u] : 0.f;
+      }
+  }
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1936,7 +1954,7 @@ constexpr int CV_JOB_MAX = 64;
 struct ConvJob {
   const float *g, *x;
   float *part;
-  int CO, CI, N, nsplit, gx, gy, block0, pad;
+  int CO, CI, N, nsplit, gx, gy, block0, with_bias;
 };
 struct ConvTable {
   int njobs, pad;
@@ -1950,7 +1968,8 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_batched_kernel(const ConvTa
   }
   const ConvJob J = T.job[lo];
   const int local = (int)blockIdx.x - J.block0;
-  conv1x1_wgrad_body(J.g, J.x, J.CO, J.CI, J.N, J.nsplit, J.part, local % J.gx, (local / J.gx) % J.gy, local / (J.gx * J.gy));
+  conv1x1_wgrad_body(J.g, J.x, J.CO, J.CI, J.N, J.nsplit, J.part, local % J.gx, (local / J.gx) % J.gy, local / (J.gx * J.gy),
+                     J.with_bias);
 }
 
 inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
@@ -1980,8 +1999,8 @@ extern "C" int spacap_conv1x1_wgrad_slabs_batched(int B, int CO, int CI, int N) 
 // njobs independent 1x1-convolution weight gradients in one launch; all arrays are HOST arrays (read before the call
 // returns); part[i] receives nslabs[i] = B[i] x (point ranges) partial results (add in order).
 extern "C" int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const float *const *x, const int *B, const int *CO,
-                                                const int *CI, const int *N, const int *nslabs, float *const *part, int njobs,
-                                                spacap_stream_t stream) {
+                                                const int *CI, const int *N, const int *nslabs, const int *with_bias,
+                                                float *const *part, int njobs, spacap_stream_t stream) {
   const char *what = "spacap_conv1x1_wgrad_batched_f32";
   SPACAP_REQUIRE(njobs >= 0 && (njobs == 0 || (g && x && B && CO && CI && N && nslabs && part)), "%s: bad arguments", what);
   hipStream_t s = spacap::as_stream(stream);
@@ -1997,7 +2016,7 @@ extern "C" int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const flo
                      N[i], nslabs[i]);
       ConvJob &J = T.job[T.njobs++];
       J.g = g[i], J.x = x[i], J.part = part[i], J.CO = CO[i], J.CI = CI[i], J.N = N[i];
-      J.nsplit = nslabs[i] / B[i], J.gx = nslabs[i], J.gy = (CO[i] + 127) / 128, J.block0 = (int)blocks, J.pad = 0;
+      J.nsplit = nslabs[i] / B[i], J.gx = nslabs[i], J.gy = (CO[i] + 127) / 128, J.block0 = (int)blocks, J.with_bias = with_bias ? with_bias[i] : 0;
       blocks += (long)nslabs[i] * ((CO[i] + 127) / 128) * ((CI[i] + 127) / 128);
       SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
     }

@@ -208,9 +208,12 @@ class Conv1x1(Function):
                                                          [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
                                                          [True, False, False])[0]
         if int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N)):
-            part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True)
-            dw = sum_slabs(part, deferrable=True).view_as(weight)
-        else:   # output widths without a slab kernel (the 259- / 97-wide heads): the library's weight gradient
+            part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True, with_bias=ctx.has_bias)
+            s = sum_slabs(part, deferrable=True)
+            if part.shape[1] != CO * CI:      # the bias gradient rode along (a column of ones in the queued kernel)
+                return dx, s[:CO * CI].view_as(weight), s[CO * CI:CO * CI + CO]
+            dw = s.view_as(weight)
+        else:   # point counts without a slab kernel (not a multiple of 32): the library's weight gradient
             dw = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
                                                      [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
                                                      [False, True, False])[1]

@@ -297,6 +297,30 @@ def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
         assert conv1x1(xg, conv) is None
 
 
+@pytest.mark.parametrize("B,CO,CI,N", [(8, 259, 256, 1024), (8, 97, 128, 256), (4, 128, 3, 256), (2, 256, 256, 512)])
+def test_conv1x1_gradients_inside_the_deferred_batch(B, CO, CI, N):
+    """Inside ``deferred_slab_sums`` (a Trainer's backward) the weight gradient is queued for the step's one batched launch
+    and the bias gradient rides along as a column of ones: both against float64, for output widths that are not multiples
+    of the 128 x 128 tile as well."""
+    from spacap3d_amd._native import deferred_slab_sums
+    from spacap3d_amd.linear import conv1x1
+    g = torch.Generator().manual_seed(CO + N)
+    conv = torch.nn.Conv1d(CI, CO, 1)
+    x, w = torch.randn(B, CI, N, generator=g), torch.randn(B, CO, N, generator=g)
+    ref = torch.nn.Conv1d(CI, CO, 1).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    (ref(x.double()) * w.double()).sum().backward()
+    conv = conv.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    with deferred_slab_sums():
+        y = conv1x1(xg, conv)
+        assert y is not None
+        (y * w.to(DEV)).sum().backward()
+    for got, want in ((conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
+        err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+        assert err < 2e-5, err
+
+
 @pytest.mark.parametrize("B,CO,CI,N", [(8, 256, 256, 1024), (2, 259, 256, 64), (3, 97, 128, 256), (1, 256, 770, 128), (2, 5, 3, 64),
                                         (1, 130, 37, 192)])
 def test_conv1x1_channel_major_kernel(B, CO, CI, N):
