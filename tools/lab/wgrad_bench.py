@@ -1,29 +1,19 @@
-"""linear_wgrad_kernel + sum_slabs at the Transformer's shapes."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import torch
-import spacap3d_amd  # noqa
-from spacap3d_amd._native import lib, check, sum_slabs
+"""Lab: the shared-MLP weight-gradient kernel at the step's shapes (default = split-bf16 for 128-multiples; run with
+SPACAP_SA_F32MFMA=1 for the fp32-MFMA kernel).    python tools/lab/wgrad_bench.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+import kernel_cases as KC  # noqa: E402
+
 dev = torch.device("cuda:0")
-for R, CK, CP in ((2048, 2048, 128), (2048, 128, 2048), (2048, 384, 128), (2048, 128, 128), (256, 2048, 128), (256, 128, 128), (16384, 128, 128)):
-    g = torch.randn(R, CK, device=dev); x = torch.randn(R, CP, device=dev)
-    ns = int(lib.spacap_linear_wgrad_slabs(R, CK, CP))
-    part = torch.empty(ns, CK * CP + CK, device=dev)
-    def run():
-        check(lib.spacap_linear_wgrad_f32(g.data_ptr(), x.data_ptr(), R, CK, CP, 1, part.data_ptr(),
-                                          torch.cuda.current_stream().cuda_stream), "w")
-    def run2():
-        run(); return sum_slabs(part)
-    for f, name in ((run, "wgrad"), (run2, "wgrad+sum")):
-        for _ in range(3): f()
-        torch.cuda.synchronize()
-        gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
-            for _ in range(20): f()
-        gr.replay(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-        e0.record(); gr.replay(); e1.record(); torch.cuda.synchronize()
-        print(f"R={R} CK={CK} CP={CP} slabs={ns} {name}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us", end="   ")
-    s = run2()
-    ref = g.double().t() @ x.double()
-    print(f"err {float((s[:CK*CP].view(CK, CP).double() - ref).abs().max() / ref.abs().max()):.1e}")
+R1, R2 = 8 * 2048 * 64, 8 * 1024 * 32
+for a in ((R1, 128, 64, True, 64, "SA1 layer 3"), (R2, 256, 128, True, 32, "SA2 layer 3"), (R2, 128, 128, False, 32, "SA2 layer 2"),
+          (8 * 512 * 16, 256, 128, True, 16, "SA3 layer 3"), (8 * 512 * 16, 128, 128, False, 16, "SA3 layer 2")):
+    c = KC.sa_wgrad(*a[:5], dev, a[5])
+    us = KC.time_case(c)
+    print(f"{c['name']:60s} {us:8.1f} us  {c['flops'] / us * 1e-6:6.1f} TFLOP/s  {c['bytes'] / us * 1e-6:5.2f} TB/s", flush=True)
+    del c
