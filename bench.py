@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the SpaCap3D hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -40,11 +40,45 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start N fresh rank processes --
+    one per GPU, the reference's one-command multi-GPU mode (scripts/train.py:198-200) -- BEFORE anything in this process
+    has touched the GPU (nothing has been imported yet but the standard library).  The parent never initialises HIP and never
+    re-execs; it relays rank 0's JSON line and exits non-zero when any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    _ap = argparse.ArgumentParser(add_help=False)
+    _ap.add_argument("--gpus", type=int, default=1)
+    _n = _ap.parse_known_args()[0].gpus
+    if _n > 1:
+        spawn_ranks(_n)
+        raise SystemExit(0)
+
+import torch  # noqa: E402
 
 from spacap3d_amd import backend, synthetic as S  # noqa: E402
 from spacap3d_amd.distributed import init_from_env  # noqa: E402

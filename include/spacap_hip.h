@@ -287,7 +287,7 @@ int spacap_relation_fused_bwd_f32(const float *dpred, const float *hid2, const f
  *   pred f32 [1] = sum(dist * good) / max(1, sum good);
  *   x0 f32 [B,L,D]: row 0 = src[b,idx] + memory[b,idx], row 1+t = dropout_p(emb[tok[b,1+t]] * sqrt(D) + pe[t]);
  *   mask u8 [B,L,L] = tok[b,k] > 0 and k <= q.
- * counter i32 [1] must be zero before the first call and is left zero.  Dropout: counter hash of (seed, *seed_dev, element). */
+ * counter i32 [1]: the call's own last-block ticket, any content (zeroed on the stream by the entry point).  Dropout: counter hash of (seed, *seed_dev, element). */
 int spacap_caption_prep_fwd_f32(const float *xyz, const float *ref, const float *src, const float *memory,
                                 const int64_t *tok, const float *emb, const float *pe, int B, int K, int D, int T, int V,
                                 float p, uint64_t seed, const uint64_t *seed_dev, float *x0, uint8_t *mask, int64_t *idx,

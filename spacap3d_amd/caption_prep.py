@@ -9,16 +9,6 @@ from torch.autograd import Function
 from ._native import check, lib
 from .attention import _next_seed, rng_state
 
-_COUNTER = {}
-
-
-def _counter(dev):
-    c = _COUNTER.get(dev)
-    if c is None:
-        c = _COUNTER[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-    return c
-
-
 class CaptionPrep(Function):
     @staticmethod
     def forward(ctx, xyz, ref, src, memory, tok, emb, pe, p, seed):
@@ -35,10 +25,11 @@ class CaptionPrep(Function):
             dist = torch.empty(B, dtype=torch.float32, device=dev)
             good = torch.empty(B, dtype=torch.bool, device=dev)
             pred = torch.empty(1, dtype=torch.float32, device=dev)
+            ticket = torch.empty(1, dtype=torch.int32, device=dev)   # last-block ticket of THIS launch (zeroed by the entry point)
             check(lib.spacap_caption_prep_fwd_f32(xyz.data_ptr(), ref.data_ptr(), srcc.data_ptr(), mem.data_ptr() if mem is not None else None,
                                                   tok.data_ptr(), embc.data_ptr(), pe.data_ptr(), B, K, D, T, V, float(p), int(seed),
                                                   rng_state(dev).data_ptr(), x0.data_ptr(), mask.data_ptr(), idx.data_ptr(),
-                                                  dist.data_ptr(), good.data_ptr(), pred.data_ptr(), _counter(dev).data_ptr(),
+                                                  dist.data_ptr(), good.data_ptr(), pred.data_ptr(), ticket.data_ptr(),
                                                   torch.cuda.current_stream(dev).cuda_stream), "spacap_caption_prep_fwd_f32")
         ctx.save_for_backward(tok, idx)
         ctx.dims = (B, K, D, T, V, float(p), int(seed), memory is not None)

@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void cap_prep_fwd_kernel(PrepArgs a) {
       cnt += g ? 1.f : 0.f;
     }
     a.pred[0] = num / fmaxf(cnt, 1.f);
-    *a.counter = 0;
   }
 }
 
@@ -218,6 +217,9 @@ extern "C" int spacap_caption_prep_fwd_f32(const float *xyz, const float *ref, c
   a.seed = seed, a.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   a.x0 = x0, a.mask = mask, a.good = good, a.idx = reinterpret_cast<long long *>(idx), a.dist = dist, a.pred = pred, a.counter = counter;
   SPACAP_REQUIRE(B <= 65535, "%s: B out of range", what);
+  // the last-block ticket belongs to THIS call (the caller allocates it with the outputs): launches in flight on other
+  // streams, or captured into other graphs, cannot disturb it
+  SPACAP_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t), spacap::as_stream(stream)), what);
   hipLaunchKernelGGL(cap_prep_fwd_kernel, dim3(T - 1, B), dim3(256), 0, spacap::as_stream(stream), a);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;

@@ -18,6 +18,19 @@ inline hipStream_t as_stream(spacap_stream_t s) { return reinterpret_cast<hipStr
 int sa_reserved_cus();
 int device_cus();
 
+// Raises a kernel's dynamic-LDS limit on the CURRENT device.  `done` is the call site's own bit mask of devices that already
+// have it (a function attribute is per device: a process that moves to another GPU must set it there too).
+inline hipError_t allow_dynamic_lds(const void *fn, int bytes, unsigned long long &done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done & bit) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done |= bit;
+  return e;
+}
+
 #define SPACAP_REQUIRE(cond, ...)          \
   do {                                     \
     if (!(cond)) {                         \

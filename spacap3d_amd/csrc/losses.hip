@@ -414,12 +414,8 @@ extern "C" int spacap_det_losses_fwd_f32(
   SPACAP_REQUIRE(lds <= 60000, "%s: K=%d too large", what, K);
   const size_t lds_staged = lds + sizeof(float) * (size_t)K * A.CH;
   if (lds_staged <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&det_proposal_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024), what);
-      attr_set = true;
-    }
+    static unsigned long long lds_ok = 0;
+    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&det_proposal_kernel<true>), 150 * 1024, lds_ok), what);
     hipLaunchKernelGGL(det_proposal_kernel<true>, dim3(B), dim3(256), lds_staged, s, A);
   } else {
     hipLaunchKernelGGL(det_proposal_kernel<false>, dim3(B), dim3(256), lds, s, A);

@@ -496,12 +496,8 @@ extern "C" int spacap_relation_fused_fwd_f32(const float *P, const float *U, con
   SPACAP_REQUIRE(B >= 0 && K >= 8 && K % 8 == 0 && B <= 65535, "%s: (B=%d, K=%d) unsupported", what, B, K);
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(P && U && b1 && W2 && b2 && W3 && b3 && hid2 && pred, "%s: null pointer", what);
-  static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rel_fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)FWD_LDS);
-    return true;
-  }();
-  (void)attr;
+  static unsigned long long lds_ok = 0;
+  SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&rel_fused_fwd_kernel), (int)FWD_LDS, lds_ok), what);
   // (two workgroups per CU overlap each other's phases)
   hipLaunchKernelGGL(rel_fused_fwd_kernel, dim3(grid_size(B, K, 2)), dim3(256), FWD_LDS, spacap::as_stream(stream), P, U, b1, W2, b2, W3,
                      b3, B, K, hid2, pred);
@@ -516,12 +512,8 @@ extern "C" int spacap_relation_fused_bwd_f32(const float *dpred, const float *hi
   SPACAP_REQUIRE(B >= 0 && K >= 8 && K % 8 == 0 && B <= 65535, "%s: (B=%d, K=%d) unsupported", what, B, K);
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(dpred && hid2 && P && U && b1 && W2 && W3 && dP && dU && part, "%s: null pointer", what);
-  static const bool attr = [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rel_fused_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)BWD_LDS);
-    return true;
-  }();
-  (void)attr;
+  static unsigned long long lds_ok = 0;
+  SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&rel_fused_bwd_kernel), (int)BWD_LDS, lds_ok), what);
   SPACAP_REQUIRE(nparts >= 1 && nparts <= B * (K / TJ) * (K / TI) && zslots >= du_slots(B, K, nparts),
                  "%s: (nparts=%d, zslots=%d) do not fit (B=%d, K=%d)", what, nparts, zslots, B, K);
   hipLaunchKernelGGL(rel_fused_bwd_kernel, dim3(nparts), dim3(256), BWD_LDS, spacap::as_stream(stream), dpred, hid2, P, U, b1, W2, W3, B, K,

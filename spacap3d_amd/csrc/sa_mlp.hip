@@ -1639,11 +1639,8 @@ extern "C" int spacap_sa_rows_index_f32(const int32_t *idx, int B, int Np, long 
   int *off = reinterpret_cast<int *>(ws + L.off);
   if (Np <= 4096 && E <= 65535 && B <= 65535) {   // one launch, no sort
     const size_t lds = (size_t)(RI_WAVES * ((Np + 1) / 2) + 2 * ((Np + 1) / 2) + 1024) * 4;
-    static const bool attr = [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&rows_index_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      return true;
-    }();
-    (void)attr;
+    static unsigned long long lds_ok = 0;
+    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&rows_index_kernel), 160 * 1024, lds_ok), what);
     hipLaunchKernelGGL(rows_index_kernel, dim3(B), dim3(1024), lds, s, idx, Np, (int)E, B, off, vals_out);
     SPACAP_CHECK_LAUNCH(what);
     return SPACAP_OK;

@@ -123,11 +123,13 @@ class DeviceSceneDataset:
         self._scene_index[scene_id] = len(self._scenes)
         self._scenes.append({
             "feat": torch.as_tensor(np.ascontiguousarray(pc, dtype=np.float32)).to(d),
-            "color": self._loaded_color(vert), "color0": torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(d),
+            "color": self._loaded_color(vert),
             "ins": torch.as_tensor(np.asarray(ins).astype(np.int32)).to(d),
             "isobj": torch.as_tensor(np.isin(np.asarray(sem), NYU40IDS).astype(np.uint8)).to(d),
             "n": int(vert.shape[0]), "nb": nb, "box8": box8, "rel": rel,
         })
+        if self.color_renorm == "per_access":   # the raw copy only exists where reset_colors() needs it (~1 GB over all of ScanNet)
+            self._scenes[-1]["color0"] = torch.as_tensor(np.ascontiguousarray(vert[:, 3:6], dtype=np.float32)).to(d)
         if self.use_multiview:
             self._scenes[-1]["multiview"] = torch.as_tensor(np.ascontiguousarray(multiview, dtype=np.float32)).to(d)
         self._tables = None

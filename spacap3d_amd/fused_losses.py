@@ -238,7 +238,12 @@ class LossTail(Function):
         with torch.cuda.device(dev):
             out = torch.empty(8, dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
-            ol, om, bm = obj_label.contiguous().view(-1), obj_mask.contiguous().view(-1), bbox_mask.contiguous().view(-1)
+            # the entry point reads raw int64 / f32 / int64 words: convert anything else instead of reading out of bounds
+            ol = obj_label.to(torch.int64).contiguous().view(-1)
+            om = obj_mask.to(torch.float32).contiguous().view(-1)
+            bm = bbox_mask.to(torch.int64).contiguous().view(-1)
+            if not (ol.numel() == om.numel() == bm.numel()):
+                raise RuntimeError("loss_tail: objectness_label, objectness_mask and bbox_mask must have one entry per proposal")
             check(lib.spacap_loss_tail_fwd_f32(det.contiguous().data_ptr(), cap.contiguous().data_ptr(),
                                                rel.contiguous().data_ptr() if rel is not None else None, ol.data_ptr(),
                                                om.data_ptr(), bm.data_ptr(), ol.numel(), out.data_ptr(), loss.data_ptr(),

@@ -230,8 +230,12 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     d["object_assignment"] = object_assignment
     # every derived scalar (box / det / relation / total loss and the three ratios below) in ONE launch each way when the three
     # fused component ops left their result vectors (fused_losses.LossTail); else the composition that follows
+    # (the three private vectors never stay in the returned dict, whichever path runs: they are autograd tensors that would
+    # keep the graph alive, and a reused dict must not hand a stale one to a later call)
+    det_vec, cap_vec = d.pop("_det_vec", None), d.pop("_cap_vec", None)
+    d.pop("_rel_vec", None)
     tail = None
-    if fast and "_det_vec" in d and "_cap_vec" in d:
+    if fast and det_vec is not None and cap_vec is not None:
         from .backend import ops as _ops
         tail = getattr(_ops(), "loss_tail", None)
     if tail is None:
@@ -260,9 +264,9 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     if not detection:
         d["det_loss"] = zero
 
-    if tail is not None and "_rel_vec" in d:
-        d["loss"], out = tail(d.pop("_det_vec"), d.pop("_cap_vec"), d.pop("_rel_vec"), objectness_label, objectness_mask,
-                              d["bbox_mask"])
+    rel_vec = d.pop("_rel_vec", None)
+    if tail is not None and rel_vec is not None:
+        d["loss"], out = tail(det_vec, cap_vec, rel_vec, objectness_label, objectness_mask, d["bbox_mask"])
         d["box_loss"], d["det_loss"], d["relation_loss"] = out[0], out[1], out[2]
         d["pos_ratio"], d["neg_ratio"], d["obj_acc"] = out[4], out[5], out[6]
         return d

@@ -377,6 +377,16 @@ def stack_supported(layers, x):
     return True
 
 
+def decode_supported(layers, x, n_words):
+    """True when ``greedy_decode`` can run: everything ``stack_supported`` asks for, plus what ``spacap_decode_attn_f32``
+    requires (h = 8, d_k = 16, at most 32 cached positions) and one feed-forward width for the whole stack (one partial-sum
+    buffer).  Anything else decodes through the cached per-operator path (``decode_incremental``)."""
+    if not stack_supported(layers, x) or n_words + 1 > 32:
+        return False
+    dff = layers[0].feed_forward.w_1.out_features
+    return all(l.self_attn.h == 8 and l.self_attn.d_k == 16 and l.feed_forward.w_1.out_features == dff for l in layers)
+
+
 def run_stack(layers, final_norm, x, mask):
     """The N pre-norm layers (self-attention + feed-forward each) followed by ``final_norm``
     (models/transformer_captioner.py: Encoder :166-178 / Decoder :193-207 in early-guide mode)."""

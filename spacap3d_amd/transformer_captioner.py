@@ -579,7 +579,8 @@ class TransformerDecoderModel(nn.Module):
             indicator, dec_memory = obj_flat.unsqueeze(1), memory
         embed, pos = self.model.tgt_embed[0], self.model.tgt_embed[1]
         st = getattr(ops(), "tf_stack", None)
-        if self.early_guide and not self.training and st is not None and st.stack_supported(dec.layers, indicator.squeeze(1)):
+        if self.early_guide and not self.training and st is not None \
+                and st.decode_supported(dec.layers, indicator.squeeze(1), MAX_DES_LEN + 1):
             # pre-allocated key / value caches, one token per sequence and step, four launches per layer (tf_layer.greedy_decode)
             words = st.greedy_decode(dec, self.model.generator, embed, pos.pe, indicator.squeeze(1), self.word_to_idx["sos"],
                                      MAX_DES_LEN + 1)

@@ -262,6 +262,28 @@ def test_bench_runs_with_two_ranks_sharing_the_gpu():
     assert abs(rec["value"] - 2 * 2 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]   # whole-job scenes / s
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses): bench.py starts two fresh rank processes
+    itself before touching the GPU (reference: the one-command multi-GPU mode of scripts/train.py:198-200), rank 0 prints
+    one line with n_gpus 2.  Both ranks share cuda:0 over gloo here (1-GPU box)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SPACAP_SHARE_GPU="1", SPACAP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["parallelism"] == "dp2"
+    assert abs(rec["value"] - 2 * 2 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+
+
 def test_flat_adam_matches_torch_adam():
     """spacap3d_amd/optim.py (one launch over a flat parameter buffer) vs torch.optim.Adam with the reference's
     settings (scripts/train.py:262), 5 steps of random gradients on oddly shaped tensors."""

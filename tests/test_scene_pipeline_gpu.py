@@ -105,12 +105,12 @@ def test_own_draws_feed_a_training_step():
     assert torch.isfinite(loss)
 
 
-def _device_dataset_feats(fx, num_points, **kw):
+def _device_dataset_feats(fx, num_points, color_renorm="per_access", **kw):
     from spacap3d_amd.dataset import DeviceSceneDataset
     from tests.test_scene_pipeline import multiview_rows
     ds = DeviceSceneDataset(DEV, fx["mean_size_arr"], dict(zip(fx["nyu40id2class_keys"].tolist(), fx["nyu40id2class_vals"].tolist())),
                             dict(zip(fx["raw2label_names"].tolist(), fx["raw2label_vals"].tolist())), num_points=num_points,
-                            max_instances=64, color_renorm="per_access", **kw)   # (the fixture holds the reference's items, quirk included)
+                            max_instances=64, color_renorm=color_renorm, **kw)   # (the fixture holds the reference's items, quirk included)
     for sid in fx["scene_ids"].tolist():
         v = fx[f"{sid}/vert"]
         ds.add_scene(sid, v, fx[f"{sid}/ins"], fx[f"{sid}/sem"], fx[f"{sid}/bbox"], fx[f"{sid}/x"], fx[f"{sid}/y"], fx[f"{sid}/z"],
@@ -184,6 +184,9 @@ def test_colours_normalised_once_by_default_and_resettable_in_the_parity_mode():
     a = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
     b = ds.batch([0], draws=draws)["point_clouds"][..., 3:6]
     assert torch.equal(a, b) and float(a.abs().max()) <= 1.0
+    once = _device_dataset_feats(fx, 2000, color_renorm="once", **kw)      # the default mode keeps no raw copy
+    assert all("color0" not in sc for sc in once._scenes)
+    assert torch.equal(once.batch([0], draws=draws)["point_clouds"][..., 3:6], a)
     ds.color_renorm = "per_access"
     c = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
     assert not torch.equal(a, c)                       # normalised a second time

@@ -311,3 +311,24 @@ def test_single_launch_attention_backward_equals_the_two_launch_form(tf, B, L, m
     check(lib.spacap_mha_bwd_delta_f32(*args, lse.data_ptr(), dout.data_ptr(), delta.data_ptr(), g2.data_ptr(),
                                        g2.data_ptr() + hd * 4, g2.data_ptr() + 2 * hd * 4, 3 * hd, st), "bwd delta")
     assert rel(g2, g1) < 2e-5
+
+
+@pytest.mark.parametrize("h", [4, 16])
+def test_eval_with_other_head_counts_decodes_through_the_cached_operator_path(tf, h):
+    """The fused decode step needs h = 8, d_k = 16 (spacap_decode_attn_f32); a model built with another head count (the
+    constructor accepts any h dividing 128, models/transformer_captioner.py:268-287) must still decode -- through the cached
+    per-operator path -- and give the captions of the reference-style loop that recomputes the prefix."""
+    from spacap3d_amd import synthetic as S
+    from spacap3d_amd.engine import synthetic_batch
+    from spacap3d_amd.spacapnet import build_default
+    torch.manual_seed(0)
+    model = build_default(vocab_size=120, num_proposal=32, N=2, h=h, d_ff=256).to(DEV).eval()
+    dec = model.caption.model.decoder
+    x = torch.zeros(4, 128, device=DEV)
+    assert tf.stack_supported(dec.layers, x) and not tf.decode_supported(dec.layers, x, 31)
+    data = synthetic_batch(2, 4096, DEV, seed=1, vocab=120)
+    with torch.no_grad():
+        d = model(dict(data), is_eval=True)
+        d2 = model.caption.forward_eval(dict(d), use_cache=False)
+    assert d["lang_cap"].shape == d2["lang_cap"].shape == (2, 32, 31)
+    assert (d["lang_cap"] == d2["lang_cap"]).float().mean() > 0.995

@@ -24,6 +24,8 @@ def main():
     name_k = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k], r.get("Queue_Id", "0")) for r in rows)
     adam = [i for i, e in enumerate(ev) if "adam_flat_kernel" in e[2]]
+    if len(adam) < 2:
+        raise SystemExit(f"prof_timeline: found {len(adam)} `adam_flat_kernel` launches, need two to delimit a step")
     i0, i1 = adam[-2] + 1, adam[-1] + 1
     step = ev[i0:i1]
     t0 = step[0][0]

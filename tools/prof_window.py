@@ -1,66 +1,92 @@
 """Per-kernel statistics of the TIMED steps only, from a rocprofv3 --kernel-trace CSV of `bench.py`.
 
-The whole-run `--stats` summary also contains MIOpen's solver search and the op micro-benchmarks; the fused Adam
-kernel marks the end of every training step, so the window [end of step (total - K) ... end of the last step]
-holds exactly the K timed steps.
+The whole-run `--stats` summary also contains the warm-up steps and the op micro-benchmarks; `adam_flat_kernel` (one launch
+per training step, the step's last kernel) marks the end of every step, so the window
+[end of step (total - K) ... end of the last step] holds exactly the K timed steps.  The queue that carries
+`adam_flat_kernel` is the step's own stream ("main"); every other queue is the side stream (the next batch's sampling
+pyramid).  The table is ordered by summed MAIN-stream time: its first row is the kernel `bench.py` reports as `roofline`.
+
 Usage: python tools/prof_window.py <kernel_trace.csv> <K timed steps> [top N]
+Exits non-zero (and prints nothing to stdout) when the marker kernel is missing or there are fewer than K + 1 steps.
 """
 import collections
 import csv
+import re
 import sys
+
+csv.field_size_limit(1 << 30)
+MARKER = "adam_flat_kernel"
+
+
+def func_name(n):
+    """kernel function without template arguments / parameter list: the key bench.py matches on."""
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"^void ", "", n)
+    return re.split(r"[<(]", n, 1)[0].strip()
+
+
+def load(path):
+    rows = list(csv.DictReader(open(path, newline="")))
+    if not rows:
+        raise SystemExit(f"prof_window: {path} holds no kernel rows")
+    name_k = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k], r.get("Queue_Id", "0")) for r in rows)
+    return ev
+
+
+def window(ev, K):
+    marks = [e for e in ev if MARKER in e[2]]
+    if len(marks) < K + 1:
+        raise SystemExit(f"prof_window: found {len(marks)} `{MARKER}` launches, need at least {K + 1} "
+                         f"(one per step marks the step's end; was the optimizer kernel renamed or the trace cut short?)")
+    t0, t1 = marks[-K - 1][1], marks[-1][1]
+    main_q = marks[-1][3]
+    return [e for e in ev if t0 <= e[0] <= t1], t0, t1, main_q
 
 
 def main():
     path, K = sys.argv[1], int(sys.argv[2])
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 40
-    rows = list(csv.DictReader(open(path)))
-    name_k = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
-    ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[name_k]) for r in rows]
-    ev.sort()
-    adam = [e for e in ev if "FusedOptimizer" in e[2] or "multi_tensor_apply" in e[2]]
-    # group Adam kernels into steps (gaps > 1 ms separate steps)
-    steps, cur = [], [adam[0]]
-    for e in adam[1:]:
-        if e[0] - cur[-1][1] > 1_000_000:
-            steps.append(cur)
-            cur = [e]
-        else:
-            cur.append(e)
-    steps.append(cur)
-    t0 = steps[-K - 1][-1][1]
-    t1 = steps[-1][-1][1]
-    win = [e for e in ev if t0 <= e[0] <= t1]
-    tot = collections.Counter()
-    cnt = collections.Counter()
-    for s, e, n in win:
-        tot[n] += e - s
-        cnt[n] += 1
+    win, t0, t1, main_q = window(load(path), K)
+    tot, cnt, side = collections.Counter(), collections.Counter(), collections.Counter()
+    for s, e, n, q in win:
+        key = n
+        (tot if q == main_q else side)[key] += e - s
+        cnt[key] += 1
     wall = (t1 - t0) / 1e6 / K
-    busy = sum(tot.values()) / 1e6 / K
-    print(f"timed window: {K} steps, {wall:.2f} ms/step wall, {busy:.2f} ms/step summed kernel time, "
-          f"{len(win) / K:.0f} kernels/step")
-    # idle time of the step's own stream: gaps between consecutive kernels (the side-stream sampling pyramid excluded)
-    main = sorted(e for e in win if "fps_" not in e[2])
+    main_busy = sum(tot.values()) / 1e6 / K
+    side_busy = sum(side.values()) / 1e6 / K
+    n_main = sum(1 for e in win if e[3] == main_q)
+    print(f"timed window: {K} steps, {wall:.3f} ms/step wall, main stream {main_busy:.3f} ms/step summed kernel time in "
+          f"{n_main / K:.0f} kernels/step, side stream(s) {side_busy:.3f} ms/step in {(len(win) - n_main) / K:.0f} kernels/step")
+    main = sorted(e for e in win if e[3] == main_q)
     idle, end, gaps = 0, main[0][1], collections.Counter()
-    for s, e, n in main[1:]:
+    for s, e, n, q in main[1:]:
         if s > end:
             idle += s - end
             gaps[min((s - end) // 1000, 20)] += 1
         end = max(end, e)
-    print(f"main stream: {idle / 1e6 / K:.2f} ms/step idle between kernels; gap histogram (us: count/step) "
+    print(f"main stream: {idle / 1e6 / K:.3f} ms/step idle between kernels; gap histogram (us: count/step) "
           + ", ".join(f"{k}{'+' if k == 20 else ''}: {v / K:.0f}" for k, v in sorted(gaps.items())))
-    big = collections.Counter()
-    end, prev = main[0][1], main[0][2]
-    for s_, e, n in main[1:]:
-        if s_ - end > 20_000:
-            big[(prev[:60], n[:60])] += s_ - end
-        if e > end:
-            end, prev = e, n
-    for (a, b), v in big.most_common(12):
-        print(f"   idle {v / 1e3 / K:7.1f} us/step between  {a}  ->  {b}")
-    print("ms/step,calls/step,avg_us,kernel")
+    # the same kernels grouped by function (templates merged): what `roofline` names
+    by_fn, by_fn_cnt = collections.Counter(), collections.Counter()
+    for n, v in tot.items():
+        by_fn[func_name(n)] += v
+    for s, e, n, q in main:
+        by_fn_cnt[func_name(n)] += 1
+    lib = sum(v for n, v in by_fn.items() if n.startswith("Cijk_") or "naive_conv" in n or "miopen" in n.lower())
+    torch_glue = sum(v for n, v in by_fn.items() if n.startswith("at::native") or n.startswith("at::cuda"))
+    print(f"main stream by origin: rocBLAS/MIOpen {lib / 1e6 / K:.3f} ms/step, at::native {torch_glue / 1e6 / K:.3f} ms/step, "
+          f"own kernels {(sum(by_fn.values()) - lib - torch_glue) / 1e6 / K:.3f} ms/step")
+    print("main_ms/step,calls/step,avg_us,function")
+    for n, v in by_fn.most_common(top):
+        print(f"{v / 1e6 / K:.4f},{by_fn_cnt[n] / K:.1f},{v / by_fn_cnt[n] / 1e3:.1f},\"{n[:150]}\"")
+    print("# per instantiation (main stream first, then side stream)")
+    print("ms/step,calls/step,avg_us,stream,kernel")
     for n, v in tot.most_common(top):
-        print(f"{v / 1e6 / K:.3f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},\"{n[:150]}\"")
+        print(f"{v / 1e6 / K:.4f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},main,\"{n[:200]}\"")
+    for n, v in side.most_common(top):
+        print(f"{v / 1e6 / K:.4f},{cnt[n] / K:.1f},{v / cnt[n] / 1e3:.1f},side,\"{n[:200]}\"")
 
 
 if __name__ == "__main__":
