@@ -314,7 +314,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="sample inside the step instead of one step ahead")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", action="store_true", help="run the detection losses as a side-stream branch (slower since they are fused)")
     ap.add_argument("--ablate", default="", help="analysis only (NOT the headline metric): 'relation' drops the "
                                                  "relation head, 'caption' the whole captioner")
     ap.add_argument("--cpu-sample", type=int, default=4, help="scenes per step in the multi-core CPU-baseline sample")
@@ -348,8 +347,7 @@ def main():
     if args.ablate == "relation":
         model.caption.check_relation = False
         model.caption.model.encoder.layers[-1].self_attn.keep_value = False
-    trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"),
-                      multi_stream=args.streams)
+    trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=(args.ablate != "relation"))
     # each rank owns its own shard of scenes (seed + rank), resident in HBM before the timed region
     data = synthetic_batch(per_gpu, cfg["n_points"], dev, seed=1000 + rank, **cfg["feats"])
 
@@ -528,7 +526,6 @@ def main():
                        "global_batch": per_gpu * world, "parallelism": f"dp{world}",
                        "hip_graph": bool(graphed), "fps_prefetch_side_stream": nxt is not None,
                        "prefetch_as_graph": bool(graphed and nxt is not None and trainer_prefetch_graph), "reserved_cus_forward": reserved_cus, "geometry_prefetch": nxt is not None, "deferred_weight_gradients": True,
-                       "side_stream_branches": bool(args.streams),
                        "sa_forward_gemm": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if os.environ.get("SPACAP_SA_F32MFMA", "0") not in ("", "0") else
                                            "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},

@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void sa_mid_fwd_kernel(const float *__restrict
 //     a1 w1 + a1 w2 + a2 w1 + a2 w2 + a1 w3 + a3 w1        (dropped: a2 w3, a3 w2, a3 w3 <= 2^-24 |a w|)
 // each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16: 6/16 of the fp32-MFMA time for the same fp32-level result.
 // The kernels are in sa_bf3.inc (forward layers) and sa_bf3_dgrad.inc (data gradient).  Earlier variants of this layer (a
-// 32x32x2 fp32-MFMA kernel, an LDS-staged split-bf16 kernel, a streaming fp32 kernel, timing builds) live in
-// tools/lab/sa_variants/ and are not part of the library.
+// 32x32x2 fp32-MFMA kernel, an LDS-staged split-bf16 kernel, a streaming fp32 kernel, timing builds) are in the
+// history (round 2, `git log -- tools/lab/sa_variants`), not in the tree.
 using f32x16 = float __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -7,7 +7,6 @@ import os
 
 import torch
 
-from . import streams
 from . import synthetic as S
 from .detector import geometry_pyramid, sampling_pyramid
 from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
@@ -16,7 +15,7 @@ from .loss_helper import get_scene_cap_loss, start_detection_losses
 
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
-                 use_relation: bool = True, split_optimizer: bool = False, multi_stream: bool = False,
+                 use_relation: bool = True, split_optimizer: bool = False,
                  adam_eps: float = 1e-8):
         self.model = model
         self.mean_size_arr = mean_size_arr
@@ -42,9 +41,6 @@ class Trainer:
         self._recapture = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
-        # independent branches of the step (relation head, detection losses) on side streams (spacap3d_amd/streams.py);
-        # off by default: with the detection losses fused into four launches the single-stream graph is faster
-        self.multi_stream = multi_stream
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
         if next(model.parameters()).is_cuda:
             # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
@@ -125,8 +121,7 @@ class Trainer:
         return d
 
     def loss(self, data_dict):
-        # the detection losses only need the proposal module's outputs: started right after it (a side-stream branch
-        # when streams are enabled) so their ~300 tiny launches overlap with the Transformer
+        # the detection losses only need the proposal module's outputs: started right after it
         kw = dict(num_heading_bin=S.NUM_HEADING_BIN, num_size_cluster=S.NUM_SIZE_CLUSTER, mean_size_arr=self.mean_size_arr)
         need = ("vote_label", "center_label")
         early = (lambda d: start_detection_losses(d, **kw)) if all(k in data_dict for k in need) else None
@@ -240,7 +235,6 @@ class Trainer:
     def _core(self, data_dict, with_optimizer=True):
         """zero grads -> forward -> loss -> backward [-> all-reduce -> Adam]; no host sync, capturable."""
         pc = data_dict["point_clouds"]
-        streams.enable(self.multi_stream and pc.is_cuda)
         if pc.is_cuda:
             from .attention import advance_rng
             advance_rng(pc.device)  # new attention-dropout masks every step, also under graph replay
@@ -281,9 +275,6 @@ class Trainer:
                 d["loss"].backward()
         else:
             d["loss"].backward()
-        if pc.is_cuda:
-            streams.join_all(pc.device)  # side-stream branches (relation head, detection losses) re-join here
-        streams.enable(False)            # the switch is process-wide: do not leak it to callers outside the step
         if with_optimizer:
             self._optimizer_step(None)
         # the loss terms of this step as device scalars (no host sync; under graph replay: the static result tensors)

@@ -169,10 +169,7 @@ def _with(d, object_assignment, objectness_label):
 
 def start_detection_losses(d, num_heading_bin=1, num_size_cluster=18, mean_size_arr=None):
     """Vote / objectness / box / class losses (lib/loss_helper.py:291-345): everything that only needs the proposal
-    module's outputs.  Issued as a side-stream branch (spacap3d_amd/streams.py) when that is enabled -- the engine
-    calls this right after the proposal module so that the ~300 tiny launches run beside the Transformer -- and
-    joined in ``get_scene_cap_loss``."""
-    from . import streams
+    module's outputs.  The engine calls this right after the proposal module; ``get_scene_cap_loss`` picks the result up."""
     from .backend import ops
     fused = getattr(ops(), "detection_losses", None) if d["seed_xyz"].is_cuda else None
     if (fused is not None and "_proposal_net" in d and d["vote_xyz"].shape[1] == d["seed_xyz"].shape[1]
@@ -180,18 +177,16 @@ def start_detection_losses(d, num_heading_bin=1, num_size_cluster=18, mean_size_
         # one autograd op on the HIP library (fused_losses.py): 3 launches forward, 1 backward
         msa = _const(("msa", id(mean_size_arr)), d["seed_xyz"].device,
                      lambda: torch.as_tensor(mean_size_arr, dtype=torch.float32).clone())
-        with streams.branch("detection_loss", d["seed_xyz"]):
-            t = fused(d, num_heading_bin, num_size_cluster, msa, NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS)
+        t = fused(d, num_heading_bin, num_size_cluster, msa, NEAR_THRESHOLD, FAR_THRESHOLD, OBJECTNESS_CLS_WEIGHTS)
         d["object_assignment"], d["objectness_label"] = t[4], t[2]
         d["_detection_losses"] = t
         return
-    with streams.branch("detection_loss", d["seed_xyz"]):
-        vote_loss = compute_vote_loss(d)
-        objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)
-        center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
-            compute_box_and_sem_cls_loss(_with(d, object_assignment, objectness_label), num_heading_bin,
-                                         num_size_cluster, mean_size_arr)
-        box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
+    vote_loss = compute_vote_loss(d)
+    objectness_loss, objectness_label, objectness_mask, object_assignment = compute_objectness_loss(d)
+    center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss = \
+        compute_box_and_sem_cls_loss(_with(d, object_assignment, objectness_label), num_heading_bin,
+                                     num_size_cluster, mean_size_arr)
+    box_loss = center_loss + 0.1 * heading_cls_loss + heading_reg_loss + 0.1 * size_cls_loss + size_reg_loss
     d["_detection_losses"] = (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment,
                               center_loss, heading_cls_loss, heading_reg_loss, size_cls_loss, size_reg_loss,
                               sem_cls_loss, box_loss)
@@ -208,7 +203,6 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     dev = d["seed_xyz"].device
     zero = _const("zero", dev, lambda: torch.zeros(()))
 
-    from . import streams
     if "_detection_losses" not in d:
         start_detection_losses(d, num_heading_bin, num_size_cluster, mean_size_arr)
     (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment, center_loss, heading_cls_loss,
@@ -222,8 +216,6 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         d["cap_loss"], d["cap_acc"] = pair if pair is not None else compute_cap_loss(d)
     else:
         d["cap_loss"], d["cap_acc"], d["pred_ious"] = zero, zero, zero
-    streams.join("detection_loss", d["seed_xyz"])
-    streams.join("relation", d["seed_xyz"])
     total = objectness_label.shape[0] * objectness_label.shape[1]
     d["objectness_label"] = objectness_label
     d["objectness_mask"] = objectness_mask

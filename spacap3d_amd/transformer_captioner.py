@@ -520,21 +520,19 @@ class TransformerDecoderModel(nn.Module):
 
     def _relation_head(self, ep):
         """relation_pred (B,K,K,9) from the last encoder layer's attention map and values (:392-397)."""
-        from . import streams
         rp = self.relation_proposal  # Linear-ReLU-Linear-ReLU-Linear (:319-326)
         sa = self.model.encoder.layers[-1].self_attn
-        with streams.branch("relation", sa.attn):
-            # the whole head as one kernel each way (csrc/relation_fused.hip); other widths compose the layers below
-            head = getattr(ops(), "relation_head", None)
-            pred = head(sa.attn, sa.value, rp[0], rp[2], rp[4]) if head is not None else None
+        # the whole head as one kernel each way (csrc/relation_fused.hip); other widths compose the layers below
+        head = getattr(ops(), "relation_head", None)
+        pred = head(sa.attn, sa.value, rp[0], rp[2], rp[4]) if head is not None else None
+        if pred is None:
+            # feature (P (x) V) + first Linear + ReLU in one kernel: the (B,K,K,128) feature is never formed
+            hid = ops().relation_layer1(sa.attn, sa.value, rp[0].weight, rp[0].bias)
+            tail = getattr(ops(), "relation_tail", None)
+            pred = tail(hid, rp[2], rp[4]) if (tail is not None and torch.is_grad_enabled()) else None
             if pred is None:
-                # feature (P (x) V) + first Linear + ReLU in one kernel: the (B,K,K,128) feature is never formed
-                hid = ops().relation_layer1(sa.attn, sa.value, rp[0].weight, rp[0].bias)
-                tail = getattr(ops(), "relation_tail", None)
-                pred = tail(hid, rp[2], rp[4]) if (tail is not None and torch.is_grad_enabled()) else None
-                if pred is None:
-                    pred = tall_linear(F.relu(tall_linear(hid, rp[2])), rp[4])
-            ep["relation_pred"] = pred
+                pred = tall_linear(F.relu(tall_linear(hid, rp[2])), rp[4])
+        ep["relation_pred"] = pred
 
     def forward_eval(self, ep, use_cache=True):
         """Greedy decoding of B*K captions (:402-453).  The reference re-runs the 6-layer encoder AND the whole

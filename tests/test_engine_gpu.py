@@ -27,12 +27,11 @@ def _run(mode, steps=6):
     model = _make()
     # tiny learning rate: the first Adam steps at the reference's 1e-3 are chaotic on a repeated synthetic batch
     # (two identical eager runs drift apart by 3 % after three steps), which would hide real discrepancies
-    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=(mode == "graph-split"),
-                 multi_stream=mode.endswith("side-stream"))
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=(mode == "graph-split"))
     data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
-    nxt = data if mode in ("prefetch", "graph", "graph-split", "graph-side-stream") else None
+    nxt = data if mode in ("prefetch", "graph", "graph-split") else None
     losses = [float(tr.step(data, next_data=nxt))]
-    if mode in ("graph", "graph-split", "graph-side-stream"):
+    if mode in ("graph", "graph-split"):
         # enable_graph runs `warmup` real optimizer steps itself; account for them
         assert tr.enable_graph(data, warmup=2), tr.graph_error
         losses += [None, None]
@@ -49,12 +48,8 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
     c = _run("prefetch")
     g = _run("graph")
     gs = _run("graph-split")  # what a multi-rank run does: fwd+bwd in the graph, gradient packing + Adam outside
-    # the detection losses as a side-stream branch (spacap3d_amd/streams.py; optional, off by default)
-    e1 = _run("eager-side-stream")
-    g1 = _run("graph-side-stream")
     assert all(x == x and abs(x) < 1e5 for x in a)
-    for name, other in (("eager-again", b), ("prefetch", c), ("graph", g), ("graph-split", gs),
-                        ("eager-side-stream", e1), ("graph-side-stream", g1)):
+    for name, other in (("eager-again", b), ("prefetch", c), ("graph", g), ("graph-split", gs)):
         for i, (x, y) in enumerate(zip(a, other)):
             if y is None:
                 continue
@@ -318,8 +313,6 @@ def test_fused_detection_losses_match_the_torch_composition(num_proposal):
     from spacap3d_amd.engine import synthetic_batch
     from spacap3d_amd.loss_helper import start_detection_losses
     from spacap3d_amd.spacapnet import build_default
-    from spacap3d_amd import streams
-    streams.enable(False)   # this test reads the branch's results without the join get_scene_cap_loss performs
     torch.manual_seed(1)
     model = build_default(vocab_size=200, num_proposal=num_proposal, N=1, d_ff=64).to(DEV).train()
     data = synthetic_batch(3, 8192, DEV, seed=5, vocab=200)

@@ -8,8 +8,7 @@ implementations, each against float64 on the same inputs:
 The bar is the same for both -- fp32 GEMM accuracy, 2e-6 of the output's scale at K <= 128 (measured 2.5e-7 .. 4.5e-7) -- which
 is the gate under which the split-bf16 kernel is the default: it must be indistinguishable from an fp32 GEMM, not merely
 "close".  The switch is read once per process, so the fp32-MFMA leg runs in a child process.  (Earlier variants -- a 32x32x2
-fp32 kernel, an LDS-staged split kernel, a streaming fp32 kernel -- were held to the same bar in round 2 and now live under
-tools/lab/sa_variants/, outside the library.)
+fp32 kernel, an LDS-staged split kernel, a streaming fp32 kernel -- were held to the same bar in round 2 and have since been deleted.)
 """
 import os
 import subprocess
