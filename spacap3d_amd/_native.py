@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspacap_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i = ctypes.c_int
 _l = ctypes.c_long
@@ -94,8 +94,14 @@ SIGNATURES = {
     "spacap_sa_mid_fwd_pool_supported": (_i, [_i, _i, _i]),
     "spacap_sa_reserve_cus": (_i, [_i]),
     "spacap_sa_mid_fwd_pool_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
-    "spacap_sa_pool_finalize_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
-    "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_pool_finalize_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
+    "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
+    "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
+    "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),
+    "spacap_sa_l3bwd_prep_f32": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "spacap_sa_l3bwd_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
+    "spacap_sa_l3bwd_dw_f32": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "spacap_sa_bwd_finalize_f32": (_i, [_p, _i, _l, _p, _p, _p, _p, _p]),
     "spacap_sa_dgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_dgrad_l1_f32": (_i, [_p] * 10 + [_f] + [_i] * 6 + [_p, _p, _p]),

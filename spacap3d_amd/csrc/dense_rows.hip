@@ -1,0 +1,239 @@
+// Dense row products of any shape on point-major (row-major) operands, for gfx950 (MI355X).
+//
+//     out[r, n] = sum_k A[r, k] Wop[k, n] (+ bias[n]),     Wop[k, n] = trans_w ? W[n, k] : W[k, n]
+//
+// Callers (all were rocBLAS GEMMs inside the training step until round 4):
+//   * the first layer of a set-abstraction module's shared MLP commuted with the grouping gather: Y = F W1[:, 3:]^T over the
+//     SOURCE points and its data gradient dF = dY W1[:, 3:] (lib/pointnet2/pointnet2_modules.py:241-259 -> QueryAndGroup +
+//     the first Conv2d of SharedMLP; W1[:, 3:] is a column slice: row stride 3 + Cf, rows not 16-byte aligned);
+//   * the vocabulary projection of the caption head, forward / data gradient (models/transformer_captioner.py:93-100;
+//     3 001 words: neither K nor N a multiple of anything);
+//   * the relation head's per-head value projection U (models/transformer_captioner.py:319-326, first Linear) and the token
+//     projection of the d_model = 512 stress configuration.
+// Organisation (the row-panel kernel of the Transformer projections, csrc/sa_mlp.hip: linear_rows_kernel, made shape-agnostic):
+// one (16 MT rows) x 64 column tile per workgroup, each wave 16 columns; K in chunks of 128: the activations of a chunk in LDS,
+// that chunk's weights in registers (through LDS for the transposed case); v_mfma_f32_16x16x4_f32 (exact fp32 products).  Rows,
+// columns and the K tail are guarded (zero fill), every operand has its own row stride, vector loads are used where the
+// addresses allow and scalar ones elsewhere.  Two-level rows: row r = (r / rows_per_group, r % rows_per_group) lives at
+// group * group_stride + (within + skip) * ld -- the caption head reads positions 1.. of every sequence without a slice copy.
+// Optional split over K (gridDim.z slices, partial results [z][R][ldo] summed by the caller in order).
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
+
+struct RowsArgs {
+  const float *a;
+  const float *W;
+  const float *bias;
+  float *out;
+  long R, lda, ldw, ldo;
+  int K, CO;
+  long a_grp, a_gstride, a_skip;   // rows per group of A (0: plain rows), elements between groups, leading rows skipped per group
+  long o_grp, o_gstride, o_skip;   // the same for out; with o_zero the skipped leading rows of every group are written as zeros
+  int o_zero;
+  int kchunks_per_slice;           // split over K: 128-wide chunks per gridDim.z slice
+  long slice_stride;               // elements between the slices' partial results
+  int vec_a, vec_w, vec_o;         // 16-byte accesses allowed for A / W / out (alignment of base, stride and offsets)
+};
+
+__device__ __forceinline__ size_t row_off(long r, long grp, long gstride, long skip, long ld) {
+  if (grp <= 0) return (size_t)r * ld;
+  const long g = r / grp, t = r - g * grp;
+  return (size_t)g * gstride + (size_t)(t + skip) * ld;
+}
+
+template <bool TRANS_W, int MT>
+__global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
+  constexpr int KC = 128, LD = KC + 4, KS = KC / 4, TMR = 16 * MT, C4 = KC / 4, RSTEP = 256 / C4, NV = TMR * C4 / 256;
+  __shared__ __attribute__((aligned(16))) float s_a[TMR * LD];
+  __shared__ __attribute__((aligned(16))) float s_w[TRANS_W ? 64 * LD : 4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int cbb = blockIdx.y * 64, cb = cbb + w * 16;
+  const long row0 = (long)blockIdx.x * TMR;
+  const int c4 = tid % C4, r0 = tid / C4;
+  const int K = a.K, CO = a.CO;
+  const int nchunks = (K + KC - 1) / KC;
+  const int cbeg = blockIdx.z * a.kchunks_per_slice, cend = min(nchunks, cbeg + a.kchunks_per_slice);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = cbeg; c < cend; ++c) {
+    const int kc = c * KC;
+    if (c > cbeg) __syncthreads();
+    const int k0 = kc + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = r0 + i * RSTEP;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row0 + row < a.R && k0 < K) {
+        const float *p = a.a + row_off(row0 + row, a.a_grp, a.a_gstride, a.a_skip, a.lda) + k0;
+        if (a.vec_a && k0 + 3 < K) {
+          v = ld4(p);
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = k0 + u < K ? p[u] : 0.f;
+        }
+      }
+      st4(&s_a[row * LD + c4 * 4], v);
+    }
+    float wf[KS];
+    if (TRANS_W) {   // the 64 x 128 weight panel W[n][k] through LDS
+#pragma unroll
+      for (int i = 0; i < 64 * C4 / 256; ++i) {
+        const int n = r0 + i * RSTEP;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cbb + n < CO && k0 < K) {
+          const float *p = a.W + (size_t)(cbb + n) * a.ldw + k0;
+          if (a.vec_w && k0 + 3 < K) {
+            v = ld4(p);
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = k0 + u < K ? p[u] : 0.f;
+          }
+        }
+        st4(&s_w[n * LD + c4 * 4], v);
+      }
+    } else {         // W[k][n]: lane (l15, lg) takes column cb + l15 of the rows kc + 4 ks + lg
+      const bool cok = cb + l15 < CO;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = kc + ks * 4 + lg;
+        wf[ks] = (cok && k < K) ? a.W[(size_t)k * a.ldw + cb + l15] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (TRANS_W) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) wf[ks] = s_w[(w * 16 + l15) * LD + ks * 4 + lg];
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = MFMA16(wf[ks], s_a[(mt * 16 + l15) * LD + ks * 4 + lg], acc[mt]);
+  }
+  // acc[mt][u] = out[row0 + 16 mt + l15][cb + 4 lg + u]
+  const int n0 = cb + 4 * lg;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias && blockIdx.z == 0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bv[u] = n0 + u < CO ? a.bias[n0 + u] : 0.f;
+  }
+  float *outz = a.out + (size_t)blockIdx.z * a.slice_stride;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long row = row0 + mt * 16 + l15;
+    if (row < a.R && n0 < CO) {
+      float *o = outz + row_off(row, a.o_grp, a.o_gstride, a.o_skip, a.ldo) + n0;
+      const f32x4 v = acc[mt] + bv;
+      if (a.vec_o && n0 + 3 < CO) {
+        st4(o, v);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (n0 + u < CO) o[u] = v[u];
+      }
+      if (a.o_zero && a.o_grp > 0 && row % a.o_grp == 0) {   // the skipped leading rows of this row's group
+        for (long s = 0; s < a.o_skip; ++s) {
+          float *z = outz + (size_t)(row / a.o_grp) * a.o_gstride + (size_t)s * a.ldo + n0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (n0 + u < CO) z[u] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// out[e] = sum_z parts[z][e], e < n (the K slices in order)
+__global__ __launch_bounds__(256) void dense_sum_slices_kernel(const float *__restrict__ parts, int S, long n, long stride,
+                                                               float *__restrict__ out) {
+  const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= n) return;
+  if (e + 3 < n) {
+    f32x4 v = ld4(parts + e);
+    for (int z = 1; z < S; ++z) v += ld4(parts + (size_t)z * stride + e);
+    st4(out + e, v);
+  } else {
+    for (long i = e; i < n; ++i) {
+      float v = parts[i];
+      for (int z = 1; z < S; ++z) v += parts[(size_t)z * stride + i];
+      out[i] = v;
+    }
+  }
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+/* K slices spacap_dense_rows_f32 should be called with for (R, K, CO): 1 unless the tile grid alone leaves most of the chip
+   idle AND the reduction is long (the vocabulary projection's data gradient: 248 rows, K = 3 001). */
+extern "C" int spacap_dense_rows_slices(long R, int K, int CO) {
+  const long tiles = ((R + 31) / 32) * ((CO + 63) / 64);
+  const int chunks = (K + 127) / 128;
+  if (tiles >= 128 || chunks < 4) return 1;
+  long s = 256 / (tiles < 1 ? 1 : tiles);
+  if (s > chunks) s = chunks;
+  if (s > 16) s = 16;
+  return (int)(s < 1 ? 1 : s);
+}
+
+/* out[r, n] = sum_k A[r, k] Wop[k, n] (+ bias[n]); A f32 rows of K floats at stride lda, W f32 [CO, K] rows at stride ldw
+   (trans_w) or [K, CO] rows at stride ldw, out rows of CO floats at stride ldo; any R >= 0, K >= 1, CO >= 1.
+   Two-level rows (a_grp / o_grp > 0): row r of A lives at (r / a_grp) * a_gstride + (r % a_grp + a_skip) * lda, likewise for out;
+   o_zero: the o_skip leading rows of every output group are written as zeros.  a_grp = o_grp = 0: plain rows.
+   slices > 1: out receives `slices` partial results, `slice_stride` floats apart (bias in slice 0); sum them with
+   spacap_dense_sum_slices_f32. */
+extern "C" int spacap_dense_rows_f32(const float *a, long lda, long a_grp, long a_gstride, long a_skip, const float *W, long ldw,
+                                     int trans_w, const float *bias, long R, int K, int CO, float *out, long ldo, long o_grp,
+                                     long o_gstride, long o_skip, int o_zero, int slices, long slice_stride,
+                                     spacap_stream_t stream) {
+  const char *what = "spacap_dense_rows_f32";
+  SPACAP_REQUIRE(R >= 0 && K >= 1 && CO >= 1 && lda >= K && ldo >= CO && ldw >= (trans_w ? K : CO) && slices >= 1 && slices <= 64,
+                 "%s: (R=%ld, K=%d, CO=%d, lda=%ld, ldw=%ld, ldo=%ld, slices=%d) unsupported", what, R, K, CO, lda, ldw, ldo, slices);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(a && W && out, "%s: null pointer", what);
+  SPACAP_REQUIRE(a_grp >= 0 && o_grp >= 0 && a_skip >= 0 && o_skip >= 0 && (slices == 1 || slice_stride > 0), "%s: bad row groups", what);
+  RowsArgs g;
+  g.a = a, g.W = W, g.bias = bias, g.out = out, g.R = R, g.lda = lda, g.ldw = ldw, g.ldo = ldo, g.K = K, g.CO = CO;
+  g.a_grp = a_grp, g.a_gstride = a_gstride, g.a_skip = a_skip, g.o_grp = o_grp, g.o_gstride = o_gstride, g.o_skip = o_skip;
+  g.o_zero = o_zero;
+  const int chunks = (K + 127) / 128;
+  g.kchunks_per_slice = (chunks + slices - 1) / slices;
+  g.slice_stride = slice_stride;
+  g.vec_a = aligned16(a) && lda % 4 == 0 && (a_grp == 0 || a_gstride % 4 == 0);
+  g.vec_w = aligned16(W) && ldw % 4 == 0;
+  g.vec_o = aligned16(out) && ldo % 4 == 0 && (o_grp == 0 || o_gstride % 4 == 0) && (slices == 1 || slice_stride % 4 == 0);
+  hipStream_t s = spacap::as_stream(stream);
+  const bool small = R <= 1024;
+  const long tiles = small ? (R + 31) / 32 : (R + 63) / 64;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)tiles, (unsigned)((CO + 63) / 64), (unsigned)slices);
+  if (trans_w) {
+    if (small) hipLaunchKernelGGL((dense_rows_kernel<true, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((dense_rows_kernel<true, 4>), grid, dim3(256), 0, s, g);
+  } else {
+    if (small) hipLaunchKernelGGL((dense_rows_kernel<false, 2>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((dense_rows_kernel<false, 4>), grid, dim3(256), 0, s, g);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* out[e] = sum over the S slices of parts[z * stride + e], e < n, slices added in order. */
+extern "C" int spacap_dense_sum_slices_f32(const float *parts, int S, long n, long stride, float *out, spacap_stream_t stream) {
+  const char *what = "spacap_dense_sum_slices_f32";
+  SPACAP_REQUIRE(parts && out && S >= 1 && n >= 0 && stride >= n && stride % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(parts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                 "%s: bad arguments", what);
+  if (n == 0) return SPACAP_OK;
+  hipLaunchKernelGGL(dense_sum_slices_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, spacap::as_stream(stream), parts, S, n,
+                     stride, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

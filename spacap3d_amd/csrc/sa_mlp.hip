@@ -442,6 +442,7 @@ __device__ __forceinline__ void split3(float v, __bf16 &h, __bf16 &m, __bf16 &l)
 
 #include "sa_bf3.inc"
 #include "sa_bf3_dgrad.inc"
+#include "sa_l3bwd.inc"
 
 // ---- pooling forward: out[g, c] = max_s relu(bn(z[g*S+s, c])), first maximum ------------------------------------
 __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restrict__ z, const float *__restrict__ st,
@@ -478,8 +479,8 @@ __global__ __launch_bounds__(256) void sa_pool_fwd_kernel(const float *__restric
 // ---- pooling backward, pass 1: masked gradient dym = (out > 0) ? dout : 0 and the BN sums over the arg-max rows
 __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ out,
                                                           const uint8_t *__restrict__ arg, const float *__restrict__ z,
-                                                          const float *__restrict__ st, long G, int S, int C,
-                                                          float *__restrict__ dym, double *__restrict__ part) {
+                                                          const float *__restrict__ zmax, const float *__restrict__ st, long G,
+                                                          int S, int C, float *__restrict__ dym, double *__restrict__ part) {
   __shared__ float s_red[2][256];
   const int tid = threadIdx.x;
   const int c = tid % C;           // C in {64, 128, 256}: 256 / C groups per pass
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const float *__restric
     const size_t o = (size_t)g * C + c;
     const float dy = out[o] > 0.f ? dout[o] : 0.f;
     dym[o] = dy;
-    const float zz = z[((size_t)g * S + arg[o]) * C + c];
+    const float zz = zmax ? zmax[o] : z[((size_t)g * S + arg[o]) * C + c];
     s1 += dy;
     s2 += dy * ((zz - mean) * istd);
   }
@@ -1318,7 +1319,7 @@ extern "C" int spacap_sa_mid_fwd_f32(const float *zin, const float *st_in, const
 __global__ __launch_bounds__(256) void sa_pool_finalize_kernel(const float *__restrict__ cand_v, const uint8_t *__restrict__ cand_i,
                                                                const float *__restrict__ st, const float *__restrict__ gamma,
                                                                long G, int S, int C, float *__restrict__ out,
-                                                               uint8_t *__restrict__ arg) {
+                                                               uint8_t *__restrict__ arg, float *__restrict__ zmax) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= G * C) return;
   const long g = i / C;
@@ -1344,13 +1345,18 @@ __global__ __launch_bounds__(256) void sa_pool_finalize_kernel(const float *__re
   const float mean = s[0], sc = s[2], be = s[3], sg = gamma[c] >= 0.f ? 1.f : -1.f;
   const float v1 = fmaxf((sg * t1 - mean) * sc + be, 0.f);
   int a = i1;
+  float za = sg * t1;     // the pre-activation of the chosen row
   if (t2 > -INFINITY) {
     const float v2 = fmaxf((sg * t2 - mean) * sc + be, 0.f);
-    if (v2 == v1 && i2 < i1) a = i2;
+    if (v2 == v1 && i2 < i1) a = i2, za = sg * t2;
   }
   if (!(v1 > 0.f) || sc == 0.f) a = 0;
   out[i] = v1;
   arg[i] = (uint8_t)a;
+  // what the pooled layer's BatchNorm backward needs of z (xhat at the arg-max row) when z itself is not stored.  Where the
+  // choice fell back to row 0 -- the activation is 0: no gradient; or gamma == 0 exactly: a constant channel -- this is the
+  // best row's value, not row 0's (only d gamma of an exactly-zero gamma could tell the difference).
+  if (zmax) zmax[i] = za;
 }
 
 /* 1 when spacap_sa_mid_fwd_pool_f32 has a kernel for this layer (the streaming split-bf16 kernel is the active one). */
@@ -1406,7 +1412,7 @@ extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, 
                                           int Cin, int Cout, int S, float *zout, double *part, float *cand_v,
                                           uint8_t *cand_i, spacap_stream_t stream) {
   const char *what = "spacap_sa_mid_fwd_pool_f32";
-  SPACAP_REQUIRE(zin && st_in && W && gamma_out && zout && part && cand_v && cand_i && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(zin && st_in && W && gamma_out && part && cand_v && cand_i && R >= 1, "%s: bad arguments", what);   // (zout may be NULL)
   SPACAP_REQUIRE(spacap_sa_mid_fwd_pool_supported(Cin, Cout, S) && R % S == 0, "%s: (Cin=%d, Cout=%d, S=%d) unsupported", what,
                  Cin, Cout, S);
   hipStream_t s = spacap::as_stream(stream);
@@ -1430,12 +1436,12 @@ extern "C" int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, 
 
 /* out[g,c] = max_s relu(bn(z[g*S+s,c])) (first maximum) and its arg, from the candidates of spacap_sa_mid_fwd_pool_f32. */
 extern "C" int spacap_sa_pool_finalize_f32(const float *cand_v, const uint8_t *cand_i, const float *stats, const float *gamma,
-                                           long G, int S, int C, float *out, uint8_t *arg, spacap_stream_t stream) {
+                                           long G, int S, int C, float *out, uint8_t *arg, float *zmax, spacap_stream_t stream) {
   const char *what = "spacap_sa_pool_finalize_f32";
   SPACAP_REQUIRE(cand_v && cand_i && stats && gamma && out && arg && G >= 1 && C >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(S == 16 || S == 32 || S == 64, "%s: S=%d unsupported", what, S);
   hipLaunchKernelGGL(sa_pool_finalize_kernel, dim3(nblocks(G * C, 256)), dim3(256), 0, spacap::as_stream(stream), cand_v, cand_i,
-                     stats, gamma, G, S, C, out, arg);
+                     stats, gamma, G, S, C, out, arg, zmax);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -1450,14 +1456,79 @@ extern "C" int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G
   return SPACAP_OK;
 }
 
-extern "C" int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z,
+extern "C" int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z, const float *zmax,
                                       const float *stats, long G, int S, int C, float *dym, double *part,
                                       spacap_stream_t stream) {
   const char *what = "spacap_sa_pool_bwd_f32";
-  SPACAP_REQUIRE(dout && out && arg && z && stats && dym && part && G >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(dout && out && arg && (z || zmax) && stats && dym && part && G >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(C == 64 || C == 128 || C == 256, "%s: C=%d unsupported", what, C);
-  hipLaunchKernelGGL(sa_pool_bwd_kernel, dim3(NPART), dim3(256), 0, spacap::as_stream(stream), dout, out, arg, z, stats, G,
-                     S, C, dym, part);
+  hipLaunchKernelGGL(sa_pool_bwd_kernel, dim3(NPART), dim3(256), 0, spacap::as_stream(stream), dout, out, arg, z, zmax, stats,
+                     G, S, C, dym, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// ---- pooled last layer without z3 (sa_l3bwd.inc) ------------------------------------------------------------------------
+extern "C" int spacap_sa_l3bwd_supported(int C2, int C3, int S) { return l3bwd_shape(C2, C3, S) ? 1 : 0; }
+namespace {
+int l3bwd_grid(long R, int C2, int C3) {
+  const int tm = l3bwd_tile(C2);
+  long g = device_cus(), tiles = (R + tm - 1) / tm;
+  if (g > NPART) g = NPART;
+  if (g > tiles) g = tiles;
+  return (int)(g < 1 ? 1 : g);
+}
+}  // namespace
+/* workgroups (= partial results) of spacap_sa_l3bwd_f32, and floats per partial: [C3][C2] | [C2][C2] | [C2] */
+extern "C" int spacap_sa_l3bwd_parts(long R, int C2, int C3) { return l3bwd_shape(C2, C3, 16) && R >= 1 ? l3bwd_grid(R, C2, C3) : 0; }
+extern "C" long spacap_sa_l3bwd_part_floats(int C2, int C3) { return (long)C3 * C2 + (long)C2 * C2 + C2; }
+
+/* Mneg [C2][C2] = -(W3^T diag(k1) W3), vrow [C2] = k0 W3 from the pooled layer's backward constants coef3 [C3][4]. */
+extern "C" int spacap_sa_l3bwd_prep_f32(const float *coef3, const float *W3, int C3, int C2, float *Mneg, float *vrow,
+                                        spacap_stream_t stream) {
+  const char *what = "spacap_sa_l3bwd_prep_f32";
+  SPACAP_REQUIRE(coef3 && W3 && Mneg && vrow && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_l3_prep_kernel, dim3(C2 + 1), dim3(256), 0, spacap::as_stream(stream), coef3, W3, C3, C2, Mneg, vrow);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* dy2 [R][C2] and the partial sums of dW3 from (dym, arg) of the pooled layer, z2 and the constants of spacap_sa_l3bwd_prep_f32;
+   part receives layer 2's BatchNorm sums (sum dy2, sum dy2 xhat2).  partW [spacap_sa_l3bwd_parts][spacap_sa_l3bwd_part_floats]. */
+extern "C" int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, const float *coef3, const float *W3, const float *Mneg,
+                                   const float *vrow, const float *z2, const float *st2, long R, int C3, int C2, float *dy2,
+                                   double *part, float *partW, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l3bwd_f32";
+  SPACAP_REQUIRE(dym && arg && coef3 && W3 && Mneg && vrow && z2 && st2 && dy2 && part && partW && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(l3bwd_shape(C2, C3, S) && R % S == 0, "%s: (C2=%d, C3=%d, S=%d) unsupported", what, C2, C3, S);
+  const L3Args a{dym, arg, coef3, W3, Mneg, vrow, z2, st2, R, S, dy2, part, partW};
+  const int grid = l3bwd_grid(R, C2, C3);
+  hipStream_t s = spacap::as_stream(stream);
+#define L3(C2V, C3V, TV)                                                                                                          \
+  {                                                                                                                               \
+    static unsigned long long lds_ok = 0;                                                                                         \
+    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&sa_l3bwd_kernel<C2V, C3V, TV>),                    \
+                                               (int)l3bwd_lds_bytes(C2V, TV), lds_ok), what);                                     \
+    hipLaunchKernelGGL((sa_l3bwd_kernel<C2V, C3V, TV>), dim3(grid), dim3(C2V * 4), l3bwd_lds_bytes(C2V, TV), s, a);               \
+  }
+  if (C2 == 64) L3(64, 128, 64)
+  else if (C3 == 128) L3(128, 128, 32)
+  else L3(128, 256, 32)
+#undef L3
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* dW3 [C3][C2] from the workgroups' partials: sums (double scratch, spacap_sa_l3bwd_part_floats entries) then
+   dW3 = S + k0 (x) colsum(a2) - diag(k1) W3 Gram. */
+extern "C" int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const float *coef3, const float *W3, int C3, int C2, double *sums,
+                                      float *dW3, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l3bwd_dw_f32";
+  SPACAP_REQUIRE(partW && coef3 && W3 && sums && dW3 && nparts >= 1 && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
+  const long n = spacap_sa_l3bwd_part_floats(C2, C3);
+  hipStream_t s = spacap::as_stream(stream);
+  hipLaunchKernelGGL(sa_l3_sum_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, partW, nparts, n, sums);
+  hipLaunchKernelGGL(sa_l3_dw_kernel, dim3(C3), dim3(256), 0, s, sums, coef3, W3, C3, C2, dW3);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -1553,20 +1624,38 @@ extern "C" int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const 
 // (S1 [C1][4] | S3 [C1][4]) interleaved per channel as [c][2][4], then S2 [4]; coef [C1][4] = (g, k0, k1, .) of layer 1:
 //   dW1[c][d] = g[c] S1[c][d] + k0[c] S2[d] - k1[c] S3[c][d],  sums over the partials in double, d < ldw columns written.
 namespace {
-__global__ __launch_bounds__(1024) void sa_l1_dw_kernel(const float *__restrict__ part_l1, int nparts, const float *__restrict__ coef,
-                                                        int C1, int ldw, float *__restrict__ dW1) {
-  extern __shared__ double s_sum[];   // [C1 * 8 + 4]
+// one workgroup per channel c: its 12 sums (S1[c][0..3], S3[c][0..3], S2[0..3]) over the partial rows, 16 lanes per sum with
+// independent loads (the first version ran the nparts loads of every sum as one dependent chain on ONE workgroup: 262 us),
+// lanes combined in a fixed order in double
+__global__ __launch_bounds__(256) void sa_l1_dw_kernel(const float *__restrict__ part_l1, int nparts, const float *__restrict__ coef,
+                                                       int C1, int ldw, float *__restrict__ dW1) {
+  __shared__ double s_lane[12][17];
+  __shared__ double s_sum[12];
+  const int c = blockIdx.x, tid = threadIdx.x, sidx = tid >> 4, l = tid & 15;
   const int n = C1 * 8 + 4;
-  for (int e = threadIdx.x; e < n; e += 1024) {
-    double a = 0.0;
-    for (int p = 0; p < nparts; ++p) a += (double)part_l1[(size_t)p * n + e];
-    s_sum[e] = a;
+  if (sidx < 12) {
+    const int e = sidx < 8 ? c * 8 + sidx : C1 * 8 + (sidx - 8);   // [c][2][4] then S2 [4]
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int p = l;
+    for (; p + 48 < nparts; p += 64) {
+      a0 += (double)part_l1[(size_t)p * n + e];
+      a1 += (double)part_l1[(size_t)(p + 16) * n + e];
+      a2 += (double)part_l1[(size_t)(p + 32) * n + e];
+      a3 += (double)part_l1[(size_t)(p + 48) * n + e];
+    }
+    for (; p < nparts; p += 16) a0 += (double)part_l1[(size_t)p * n + e];
+    s_lane[sidx][l] = (a0 + a1) + (a2 + a3);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < C1 * ldw; e += 1024) {
-    const int c = e / ldw, d = e - c * ldw;
+  if (tid < 12) {
+    double a = 0.0;
+    for (int i = 0; i < 16; ++i) a += s_lane[tid][i];
+    s_sum[tid] = a;
+  }
+  __syncthreads();
+  if (tid < ldw) {
     const double g = coef[c * 4 + 0], k0 = coef[c * 4 + 1], k1 = coef[c * 4 + 2];
-    dW1[e] = (float)(g * s_sum[(c * 2 + 0) * 4 + d] + k0 * s_sum[C1 * 8 + d] - k1 * s_sum[(c * 2 + 1) * 4 + d]);
+    dW1[c * ldw + tid] = (float)(g * s_sum[tid] + k0 * s_sum[8 + tid] - k1 * s_sum[4 + tid]);
   }
 }
 }  // namespace
@@ -1574,8 +1663,7 @@ extern "C" int spacap_sa_l1_dw_f32(const float *part_l1, int nparts, const float
                                    spacap_stream_t stream) {
   const char *what = "spacap_sa_l1_dw_f32";
   SPACAP_REQUIRE(part_l1 && coef && dW1 && nparts >= 1 && C1 >= 1 && C1 <= 512 && ldw >= 1 && ldw <= 4, "%s: bad arguments", what);
-  hipLaunchKernelGGL(sa_l1_dw_kernel, dim3(1), dim3(1024), (size_t)(C1 * 8 + 4) * sizeof(double), spacap::as_stream(stream), part_l1,
-                     nparts, coef, C1, ldw, dW1);
+  hipLaunchKernelGGL(sa_l1_dw_kernel, dim3(C1), dim3(256), 0, spacap::as_stream(stream), part_l1, nparts, coef, C1, ldw, dW1);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

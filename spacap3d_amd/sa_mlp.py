@@ -15,6 +15,9 @@ from ._native import check, lib, sum_slabs
 
 # SA1-shaped modules (no point features, 64 -> 64 -> ...): do not store the first layer's pre-activation (see _SAMLP.forward)
 RECOMPUTE_Z1 = True
+# pooled last layer: do not store its pre-activation z3; its backward is one pass over z2 (see _SAMLP.backward).  False restores
+# the stored-z3 path (the A/B leg of tests/test_sa_mlp_gpu.py)
+Z3_FREE = True
 
 
 def _ptr(t):
@@ -52,7 +55,12 @@ class _SAMLP(Function):
             has_feat = int(feat is not None)
             z1 = torch.empty(R, 4 if recompute else C1, **f32)
             z2 = torch.empty(R, C2, **f32)
-            z3 = torch.empty(R, C3, **f32)
+            # pooled last layer: when the z3-free backward has a kernel for this shape (csrc/sa_l3bwd.inc) the layer's
+            # pre-activation is never stored -- the forward keeps the pooling candidates, the backward the arg-max rows' values
+            pool_fused = bool(lib.spacap_sa_mid_fwd_pool_supported(C2, C3, S))
+            z3_free = Z3_FREE and pool_fused and bool(lib.spacap_sa_l3bwd_supported(C2, C3, S))
+            z3 = None if z3_free else torch.empty(R, C3, **f32)
+            zmax = torch.empty(B, N, C3, **f32) if z3_free else None
 
             def finalize(k, C, gamma, beta):
                 bn = bns[k]
@@ -84,7 +92,7 @@ class _SAMLP(Function):
             finalize(1, C2, g2, b2)
             out = torch.empty(B, N, C3, **f32)
             arg = torch.empty(B, N, C3, dtype=torch.uint8, device=dev)
-            if lib.spacap_sa_mid_fwd_pool_supported(C2, C3, S):
+            if pool_fused:
                 # the last layer's kernel leaves the two best pooling candidates per (sub-group, channel); once the layer's
                 # statistics are final a G x C3 pass picks the first maximum: z3 is not read again in the forward
                 nsub = R // min(S, 32)
@@ -92,18 +100,21 @@ class _SAMLP(Function):
                 cand_v = torch.empty(nsub, C3, 2, **f32)
                 cand_i = torch.empty(nsub, C3, 2, dtype=torch.uint8, device=dev)
                 check(lib.spacap_sa_mid_fwd_pool_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), g3c.data_ptr(), R, C2, C3,
-                                                     S, z3.data_ptr(), part.data_ptr(), cand_v.data_ptr(), cand_i.data_ptr(), st),
+                                                     S, _ptr(z3), part.data_ptr(), cand_v.data_ptr(), cand_i.data_ptr(), st),
                       "spacap_sa_mid_fwd_pool_f32")
                 finalize(2, C3, g3, b3)
                 check(lib.spacap_sa_pool_finalize_f32(cand_v.data_ptr(), cand_i.data_ptr(), stats[2].data_ptr(), g3c.data_ptr(),
-                                                      G, S, C3, out.data_ptr(), arg.data_ptr(), st), "spacap_sa_pool_finalize_f32")
+                                                      G, S, C3, out.data_ptr(), arg.data_ptr(), _ptr(zmax), st),
+                      "spacap_sa_pool_finalize_f32")
             else:
                 check(lib.spacap_sa_mid_fwd_f32(z2.data_ptr(), stats[1].data_ptr(), W3c.data_ptr(), R, C2, C3, z3.data_ptr(),
                                                 part.data_ptr(), st), "spacap_sa_mid_fwd_f32")
                 finalize(2, C3, g3, b3)
                 check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
                                                  st), "spacap_sa_pool_fwd_f32")
-        ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg)
+        ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3 if z3 is not None else zmax, stats[0], stats[1],
+                              stats[2], out, arg)
+        ctx.z3_free = z3_free         # the saved "z3" is then zmax (B, N, C3): the arg-max rows' pre-activations
         ctx.pm = pm                   # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)
         ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
@@ -136,18 +147,36 @@ class _SAMLP(Function):
 
             # pooled layer: masked gradient + BN sums over the arg-max rows
             dym = torch.empty(G, C3, **f32)
-            check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), z3.data_ptr(), st3.data_ptr(),
-                                             G, S, C3, dym.data_ptr(), part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
+            z3_free = ctx.z3_free
+            check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), None if z3_free else z3.data_ptr(),
+                                             z3.data_ptr() if z3_free else None, st3.data_ptr(), G, S, C3, dym.data_ptr(),
+                                             part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
             finalize(2, C3, st3)
-            # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
-            pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
-            check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
-                                          z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-            dW3 = sum_slabs(pw, deferrable=True)
             dy2 = torch.empty(R, C2, **f32)
-            check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
-                                          W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
-                                          part.data_ptr(), st), "spacap_sa_dgrad_f32")
+            if z3_free:
+                # layer 3 without z3: ONE pass over z2 gives dy2, layer 2's BN sums and the partial sums of dW3
+                # (csrc/sa_l3bwd.inc: dy2 = (g d) W3 + k0 W3 - a2 M;  dW3 = (g d)^T a2 + k0 (x) colsum a2 - diag(k1) W3 a2^T a2)
+                mneg, vrow = torch.empty(C2, C2, **f32), torch.empty(C2, **f32)
+                check(lib.spacap_sa_l3bwd_prep_f32(coef[2].data_ptr(), W3.data_ptr(), C3, C2, mneg.data_ptr(), vrow.data_ptr(), st),
+                      "spacap_sa_l3bwd_prep_f32")
+                npw, nfl = int(lib.spacap_sa_l3bwd_parts(R, C2, C3)), int(lib.spacap_sa_l3bwd_part_floats(C2, C3))
+                pw = torch.empty(npw, nfl, **f32)
+                check(lib.spacap_sa_l3bwd_f32(dym.data_ptr(), arg.data_ptr(), S, coef[2].data_ptr(), W3.data_ptr(), mneg.data_ptr(),
+                                              vrow.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
+                                              part.data_ptr(), pw.data_ptr(), st), "spacap_sa_l3bwd_f32")
+                sums = torch.empty(nfl, dtype=torch.float64, device=dev)
+                dW3 = torch.empty(C3, C2, **f32)
+                check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef[2].data_ptr(), W3.data_ptr(), C3, C2, sums.data_ptr(),
+                                                 dW3.data_ptr(), st), "spacap_sa_l3bwd_dw_f32")
+            else:
+                # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
+                pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
+                check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                              z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+                dW3 = sum_slabs(pw, deferrable=True)
+                check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                              W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
+                                              part.data_ptr(), st), "spacap_sa_dgrad_f32")
             finalize(1, C2, st2)
             # layer 2
             pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)

@@ -313,10 +313,10 @@ def test_single_launch_attention_backward_equals_the_two_launch_form(tf, B, L, m
     assert rel(g2, g1) < 2e-5
 
 
-@pytest.mark.parametrize("h", [4, 16])
+@pytest.mark.parametrize("h", [4, 2])
 def test_eval_with_other_head_counts_decodes_through_the_cached_operator_path(tf, h):
     """The fused decode step needs h = 8, d_k = 16 (spacap_decode_attn_f32); a model built with another head count (the
-    constructor accepts any h dividing 128, models/transformer_captioner.py:268-287) must still decode -- through the cached
+    constructor accepts any h dividing 128, models/transformer_captioner.py:268-287; the attention kernels take d_k = 16, 32, 64) must still decode -- through the cached
     per-operator path -- and give the captions of the reference-style loop that recomputes the prefix."""
     from spacap3d_amd import synthetic as S
     from spacap3d_amd.engine import synthetic_batch

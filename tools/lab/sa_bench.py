@@ -34,7 +34,7 @@ def bench(name, B, Np, N, S, C1, C2, C3):
     res["finalize"] = timeit(lambda: check(lib.spacap_sa_bn_finalize_f32(part.data_ptr(), C3, R, 1e-5, 0.1, g.data_ptr(), g.data_ptr(), None, None, s3.data_ptr(), st), "x"))
     s3 = stats(C3)
     res["pool_fwd"] = timeit(lambda: check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), s3.data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(), st), "x"))
-    res["pool_bwd"] = timeit(lambda: check(lib.spacap_sa_pool_bwd_f32(dym.data_ptr(), out.data_ptr(), arg.data_ptr(), z3.data_ptr(), s3.data_ptr(), G, S, C3, dym.data_ptr(), part.data_ptr(), st), "x"))
+    res["pool_bwd"] = timeit(lambda: check(lib.spacap_sa_pool_bwd_f32(dym.data_ptr(), out.data_ptr(), arg.data_ptr(), z3.data_ptr(), None, s3.data_ptr(), G, S, C3, dym.data_ptr(), part.data_ptr(), st), "x"))
     pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
     res["wgrad L3"] = timeit(lambda: check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(), z2.data_ptr(), s2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "x"))
     res["wgrad L3 sum"] = timeit(lambda: pw.sum(0))
