@@ -596,6 +596,26 @@ int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const float *const *
                                      const int *N, const int *nslabs, const int *with_bias, float *const *part, int njobs,
                                      spacap_stream_t stream);
 
+/* Dense row products of any shape (csrc/dense_rows.hip):  out[r, n] = sum_k A[r, k] Wop[k, n] (+ bias[n]),
+   Wop[k, n] = trans_w ? W[n, k] : W[k, n].  A: rows of K floats at stride lda; W: [CO, K] (trans_w) or [K, CO] rows at stride
+   ldw (a column slice of a wider matrix is fine: no alignment required); out: rows of CO floats at stride ldo.  Any R >= 0,
+   K >= 1, CO >= 1.  Two-level rows (a_grp / o_grp > 0): row r lives at (r / grp) * gstride + (r % grp + skip) * ld -- the
+   caption head reads positions 1.. of every sequence in place (models/transformer_captioner.py:373-379: out[:, 1:, :]) and
+   its data gradient is written straight into the padded layout (o_zero: the skipped leading rows of every group are zeroed).
+   slices > 1 splits the reduction over K: `slices` partial results `slice_stride` floats apart (bias in slice 0), to be
+   added in order by spacap_dense_sum_slices_f32; spacap_dense_rows_slices gives the split worth using for a shape.
+   batch != 0: the `slices` are independent products instead (operand z at a + z a_zstride, W + z w_zstride, out + z
+   slice_stride; bias shared).
+   Replaces the rocBLAS GEMMs of: the set-abstraction modules' first-layer feature product F W1[:, 3:]^T and its data gradient
+   (lib/pointnet2/pointnet2_modules.py:241-259, first Conv2d of the SharedMLP commuted with the grouping), the vocabulary
+   projection (models/transformer_captioner.py:93-100), the relation head's value projection (:319-326). */
+int spacap_dense_rows_slices(long R, int K, int CO);
+int spacap_dense_rows_f32(const float *a, long lda, long a_grp, long a_gstride, long a_skip, const float *W, long ldw, int trans_w,
+                          const float *bias, long R, int K, int CO, float *out, long ldo, long o_grp, long o_gstride, long o_skip,
+                          int o_zero, int slices, long slice_stride, int batch, long a_zstride, long w_zstride,
+                          spacap_stream_t stream);
+int spacap_dense_sum_slices_f32(const float *parts, int S, long n, long stride, float *out, spacap_stream_t stream);
+
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
  * a f32 [R,K], Wop[k,n] = trans_w ? W[n,k] (W f32 [CO,K]: y = x W^T) : W[k,n] (W f32 [K,CO]: dx = g W), bias f32 [CO]

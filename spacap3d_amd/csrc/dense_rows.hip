@@ -36,8 +36,10 @@ struct RowsArgs {
   long a_grp, a_gstride, a_skip;   // rows per group of A (0: plain rows), elements between groups, leading rows skipped per group
   long o_grp, o_gstride, o_skip;   // the same for out; with o_zero the skipped leading rows of every group are written as zeros
   int o_zero;
-  int kchunks_per_slice;           // split over K: 128-wide chunks per gridDim.z slice
-  long slice_stride;               // elements between the slices' partial results
+  int kchunks_per_slice;           // split over K: 128-wide chunks per gridDim.z slice (all of them when z is a batch index)
+  long slice_stride;               // elements between the slices' results
+  long a_zstride, w_zstride;       // batch mode (split_k == 0): elements between the z-th operands
+  int split_k;
   int vec_a, vec_w, vec_o;         // 16-byte accesses allowed for A / W / out (alignment of base, stride and offsets)
 };
 
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
   const int c4 = tid % C4, r0 = tid / C4;
   const int K = a.K, CO = a.CO;
   const int nchunks = (K + KC - 1) / KC;
-  const int cbeg = blockIdx.z * a.kchunks_per_slice, cend = min(nchunks, cbeg + a.kchunks_per_slice);
+  const int cbeg = a.split_k ? blockIdx.z * a.kchunks_per_slice : 0, cend = a.split_k ? min(nchunks, cbeg + a.kchunks_per_slice) : nchunks;
+  const float *Ab = a.a + (size_t)blockIdx.z * a.a_zstride, *Wb = a.W + (size_t)blockIdx.z * a.w_zstride;
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
       const int row = r0 + i * RSTEP;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row0 + row < a.R && k0 < K) {
-        const float *p = a.a + row_off(row0 + row, a.a_grp, a.a_gstride, a.a_skip, a.lda) + k0;
+        const float *p = Ab + row_off(row0 + row, a.a_grp, a.a_gstride, a.a_skip, a.lda) + k0;
         if (a.vec_a && k0 + 3 < K) {
           v = ld4(p);
         } else {
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
         const int n = r0 + i * RSTEP;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (cbb + n < CO && k0 < K) {
-          const float *p = a.W + (size_t)(cbb + n) * a.ldw + k0;
+          const float *p = Wb + (size_t)(cbb + n) * a.ldw + k0;
           if (a.vec_w && k0 + 3 < K) {
             v = ld4(p);
           } else {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int k = kc + ks * 4 + lg;
-        wf[ks] = (cok && k < K) ? a.W[(size_t)k * a.ldw + cb + l15] : 0.f;
+        wf[ks] = (cok && k < K) ? Wb[(size_t)k * a.ldw + cb + l15] : 0.f;
       }
     }
     __syncthreads();
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
   // acc[mt][u] = out[row0 + 16 mt + l15][cb + 4 lg + u]
   const int n0 = cb + 4 * lg;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias && blockIdx.z == 0) {
+  if (a.bias && (blockIdx.z == 0 || !a.split_k)) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) bv[u] = n0 + u < CO ? a.bias[n0 + u] : 0.f;
   }
@@ -187,12 +190,13 @@ extern "C" int spacap_dense_rows_slices(long R, int K, int CO) {
    (trans_w) or [K, CO] rows at stride ldw, out rows of CO floats at stride ldo; any R >= 0, K >= 1, CO >= 1.
    Two-level rows (a_grp / o_grp > 0): row r of A lives at (r / a_grp) * a_gstride + (r % a_grp + a_skip) * lda, likewise for out;
    o_zero: the o_skip leading rows of every output group are written as zeros.  a_grp = o_grp = 0: plain rows.
-   slices > 1: out receives `slices` partial results, `slice_stride` floats apart (bias in slice 0); sum them with
-   spacap_dense_sum_slices_f32. */
+   slices > 1, batch == 0: out receives `slices` partial results over K, `slice_stride` floats apart (bias in slice 0); sum them
+   with spacap_dense_sum_slices_f32.  batch != 0: `slices` independent products, operand z at a + z a_zstride, W + z w_zstride,
+   out + z slice_stride (the relation head's per-head value projection: 8 heads, 16-wide windows of one weight matrix). */
 extern "C" int spacap_dense_rows_f32(const float *a, long lda, long a_grp, long a_gstride, long a_skip, const float *W, long ldw,
                                      int trans_w, const float *bias, long R, int K, int CO, float *out, long ldo, long o_grp,
-                                     long o_gstride, long o_skip, int o_zero, int slices, long slice_stride,
-                                     spacap_stream_t stream) {
+                                     long o_gstride, long o_skip, int o_zero, int slices, long slice_stride, int batch,
+                                     long a_zstride, long w_zstride, spacap_stream_t stream) {
   const char *what = "spacap_dense_rows_f32";
   SPACAP_REQUIRE(R >= 0 && K >= 1 && CO >= 1 && lda >= K && ldo >= CO && ldw >= (trans_w ? K : CO) && slices >= 1 && slices <= 64,
                  "%s: (R=%ld, K=%d, CO=%d, lda=%ld, ldw=%ld, ldo=%ld, slices=%d) unsupported", what, R, K, CO, lda, ldw, ldo, slices);
@@ -206,8 +210,10 @@ extern "C" int spacap_dense_rows_f32(const float *a, long lda, long a_grp, long 
   const int chunks = (K + 127) / 128;
   g.kchunks_per_slice = (chunks + slices - 1) / slices;
   g.slice_stride = slice_stride;
-  g.vec_a = aligned16(a) && lda % 4 == 0 && (a_grp == 0 || a_gstride % 4 == 0);
-  g.vec_w = aligned16(W) && ldw % 4 == 0;
+  g.split_k = batch ? 0 : 1;
+  g.a_zstride = batch ? a_zstride : 0, g.w_zstride = batch ? w_zstride : 0;
+  g.vec_a = aligned16(a) && lda % 4 == 0 && (a_grp == 0 || a_gstride % 4 == 0) && g.a_zstride % 4 == 0;
+  g.vec_w = aligned16(W) && ldw % 4 == 0 && g.w_zstride % 4 == 0;
   g.vec_o = aligned16(out) && ldo % 4 == 0 && (o_grp == 0 || o_gstride % 4 == 0) && (slices == 1 || slice_stride % 4 == 0);
   hipStream_t s = spacap::as_stream(stream);
   const bool small = R <= 1024;
@@ -234,6 +240,69 @@ extern "C" int spacap_dense_sum_slices_f32(const float *parts, int S, long n, lo
   if (n == 0) return SPACAP_OK;
   hipLaunchKernelGGL(dense_sum_slices_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, spacap::as_stream(stream), parts, S, n,
                      stride, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// ---- weight + bias gradient of a row product with FEW rows and a wide output (the vocabulary projection: 248 rows, 3 001 x 128):
+//   dW[m][n] = sum_r G[r][m] X[r][n],   db[m] = sum_r G[r][m]
+// One 64 (m) x 128 (n) tile per workgroup, thread = 8 m x 4 n, the rows added in ascending order (no partial results).  X rows may
+// be two-level (positions 1.. of every sequence).  Plain fp32 FMAs: 0.2 GFLOP, a latency-bound launch either way.
+namespace {
+__global__ __launch_bounds__(256) void dense_wgrad_small_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X,
+                                                                long ldx, long x_grp, long x_gstride, long x_skip, long R, int M, int N,
+                                                                float *__restrict__ dW, float *__restrict__ db) {
+  const int tid = threadIdx.x, n4 = tid & 31, mq = tid >> 5;
+  const int m0 = blockIdx.x * 64 + mq * 8, n0 = blockIdx.y * 128 + n4 * 4;
+  float acc[8][4], sb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sb[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[i][u] = 0.f;
+  }
+  const bool nok = n0 < N;
+  for (long r = 0; r < R; ++r) {
+    const float *g = G + (size_t)r * ldg + m0;
+    float gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gv[i] = m0 + i < M ? g[i] : 0.f;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (nok) {
+      const float *xp = X + row_off(r, x_grp, x_gstride, x_skip, ldx) + n0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = n0 + u < N ? xp[u] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sb[i] += gv[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[i][u] = __builtin_fmaf(gv[i], x[u], acc[i][u]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (m0 + i < M) {
+      if (nok) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (n0 + u < N) dW[(size_t)(m0 + i) * N + n0 + u] = acc[i][u];
+      }
+      if (db && blockIdx.y == 0 && n4 == 0) db[m0 + i] = sb[i];
+    }
+  }
+}
+}  // namespace
+
+/* dW f32 [M,N] = G^T X, db f32 [M] (nullable) = column sums of G; G f32 rows of M floats at stride ldg, X rows of N floats at
+   stride ldx (two-level rows as in spacap_dense_rows_f32), R rows added in ascending order.  For R up to a few thousand. */
+extern "C" int spacap_dense_wgrad_small_f32(const float *G, long ldg, const float *X, long ldx, long x_grp, long x_gstride, long x_skip,
+                                            long R, int M, int N, float *dW, float *db, spacap_stream_t stream) {
+  const char *what = "spacap_dense_wgrad_small_f32";
+  SPACAP_REQUIRE(R >= 0 && M >= 1 && N >= 1 && ldg >= M && ldx >= N && x_grp >= 0 && x_skip >= 0, "%s: bad sizes", what);
+  SPACAP_REQUIRE(G && X && dW, "%s: null pointer", what);
+  hipLaunchKernelGGL(dense_wgrad_small_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 127) / 128)), dim3(256), 0,
+                     spacap::as_stream(stream), G, ldg, X, ldx, x_grp, x_gstride, x_skip, R, M, N, dW, db);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -1488,7 +1488,8 @@ extern "C" int spacap_sa_l3bwd_prep_f32(const float *coef3, const float *W3, int
                                         spacap_stream_t stream) {
   const char *what = "spacap_sa_l3bwd_prep_f32";
   SPACAP_REQUIRE(coef3 && W3 && Mneg && vrow && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
-  hipLaunchKernelGGL(sa_l3_prep_kernel, dim3(C2 + 1), dim3(256), 0, spacap::as_stream(stream), coef3, W3, C3, C2, Mneg, vrow);
+  SPACAP_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "%s: C2=%d unsupported", what, C2);
+  hipLaunchKernelGGL(sa_l3_prep_kernel, dim3(C2 + 1), dim3(1024), 0, spacap::as_stream(stream), coef3, W3, C3, C2, Mneg, vrow);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
@@ -1501,19 +1502,20 @@ extern "C" int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, 
   const char *what = "spacap_sa_l3bwd_f32";
   SPACAP_REQUIRE(dym && arg && coef3 && W3 && Mneg && vrow && z2 && st2 && dy2 && part && partW && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(l3bwd_shape(C2, C3, S) && R % S == 0, "%s: (C2=%d, C3=%d, S=%d) unsupported", what, C2, C3, S);
-  const L3Args a{dym, arg, coef3, W3, Mneg, vrow, z2, st2, R, S, dy2, part, partW};
+  const L3Args a{dym, arg, coef3, W3, Mneg, vrow, z2, st2, R, S, dy2, part, partW, getenv("SPACAP_L3_DBG") ? atoi(getenv("SPACAP_L3_DBG")) : 0};
   const int grid = l3bwd_grid(R, C2, C3);
   hipStream_t s = spacap::as_stream(stream);
-#define L3(C2V, C3V, TV)                                                                                                          \
+#define L3(C2V, C3V, TV, PV)                                                                                                      \
   {                                                                                                                               \
     static unsigned long long lds_ok = 0;                                                                                         \
-    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&sa_l3bwd_kernel<C2V, C3V, TV>),                    \
-                                               (int)l3bwd_lds_bytes(C2V, TV), lds_ok), what);                                     \
-    hipLaunchKernelGGL((sa_l3bwd_kernel<C2V, C3V, TV>), dim3(grid), dim3(C2V * 4), l3bwd_lds_bytes(C2V, TV), s, a);               \
+    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&sa_l3bwd_kernel<C2V, C3V, TV, PV>),                \
+                                               (int)l3bwd_lds_bytes(C2V, TV, PV), lds_ok), what);                                 \
+    hipLaunchKernelGGL((sa_l3bwd_kernel<C2V, C3V, TV, PV>), dim3(grid), dim3(C2V * 4), l3bwd_lds_bytes(C2V, TV, PV), s, a);       \
   }
-  if (C2 == 64) L3(64, 128, 64)
-  else if (C3 == 128) L3(128, 128, 32)
-  else L3(128, 256, 32)
+  // C2 = 64: one launch; C2 = 128: the data half, then the weight half (each streams z2; one register file holds either)
+  if (C2 == 64) L3(64, 128, 64, 0)
+  else if (C3 == 128) { L3(128, 128, 32, 1) L3(128, 128, 32, 2) }
+  else { L3(128, 256, 32, 1) L3(128, 256, 32, 2) }
 #undef L3
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -1527,8 +1529,9 @@ extern "C" int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const floa
   SPACAP_REQUIRE(partW && coef3 && W3 && sums && dW3 && nparts >= 1 && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
   const long n = spacap_sa_l3bwd_part_floats(C2, C3);
   hipStream_t s = spacap::as_stream(stream);
-  hipLaunchKernelGGL(sa_l3_sum_kernel, dim3(nblocks(n, 256)), dim3(256), 0, s, partW, nparts, n, sums);
-  hipLaunchKernelGGL(sa_l3_dw_kernel, dim3(C3), dim3(256), 0, s, sums, coef3, W3, C3, C2, dW3);
+  SPACAP_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "%s: C2=%d unsupported", what, C2);
+  hipLaunchKernelGGL(sa_l3_sum_kernel, dim3(nblocks(n, 16)), dim3(256), 0, s, partW, nparts, n, sums);
+  hipLaunchKernelGGL(sa_l3_dw_kernel, dim3(C3), dim3(1024), 0, s, sums, coef3, W3, C3, C2, dW3);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

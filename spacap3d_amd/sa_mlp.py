@@ -6,6 +6,8 @@ lib/pointnet2/pytorch_utils.py:11-36).  See ``csrc/sa_mlp.hip`` for the kernels 
 The grouping indices come from ``ball_query`` as before; eval mode and MLP shapes without kernels keep using
 the per-operator path (``QueryAndGroup`` + ``SharedMLP``), which is also HIP.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -15,9 +17,12 @@ from ._native import check, lib, sum_slabs
 
 # SA1-shaped modules (no point features, 64 -> 64 -> ...): do not store the first layer's pre-activation (see _SAMLP.forward)
 RECOMPUTE_Z1 = True
-# pooled last layer: do not store its pre-activation z3; its backward is one pass over z2 (see _SAMLP.backward).  False restores
-# the stored-z3 path (the A/B leg of tests/test_sa_mlp_gpu.py)
-Z3_FREE = True
+# pooled last layer: do not store its pre-activation z3; its backward is then one pass over z2 (see _SAMLP.backward,
+# csrc/sa_l3bwd.inc).  Correct (float64 gate, A/B leg of tests/test_sa_mlp_gpu.py) and 0.8 - 1.1 GB of HBM traffic lighter per
+# module, but SLOWER than the stored-z3 kernels as measured in round 4 (SA1: 1 010 vs 499 us, tools/lab/l3bwd_bench.py): the
+# scatter of the sparse term through LDS float atomics costs 540 us there (ds_add_f32 runs at ~1 500 cycles per wave
+# instruction on gfx950), the streaming skeleton with one tile in flight another 240.  Off until that is fixed.
+Z3_FREE = os.environ.get("SPACAP_SA_Z3_FREE", "0") not in ("", "0")
 
 
 def _ptr(t):

@@ -124,7 +124,10 @@ def _sa1_vs_float64(C, seed):
         B, P, Sn = idx.shape
         flat = idx.view(B, -1)
         # the kernels' selections: relu'(bn(z_k)) with the fp32 expression of the kernels, arg-max of the pooled layer
-        masks = [(((z - st[:, 0]) * st[:, 2] + st[:, 3]) > 0).view(B, P, Sn, -1) for z, st in zip(zs, sts)]
+        # (the pooled last layer stores no pre-activation any more, only its value at the arg-max rows, saved[9] of shape
+        # (B, P, C3): the frozen restatement gathers the arg-max rows, so that mask is all it needs of the last layer)
+        masks = [(((z - st[:, 0]) * st[:, 2] + st[:, 3]) > 0).view(B, P, -1, z.shape[-1]).expand(B, P, Sn, -1)
+                 for z, st in zip(zs, sts)]
         argl = arg.view(B, P, 1, -1).long()
     x64, f64 = xyz.double(), feats.double()
     g_xyz = torch.gather(x64, 1, flat.unsqueeze(-1).expand(-1, -1, 3)).view(B, P, Sn, 3)
