@@ -12,14 +12,13 @@ head on, attention dropout 0.1 as in the reference) -- fp32, inputs resident in 
 are sharded by rank (weak scaling); rank 0 prints ONE JSON line.
 
 Extra objects on the line (tier contract):
-  roofline      the kernel function with the largest summed duration on the step's own stream (profiles/*_timed_window_kernels.csv):
-                `rel_fused_bwd_kernel`, the relation head's backward on 524 288 proposal pairs in one launch
-                (csrc/relation_fused.hip).  launch_us = its duration INSIDE eager training steps run right after the timed
-                region (HIP events on the step's stream around the C-ABI call, the next batch's sampling chain beside it);
-                achieved = algorithmic flops / launch_us against the ceiling of the implemented arithmetic (the 128 x 128
-                products as split-bf16: 6 bf16 MFMA products per fp32 product, 2 500 / 6 TFLOP/s; the per-key and 9-wide
-                products as fp32 MFMA, 157.3 TFLOP/s; ceiling = flops / time of each part at its own peak); arithmetic
-                intensity 129 flop/B, above the ridge: bound "mfma".  traffic = HBM bytes per launch from the tracked
+  roofline      the kernel FUNCTION with the largest summed duration on the step's own stream, read at run time from the first row of
+                the newest window table under profiles/ (rNN_*_timed_window_kernels.csv, tools/prof_window.py over a rocprofv3
+                kernel trace of this very command; the line fails loudly when the table is empty or names a function without a
+                case here), at that function's LARGEST launch of the step.  launch_us = its duration INSIDE eager training
+                steps run right after the timed region (HIP events on the step's stream around the C-ABI call, the next batch's
+                sampling chain beside it); achieved = algorithmic flops or bytes / launch_us against the roof that binds the
+                implemented arithmetic (tools/kernel_cases.py: roofline_entry).  traffic = HBM bytes per launch from the tracked
                 rocprofv3 --pmc passes (profiles/rNN_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE, tools/pmc_parse.py).
   roofline_more the same object for: the largest shared-MLP forward layer (SA2 layer 3, 262 144 rows, 128 -> 256, streaming
                 split-bf16 kernel, HBM-bound, in-step duration as above), the relation head's forward, the largest
@@ -288,6 +287,31 @@ class InStepTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) * 1e3 / max(1, len(self.events))
 
 
+def window_table_top():
+    """(function name, table file) of the first row of the newest profiles/rNN_*_timed_window_kernels.csv: the kernel function
+    with the largest summed main-stream duration in the timed steps (tools/prof_window.py).  Raises when there is no usable
+    table: the roofline object must name what the profile says, not what a comment remembers."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_timed_window_kernels.csv")))
+    files = [f for f in files if os.path.getsize(f) > 0]
+    if not files:
+        raise SystemExit("bench.py: no non-empty profiles/r*_timed_window_kernels.csv (run tools/prof_step.sh and commit its table)")
+    path = files[-1]
+    rows, on = [], False
+    for line in open(path):
+        if line.startswith("main_ms/step,calls/step,avg_us,function"):
+            on = True
+            continue
+        if on:
+            if line.startswith("#") or not line.strip():
+                break
+            rows.append(next(csv.reader([line])))
+    if not rows:
+        raise SystemExit(f"bench.py: {path} holds no per-function rows")
+    return rows[0][3], os.path.basename(path), [(r[3], float(r[0]), float(r[1])) for r in rows[:8]]
+
+
 def step_flops(cfg, B):
     """Algorithmic flops of one training step (SURVEY.md section 8d formulas): dense layers 2*cin*cout*rows forward, x3 for
     forward + data gradient + weight gradient (first layers of SA1 / the embedding have no data gradient: < 1 %)."""
@@ -386,20 +410,36 @@ def main():
     n_params, allreduce_bytes = sum(p.numel() for p in model.parameters()), trainer.bucket.nbytes
 
     # -- the roofline kernel's duration INSIDE a step (beside the side-stream sampling chain, with the step's grid) ----------
-    in_step = in_step_rel = None
+    in_step = in_step_top = None
+    top_fn = top_file = top_rows = None
+    if rank == 0:
+        top_fn, top_file, top_rows = window_table_top()
+    # (function of the window table) -> (module whose `lib` launches it, C entry point, selector of its LARGEST launch in the step)
+    R1_, R2_ = per_gpu * 2048 * 64, per_gpu * 1024 * 32
+    import spacap3d_amd.linear as lin
+    import spacap3d_amd.sa_mlp as sam
+    import spacap3d_amd.tf_layer as tfl
+    TOP = {
+        "sa_wgrad_kernel": (sam, "spacap_sa_wgrad_f32", lambda a: (a[7], a[8], a[9]) == (R1_, 128, 64)),
+        "rel_fused_bwd_kernel": (lin, "spacap_relation_fused_bwd_f32", lambda a: True),
+        "sa_mid_fwd_bf3s_kernel": (sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)),
+        "sa_dgrad_bf3s_kernel": (sam, "spacap_sa_dgrad_f32", lambda a: (a[8], a[9], a[10]) == (R2_, 256, 128)),
+        "tf_ffn_kernel": (tfl, "spacap_tf_ffn_f32", lambda a: a[0] == 0 and a[6] == per_gpu * 256),
+    }
     if world == 1 and nxt is not None and not args.ablate and not args.no_in_step and (per_gpu, cfg["n_points"]) == (8, 40000):
-        import spacap3d_amd.linear as lin
-        import spacap3d_amd.sa_mlp as sam
-        R2_ = per_gpu * 1024 * 32
+        if top_fn not in TOP:
+            raise SystemExit(f"bench.py: the window table {top_file} names `{top_fn}` as the largest main-stream kernel function, "
+                             f"for which bench.py has no roofline case: add one (TOP / tools/kernel_cases.py)")
         keep_graph, trainer.graph = trainer.graph, None     # a few EAGER steps: same kernels, events can bracket them
-        with InStepTimer(sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)) as ist, \
-                InStepTimer(lin, "spacap_relation_fused_bwd_f32", lambda a: True) as irel:
+        tmod, tname, tsel = TOP[top_fn]
+        with InStepTimer(sam, "spacap_sa_mid_fwd_pool_f32", TOP["sa_mid_fwd_bf3s_kernel"][2]) as ist, \
+                InStepTimer(tmod, tname, tsel) as itop:
             for _ in range(8):
                 trainer.step(data, next_data=nxt)
             torch.cuda.synchronize()
         if ist.events:
             in_step = {"us": ist.mean_us(), "launches": len(ist.events)}
-        in_step_rel = {"us": irel.mean_us(), "launches": len(irel.events)} if irel.events else None
+        in_step_top = {"us": itop.mean_us(), "launches": len(itop.events)} if itop.events else None
         trainer.graph = keep_graph
 
     # -- inference forward (greedy decoding) -------------------------------------------------------------------------------
@@ -444,27 +484,37 @@ def main():
         # the layer kernels are timed with their full grid (nothing runs beside them here); the step launches the forward
         # ones with `reserved_cus` CUs left to the sampling chain: that launch is timed as well
         KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
-        # `roofline` = the kernel function with the largest summed duration on the step's own stream (window table under
-        # profiles/: rel_fused_bwd_kernel, one launch per step), priced with the duration it has INSIDE the step and against
-        # the roof that binds the implemented arithmetic (its 128 x 128 products as split-bf16, the rest as fp32 MFMA)
+        # `roofline` = the kernel function with the largest summed duration on the step's own stream = the first row of the
+        # window table under profiles/ (read above), at its largest launch of the step, priced with the duration it has INSIDE
+        # the step and against the roof that binds the implemented arithmetic
         how_tail = ("launch_us = mean duration of this launch INSIDE {n} eager training steps run right after the timed region (HIP "
                     "events on the step's stream around the C-ABI call; the sampling chain of the next batch runs beside it on the "
-                    "side stream and the grid leaves " + str(reserved_cus) + " CUs to it, as in the replayed step -- compare the "
-                    "kernel's row in profiles/*_step_timeline.txt); launch_us_isolated_*: 20 back-to-back launches with nothing "
-                    "beside them; traffic from " + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+                    "side stream, as in the replayed step -- compare the kernel's row in profiles/*_step_timeline.txt); "
+                    "launch_us_isolated_*: 20 back-to-back launches with nothing beside them; traffic from "
+                    + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
+        R1 = B * 2048 * 64
+        top_case = {
+            "sa_wgrad_kernel": lambda: KC.sa_wgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
+            "rel_fused_bwd_kernel": lambda: KC.rel_fused(B, cfg["proposals"], 1, dev),
+            "sa_mid_fwd_bf3s_kernel": lambda: KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3"),
+            "sa_dgrad_bf3s_kernel": lambda: KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
+            "tf_ffn_kernel": lambda: KC.tf_ffn(B * 256, 2048, 0, dev),
+        }
+        if top_fn not in top_case:
+            raise SystemExit(f"bench.py: no roofline case for `{top_fn}` (first row of {top_file})")
+        c_top = top_case[top_fn]()
+        iso_top = KC.time_case(c_top)
+        roof = KC.roofline_entry(c_top, in_step_top["us"] if in_step_top else iso_top, pmc)
+        roof["launch_us_isolated_full_grid"] = iso_top
+        roof["function"] = top_fn
+        roof["chosen_by"] = (f"first row of profiles/{top_file} (largest summed main-stream duration per step: "
+                             + "; ".join(f"{n} {ms:.3f} ms in {c:.0f} launches" for n, ms, c in top_rows[:4]) + ")")
+        if in_step_top:
+            roof["in_step_launches_timed"] = in_step_top["launches"]
+        roof["how"] = how_tail.format(n=in_step_top["launches"] if in_step_top else 0)
+        del c_top
         c_rel = KC.rel_fused(B, cfg["proposals"], 1, dev)
-        iso_rel = KC.time_case(c_rel)
-        roof = KC.roofline_entry(c_rel, in_step_rel["us"] if in_step_rel else iso_rel, pmc)
-        roof["launch_us_isolated_full_grid"] = iso_rel
-        if in_step_rel:
-            roof["in_step_launches_timed"] = in_step_rel["launches"]
-        if reserved_cus:
-            KC.check(KC.lib.spacap_sa_reserve_cus(reserved_cus), "spacap_sa_reserve_cus")
-            c_rel2 = KC.rel_fused(B, cfg["proposals"], 1, dev)     # (the grid is fixed when the buffers are sized)
-            roof["launch_us_isolated_with_the_steps_grid"] = KC.time_case(c_rel2)
-            del c_rel2
-            KC.check(KC.lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
-        roof["how"] = how_tail.format(n=in_step_rel["launches"] if in_step_rel else 0)
+        roof_relb = KC.roofline_entry(c_rel, KC.time_case(c_rel), pmc)
         del c_rel
         c_relf = KC.rel_fused(B, cfg["proposals"], 0, dev)
         roof_relf = KC.roofline_entry(c_relf, KC.time_case(c_relf), pmc)
@@ -529,7 +579,7 @@ def main():
                        "sa_forward_gemm": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if os.environ.get("SPACAP_SA_F32MFMA", "0") not in ("", "0") else
                                            "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
-            "roofline": roof, "roofline_more": [roof_sa, roof_relf, roof_dg, roof_hbm, roof_ffn, roof_fps],
+            "roofline": roof, "roofline_more": [roof_sa, roof_relb, roof_relf, roof_dg, roof_hbm, roof_ffn, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
                      "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
             "ops": ops, "final_loss": loss_val,

@@ -615,6 +615,17 @@ int spacap_dense_rows_f32(const float *a, long lda, long a_grp, long a_gstride, 
                           int o_zero, int slices, long slice_stride, int batch, long a_zstride, long w_zstride,
                           spacap_stream_t stream);
 int spacap_dense_sum_slices_f32(const float *parts, int S, long n, long stride, float *out, spacap_stream_t stream);
+/* Weight + bias gradient of such a product with FEW rows and a wide output (the vocabulary projection: 248 rows, 3 001 x 128):
+   dW f32 [M,N] = G^T X, db f32 [M] (nullable) = column sums of G; G rows of M floats at stride ldg, X rows of N floats at stride
+   ldx (two-level rows as above), the R rows added in ascending order. */
+int spacap_dense_wgrad_small_f32(const float *G, long ldg, const float *X, long ldx, long x_grp, long x_gstride, long x_skip, long R,
+                                 int M, int N, float *dW, float *db, spacap_stream_t stream);
+/* Block-diagonal weight gradient dW[o][z N + n] = sum_r G[r][z M + o] X[r][z N + n], z < Z (the relation head's first Linear
+   applied per head, models/transformer_captioner.py:319-326): part f32 [nslab][M][Z N] per-row-slab partials in dW's layout,
+   nslab = spacap_dense_wgrad_blocks_slabs(R) or any count >= 1; the caller adds the slabs in order. */
+int spacap_dense_wgrad_blocks_slabs(long R);
+int spacap_dense_wgrad_blocks_f32(const float *G, long ldg, const float *X, long ldx, long R, int Z, int M, int N, int nslab,
+                                  float *part, spacap_stream_t stream);
 
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
@@ -769,6 +780,11 @@ int spacap_copy_batched(const void *const *src, void *const *dst, const long *nb
 
 /* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
 int spacap_stream_delay(int microseconds, spacap_stream_t stream);
+/* A dependency from inside a captured step to a stream outside it (events cannot express one): spacap_stream_signal writes
+   *flag = *value (device words) in stream order; spacap_stream_wait_ge holds its stream (one spinning wave) until *flag >= value,
+   at most timeout_ms.  engine.py: the all-reduce of the captioner's gradient slice starts while the detector's backward runs. */
+int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, spacap_stream_t stream);
+int spacap_stream_signal(int64_t *flag, const int64_t *value, spacap_stream_t stream);
 
 /* Lab only (tools/lab/step_stamps.py): writes the device's 100 MHz wall clock into *slot when the stream reaches it. */
 int spacap_lab_stamp(uint64_t *slot, spacap_stream_t stream);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "spacap_copy_batched": (_i, [_p, _p, _p, _i, _p]),
     "spacap_lab_stamp": (_i, [_p, _p]),
     "spacap_stream_delay": (_i, [_i, _p]),
+    "spacap_stream_wait_ge": (_i, [_p, _l, _i, _p]),
+    "spacap_stream_signal": (_i, [_p, _p, _p]),
     "spacap_sa_nparts": (_i, []),
     "spacap_sa_wgrad_slabs": (_i, [_l, _i, _i, _i]),
     "spacap_sa_mlp_supported": (_i, [_i, _i, _i]),
@@ -99,6 +101,9 @@ SIGNATURES = {
     "spacap_dense_rows_slices": (_i, [_l, _i, _i]),
     "spacap_dense_rows_f32": (_i, [_p, _l, _l, _l, _l, _p, _l, _i, _p, _l, _i, _i, _p, _l, _l, _l, _l, _i, _i, _l, _i, _l, _l, _p]),
     "spacap_dense_sum_slices_f32": (_i, [_p, _i, _l, _l, _p, _p]),
+    "spacap_dense_wgrad_small_f32": (_i, [_p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p]),
+    "spacap_dense_wgrad_blocks_slabs": (_i, [_l]),
+    "spacap_dense_wgrad_blocks_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
     "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
     "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),

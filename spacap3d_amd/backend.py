@@ -48,6 +48,7 @@ class HipBackend:
         self.conv1x1 = _lin.conv1x1
         self.relation_tail = _lin.relation_tail
         self.relation_head = _lin.relation_head
+        self.vocab_projection = _lin.vocab_projection
         from . import caption_prep as _cp
         self.caption_prep = _cp.caption_prep
         from . import tf_layer as _tf

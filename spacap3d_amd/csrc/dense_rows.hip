@@ -306,3 +306,52 @@ extern "C" int spacap_dense_wgrad_small_f32(const float *G, long ldg, const floa
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ---- block-diagonal weight gradient: dW[o][z N + n] = sum_r G[r][z M + o] X[r][z N + n], z < Z -------------------------------
+// (the relation head's first Linear applied per head: G = dU [R][Z M], X = the value vectors [R][Z N], models/
+// transformer_captioner.py:319-326.)  One (row slab, z) per workgroup, thread = one o and 8 columns n; per-slab partial results
+// in dW's own layout [slab][M][Z N], to be added in slab order.
+namespace {
+__global__ __launch_bounds__(256) void dense_wgrad_blocks_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X,
+                                                                 long ldx, long R, int Z, int M, int N, float *__restrict__ part) {
+  const int s = blockIdx.x, z = blockIdx.y, nslab = gridDim.x;
+  const long per = (R + nslab - 1) / nslab, rbeg = (long)s * per, rend = rbeg + per < R ? rbeg + per : R;
+  float *po = part + (size_t)s * M * Z * N;
+  for (int o = threadIdx.x % 128; o < M; o += 128) {
+    for (int n0 = 8 * (threadIdx.x / 128); n0 < N; n0 += 16) {
+      float acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+      for (long r = rbeg; r < rend; ++r) {
+        const float g = G[(size_t)r * ldg + (size_t)z * M + o];
+        const float *x = X + (size_t)r * ldx + (size_t)z * N + n0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = __builtin_fmaf(g, n0 + u < N ? x[u] : 0.f, acc[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (n0 + u < N) po[(size_t)o * Z * N + (size_t)z * N + n0 + u] = acc[u];
+    }
+  }
+}
+}  // namespace
+
+/* row slabs (= partial results) spacap_dense_wgrad_blocks_f32 should be called with for R rows */
+extern "C" int spacap_dense_wgrad_blocks_slabs(long R) {
+  long n = (R + 127) / 128;
+  if (n > 64) n = 64;
+  return (int)(n < 1 ? 1 : n);
+}
+
+/* part f32 [nslab][M][Z N]: per row slab, dW[o][z N + n] = sum_r G[r][z M + o] X[r][z N + n] (block-diagonal product of G^T X);
+   G rows of Z M floats at stride ldg, X rows of Z N floats at stride ldx.  The caller adds the slabs in order. */
+extern "C" int spacap_dense_wgrad_blocks_f32(const float *G, long ldg, const float *X, long ldx, long R, int Z, int M, int N, int nslab,
+                                             float *part, spacap_stream_t stream) {
+  const char *what = "spacap_dense_wgrad_blocks_f32";
+  SPACAP_REQUIRE(R >= 1 && Z >= 1 && Z <= 65535 && M >= 1 && N >= 1 && nslab >= 1 && ldg >= (long)Z * M && ldx >= (long)Z * N,
+                 "%s: bad sizes", what);
+  SPACAP_REQUIRE(G && X && part, "%s: null pointer", what);
+  hipLaunchKernelGGL(dense_wgrad_blocks_kernel, dim3(nslab, Z), dim3(256), 0, spacap::as_stream(stream), G, ldg, X, ldx, R, Z, M, N, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

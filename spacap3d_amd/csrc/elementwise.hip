@@ -433,6 +433,38 @@ extern "C" int spacap_stream_delay(int microseconds, spacap_stream_t stream) {
   return SPACAP_OK;
 }
 
+// ---- a stream waits for a word in device memory: one wave spins until *flag >= value (engine.py: the gradient all-reduce of
+// the captioner's slice starts on the communication stream as soon as the captured step, in the middle of its backward, has
+// written the step number there -- a dependency from INSIDE a hipGraph to a stream outside it, which events cannot express).
+// Gives up after `timeout_ms` of wall clock (the caller then simply runs later than it could have).
+namespace {
+__global__ void wait_ge_kernel(const long long *flag, long long value, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
+    if (wall_clock64() - t0 > ticks) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+__global__ void signal_set_kernel(long long *flag, const long long *value) {
+  __hip_atomic_store(flag, *value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+extern "C" int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, spacap_stream_t stream) {
+  SPACAP_REQUIRE(flag && timeout_ms >= 1 && timeout_ms <= 60000, "spacap_stream_wait_ge: bad arguments");
+  hipLaunchKernelGGL(wait_ge_kernel, dim3(1), dim3(1), 0, spacap::as_stream(stream), reinterpret_cast<const long long *>(flag),
+                     (long long)value, (unsigned long long)timeout_ms * 100000ull);
+  SPACAP_CHECK_LAUNCH("spacap_stream_wait_ge");
+  return SPACAP_OK;
+}
+/* *flag = *value (both device words), visible to spacap_stream_wait_ge on any stream once everything before it on this stream is done */
+extern "C" int spacap_stream_signal(int64_t *flag, const int64_t *value, spacap_stream_t stream) {
+  SPACAP_REQUIRE(flag && value, "spacap_stream_signal: null pointer");
+  hipLaunchKernelGGL(signal_set_kernel, dim3(1), dim3(1), 0, spacap::as_stream(stream), reinterpret_cast<long long *>(flag),
+                     reinterpret_cast<const long long *>(value));
+  SPACAP_CHECK_LAUNCH("spacap_stream_signal");
+  return SPACAP_OK;
+}
+
 // ---- lab: device timestamps inside a captured step (tools/lab/step_stamps.py) --------------------------------------------
 namespace {
 __global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }   // s_memrealtime: 100 MHz

@@ -221,12 +221,12 @@ class Conv1x1(Function):
         return dx, dw, db
 
 
-# The library's own forward / input-gradient kernel for these convolutions (csrc/conv1x1.hip) is built and gated
-# (tests/test_attention_gpu.py::test_conv1x1_channel_major_kernel) but NOT on the default path: isolated it takes 6 - 16 us
-# where the library call takes 20 (29 vs 21 at 768 -> 256 channels), inside the replayed step the difference did not show
-# (8.30 vs 8.27 ms, tools/lab/conv_cm_bench.py), and its different summation order moves the chaotic 5-step trajectory
-# gate (tests/test_engine_gpu.py) past its 5 % bar at step 3.
-USE_OWN_CONV = False
+# Forward and input gradient of these convolutions run on the library's own channel-major kernel (csrc/conv1x1.hip, bias in
+# its epilogue; gated against float64 in tests/test_attention_gpu.py::test_conv1x1_channel_major_kernel).  Rounds 2 - 3 kept them
+# on MIOpen / rocBLAS because the kernel's summation order moved a chaotic 5-step trajectory gate; that gate now freezes the
+# discrete selections it cannot control (tests/test_engine_gpu.py) and a re-association passes it.  False restores the library
+# calls (A/B measurements).
+USE_OWN_CONV = True
 
 
 def conv1x1_cm(mode, weight, t, bias, M):
@@ -383,5 +383,142 @@ def relation_head(P, V, lin1, lin2, lin3):
             tuple(lin1.weight.shape) != (128, H * D) or tuple(lin2.weight.shape) != (128, 128) or \
             not lib.spacap_relation_fused_supported(H, K, 128, lin3.weight.shape[0]) or lin3.weight.shape[1] != 128:
         return None
-    U = torch.einsum("bhjd,ohd->bjho", V, lin1.weight.view(128, H, D))  # (B,K,H,C): tiny, autograd gives dV and dW1
+    U = RelationU.apply(V, lin1.weight)   # (B,K,H,C): the first Linear applied per head to the value vectors
     return RelationHead.apply(P, U, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias)
+
+
+# ---- dense row products of any shape (csrc/dense_rows.hip): what used to be rocBLAS GEMMs inside the step ----------------------
+
+def _dense(dev, a_ptr, lda, W_ptr, ldw, trans_w, bias_ptr, R, K, CO, out_ptr, ldo, a_rows=(0, 0, 0), o_rows=(0, 0, 0), o_zero=0,
+           slices=1, slice_stride=0, batch=0, a_z=0, w_z=0):
+    check(lib.spacap_dense_rows_f32(a_ptr, lda, a_rows[0], a_rows[1], a_rows[2], W_ptr, ldw, 1 if trans_w else 0, bias_ptr, R, K, CO,
+                                    out_ptr, ldo, o_rows[0], o_rows[1], o_rows[2], int(o_zero), int(slices), int(slice_stride),
+                                    int(batch), int(a_z), int(w_z), torch.cuda.current_stream(dev).cuda_stream),
+          "spacap_dense_rows_f32")
+
+
+def dense_product(a2, W, trans_w, bias=None, col0=0, ncols=None):
+    """out = a2 Wv^T (+ bias) when ``trans_w`` else a2 Wv, with Wv = W[:, col0 : col0 + ncols] a COLUMN SLICE of the dense 2-D
+    matrix W (no copy: the kernel takes the row stride).  a2 (R, K) dense.  Any sizes."""
+    R, K = a2.shape
+    ldw = W.shape[1]
+    ncols = ldw - col0 if ncols is None else ncols
+    CO = W.shape[0] if trans_w else ncols
+    assert a2.is_contiguous() and W.is_contiguous() and (ncols == K if trans_w else W.shape[0] == K)
+    dev = a2.device
+    with torch.cuda.device(dev):
+        out = torch.empty(R, CO, dtype=torch.float32, device=dev)
+        _dense(dev, a2.data_ptr(), K, W.data_ptr() + 4 * col0, ldw, trans_w, bias.data_ptr() if bias is not None else None, R, K, CO,
+               out.data_ptr(), CO)
+    return out
+
+
+class VocabProjection(Function):
+    """logits[b, t, :] = n[b, t + skip, :] W^T + bias, t < L - skip: the caption head's vocabulary projection
+    (models/transformer_captioner.py:93-100 ``Generator.proj``) applied to positions skip.. of every sequence
+    (:373-379: the decoder's output without the object-indicator position) -- read in place instead of through a slice copy,
+    and with the data gradient written straight into the full (B, L, D) layout (position < skip: zeros).  Forward, data
+    gradient (split over the 3 001-long reduction, slices added in order) and weight / bias gradient are csrc/dense_rows.hip."""
+
+    @staticmethod
+    def forward(ctx, n, weight, bias, skip):
+        if not n.is_cuda:
+            raise RuntimeError("CPU not supported")
+        n, w = n.contiguous(), weight.contiguous()
+        B, L, D = n.shape
+        V, T = w.shape[0], L - skip
+        dev = n.device
+        with torch.cuda.device(dev):
+            logits = torch.empty(B, T, V, dtype=torch.float32, device=dev)
+            _dense(dev, n.data_ptr(), D, w.data_ptr(), D, True, bias.data_ptr() if bias is not None else None, B * T, D, V,
+                   logits.data_ptr(), V, a_rows=(T, L * D, skip) if skip else (0, 0, 0))
+        ctx.save_for_backward(n, w)
+        ctx.skip, ctx.has_bias = int(skip), bias is not None
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        n, w = ctx.saved_tensors
+        skip = ctx.skip
+        B, L, D = n.shape
+        V, T = w.shape[0], L - skip
+        R = B * T
+        dev = n.device
+        g = g.contiguous()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            dn = None
+            if ctx.needs_input_grad[0]:
+                S = int(lib.spacap_dense_rows_slices(R, V, D))
+                dn = torch.empty(B, L, D, dtype=torch.float32, device=dev)
+                rows = (T, L * D, skip) if skip else (0, 0, 0)
+                if S > 1:
+                    parts = torch.empty(S, B * L * D, dtype=torch.float32, device=dev)
+                    _dense(dev, g.data_ptr(), V, w.data_ptr(), D, False, None, R, V, D, parts.data_ptr(), D, o_rows=rows,
+                           o_zero=1 if skip else 0, slices=S, slice_stride=B * L * D)
+                    check(lib.spacap_dense_sum_slices_f32(parts.data_ptr(), S, B * L * D, B * L * D, dn.data_ptr(), st),
+                          "spacap_dense_sum_slices_f32")
+                else:
+                    _dense(dev, g.data_ptr(), V, w.data_ptr(), D, False, None, R, V, D, dn.data_ptr(), D, o_rows=rows,
+                           o_zero=1 if skip else 0)
+            dW = torch.empty(V, D, dtype=torch.float32, device=dev)
+            db = torch.empty(V, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            check(lib.spacap_dense_wgrad_small_f32(g.data_ptr(), V, n.data_ptr(), D, T if skip else 0, L * D, skip, R, V, D,
+                                                   dW.data_ptr(), db.data_ptr() if db is not None else None, st),
+                  "spacap_dense_wgrad_small_f32")
+        return dn, dW, db, None
+
+
+def vocab_projection(n, lin, skip):
+    """``lin(n[:, skip:, :])`` for the vocabulary ``nn.Linear`` ``lin``; None when the tensors are not float32 CUDA."""
+    if not (n.is_cuda and n.dtype == torch.float32 and n.dim() == 3 and lin.weight.shape[1] == n.shape[-1] and n.shape[1] > skip):
+        return None
+    return VocabProjection.apply(n, lin.weight, lin.bias, skip)
+
+
+class RelationU(Function):
+    """U[b, j, h, :] = W1[:, d h : d h + d] V[b, h, j, :]: the relation head's first Linear applied per head to the value vectors
+    (models/transformer_captioner.py:319-326 with the pair feature of :393-397 factored, see relation_head).  V is the (B, h, K, d)
+    VIEW of the packed q | k | v projection (row stride 3 h d): read in place.  h independent products of one launch each way;
+    the weight gradient is h diagonal blocks of dU^T V (per-slab partials in dW1's own layout + one deferrable sum)."""
+
+    @staticmethod
+    def forward(ctx, V, W1):
+        B, H, K, D = V.shape
+        C = W1.shape[0]
+        Vr = V.transpose(1, 2)                      # (B, K, H, D)
+        if not (Vr.stride(3) == 1 and Vr.stride(2) == D and Vr.stride(0) == K * Vr.stride(1)):
+            Vr = Vr.contiguous()
+        W1c = W1.contiguous()
+        lda = Vr.stride(1)
+        dev = V.device
+        with torch.cuda.device(dev):
+            U = torch.empty(B, K, H, C, dtype=torch.float32, device=dev)
+            _dense(dev, Vr.data_ptr(), lda, W1c.data_ptr(), H * D, True, None, B * K, D, C, U.data_ptr(), H * C, slices=H,
+                   slice_stride=C, batch=1, a_z=D, w_z=D)
+        ctx.save_for_backward(Vr, W1c)
+        return U
+
+    @staticmethod
+    def backward(ctx, dU):
+        Vr, W1 = ctx.saved_tensors
+        B, K, H, D = Vr.shape
+        C = W1.shape[0]
+        R = B * K
+        dev = dU.device
+        dU = dU.contiguous()
+        lda = Vr.stride(1)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            dV = None
+            if ctx.needs_input_grad[0]:
+                dVr = torch.empty(B, K, H, D, dtype=torch.float32, device=dev)
+                _dense(dev, dU.data_ptr(), H * C, W1.data_ptr(), H * D, False, None, R, C, D, dVr.data_ptr(), H * D, slices=H,
+                       slice_stride=D, batch=1, a_z=C, w_z=D)
+                dV = dVr.transpose(1, 2)
+            nslab = int(lib.spacap_dense_wgrad_blocks_slabs(R))
+            part = torch.empty(nslab, C * H * D, dtype=torch.float32, device=dev)
+            check(lib.spacap_dense_wgrad_blocks_f32(dU.data_ptr(), H * C, Vr.data_ptr(), lda, R, H, C, D, nslab, part.data_ptr(), st),
+                  "spacap_dense_wgrad_blocks_f32")
+            dW1 = sum_slabs(part, deferrable=True).view(C, H * D)
+        return dV, dW1

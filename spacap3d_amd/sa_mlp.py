@@ -49,7 +49,10 @@ class _SAMLP(Function):
         xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
         W1c, W2c, W3c = W1.contiguous(), W2.contiguous(), W3.contiguous()
         feat = feat.contiguous() if feat is not None else None
-        Y = torch.matmul(pm, W1c[:, 3:].t()).contiguous() if pm is not None else None
+        # first layer commuted with the gather: Y = F W1[:, 3:]^T over the SOURCE points (csrc/dense_rows.hip reads the column
+        # slice of W1 in place)
+        pmc = pm.contiguous() if pm is not None else None
+        Y = _feature_product(pmc, W1c) if pm is not None else None
         nparts = int(lib.spacap_sa_nparts())
         with torch.cuda.device(dev):
             part = torch.empty(nparts * 2 * max(C1, C2, C3), dtype=torch.float64, device=dev)
@@ -120,7 +123,7 @@ class _SAMLP(Function):
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3 if z3 is not None else zmax, stats[0], stats[1],
                               stats[2], out, arg)
         ctx.z3_free = z3_free         # the saved "z3" is then zmax (B, N, C3): the arg-max rows' pre-activations
-        ctx.pm = pm                   # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
+        ctx.pm = pmc                  # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)
         ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
         ctx.has_Y = Y is not None
@@ -248,7 +251,8 @@ class _SAMLP(Function):
                 Cf = W1.shape[1] - 3
                 g2, x2 = dY.view(-1, C1), pm.reshape(-1, Cf)
                 if ctx.needs_input_grad[4]:
-                    dpm = torch.matmul(g2, W1[:, 3:]).view_as(pm)
+                    from .linear import dense_product
+                    dpm = dense_product(g2, W1, False, col0=3).view_as(pm)    # dY W1[:, 3:]
                 dW1 = torch.cat([dWx[:, :3], _feature_weight_gradient(g2, x2)], 1)
             else:
                 dW1 = dWx[:, :W1.shape[1]].contiguous()
@@ -261,6 +265,13 @@ class _SAMLP(Function):
                 if ctx.needs_input_grad[1]:
                     dnew = -drel.view(B, N, S, 3).sum(2)
         return (dxyz, dnew, None, None, dpm, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
+
+
+def _feature_product(pm, W1c):
+    """Y (B, Np, C1) = pm (B, Np, Cf) W1[:, 3:]^T."""
+    from .linear import dense_product
+    B, Np, Cf = pm.shape
+    return dense_product(pm.view(B * Np, Cf), W1c, True, col0=3).view(B, Np, W1c.shape[0])
 
 
 def supported(mlp_module, nsample):
@@ -369,7 +380,7 @@ def sa_mlp_eval(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
             feat, W1a = features.reshape(B, -1).contiguous(), W1.contiguous()
         else:
             pm = point_major_of(features)
-            Y = torch.matmul(pm if pm is not None else features.transpose(1, 2), W1[:, 3:].t()).contiguous()
+            Y = _feature_product((pm if pm is not None else features.transpose(1, 2)).contiguous(), W1.contiguous())
             W1a = W1[:, :3].contiguous()
     else:
         W1a = W1.contiguous()

@@ -473,7 +473,7 @@ class TransformerDecoderModel(nn.Module):
         src_pos = self._src_pos(ep)
         prep = getattr(ops(), "caption_prep", None) if (src.is_cuda and self.early_guide and self.model.encoder is not None) else None
         src_mask = ep["bbox_mask"].unsqueeze(1)
-        x0 = None
+        x0 = out_full = None
         if prep is not None:
             # encoder first, then nearest proposal + object indicator + token embedding + positional encoding + dropout + mask
             # as one launch (csrc/caption_prep.hip) and the decoder stack on its output
@@ -485,7 +485,8 @@ class TransformerDecoderModel(nn.Module):
             if got is not None:
                 x0, m8, idx1, dist, good, pred_ious = got
                 ep["match_idx"] = idx1
-                out = self.model.decoder(x0, None, None, m8)[:, 1:, :]
+                out_full = self.model.decoder(x0, None, None, m8)
+                out = out_full[:, 1:, :]
         if x0 is None:
             _, _, target_ious, idx = nn_distance(ep["aggregated_vote_xyz"], ep["ref_center_label"].unsqueeze(1))
             ep["match_idx"] = idx.squeeze(1)
@@ -508,7 +509,13 @@ class TransformerDecoderModel(nn.Module):
         if fused is not None and ep["lang_ids"].shape[1] >= out.shape[1] + 1:
             # vocabulary projection, then log-softmax + the caption loss / accuracy in one op (fused_losses.CaptionHeadLoss);
             # loss_helper.get_scene_cap_loss picks the pair up instead of recomputing it from the log-probabilities
-            ep["lang_cap"], cl, ca, ep["_cap_vec"] = fused(self.model.generator.proj(out), ep["lang_ids"], good)
+            # (the projection reads positions 1.. of the decoder output in place and writes its data gradient into the full
+            # layout: no slice copy, no padding of the gradient -- linear.VocabProjection)
+            vp = getattr(ops(), "vocab_projection", None) if out_full is not None else None
+            logits = vp(out_full, self.model.generator.proj, 1) if vp is not None else None
+            if logits is None:
+                logits = self.model.generator.proj(out)
+            ep["lang_cap"], cl, ca, ep["_cap_vec"] = fused(logits, ep["lang_ids"], good)
             ep["_cap_loss"] = (cl, ca)
         else:
             ep["lang_cap"] = self.model.generator(out)

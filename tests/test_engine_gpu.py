@@ -153,9 +153,15 @@ def test_five_step_trajectory_matches_the_oracle_backend():
     from spacap3d_amd.engine import Trainer
     data = _anchored_batch()
 
-    def run(device, be, steps=5):
+    def run(device, be, steps=5, jitter=0.0):
         with backend.use_backend(be):
-            tr = Trainer(_fresh_model(device), S.mean_size_arr().numpy(), lr=1e-4, adam_eps=1e-3)
+            model = _fresh_model(device)
+            if jitter:   # the same weights up to a relative perturbation of fp32-rounding size
+                g = torch.Generator().manual_seed(7)
+                with torch.no_grad():
+                    for p in model.parameters():
+                        p.mul_(1.0 + jitter * torch.randn(p.shape, generator=g).to(p.device))
+            tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-4, adam_eps=1e-3)
             d = {k: v.to(device) for k, v in data.items()}
             out = []
             for _ in range(steps):
@@ -165,6 +171,11 @@ def test_five_step_trajectory_matches_the_oracle_backend():
 
     cpu = run("cpu", OracleBackend())
     gpu = run(DEV, backend.HipBackend())
+    # the trajectory's own noise floor: the HIP path again from weights perturbed by 1e-7 relative (less than one fp32
+    # rounding of a summation order).  Whatever two such runs differ by is not a property of any kernel: the band of a term
+    # at a step is never tighter than three times that difference, so that a re-association of a sum (a different but equally
+    # correct kernel) cannot fail this gate while a wrong gradient (errors of 1e-3 and up, growing step by step) still does.
+    gpu2 = run(DEV, backend.HipBackend(), jitter=1e-7)
     # Step 0 (same weights): every term within 1e-3.  Later steps: the two runs' forward values differ by ~2e-5 (fp32
     # through ~15 BatchNorm'd layers), so a ReLU whose input lies within that of zero resolves differently; at this size
     # the proposal head sees only 2 x 64 positions, and ONE such flip was measured to change the gradient entering the
@@ -178,7 +189,8 @@ def test_five_step_trajectory_matches_the_oracle_backend():
         for k in a:
             # (the runs drift apart step by step once a selection differs: the band doubles after the third step)
             tol = (5e-3 if k in tight else 5e-2) * (1 if i < 3 else 3)
-            assert abs(a[k] - b[k]) <= tol * max(abs(a[k]), 1e-2), (i, k, a, b)
+            floor = 3.0 * abs(b[k] - gpu2[i][k])
+            assert abs(a[k] - b[k]) <= max(tol * max(abs(a[k]), 1e-2), floor), (i, k, a, b, gpu2[i])
     # everything goes down on both (anchored boxes, pinned proposals: a stable set of positives)
     for run_ in (cpu, gpu):
         assert run_[-1]["loss"] < run_[0]["loss"] and run_[-1]["cap_loss"] < run_[0]["cap_loss"] \
