@@ -86,20 +86,33 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(const RowsArgs a) {
     }
     float wf[KS];
     if (TRANS_W) {   // the 64 x 128 weight panel W[n][k] through LDS
+      if (a.vec_w) {
 #pragma unroll
-      for (int i = 0; i < 64 * C4 / 256; ++i) {
-        const int n = r0 + i * RSTEP;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (cbb + n < CO && k0 < K) {
-          const float *p = Wb + (size_t)(cbb + n) * a.ldw + k0;
-          if (a.vec_w && k0 + 3 < K) {
-            v = ld4(p);
-          } else {
+        for (int i = 0; i < 64 * C4 / 256; ++i) {
+          const int n = r0 + i * RSTEP;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (cbb + n < CO && k0 < K) {
+            const float *p = Wb + (size_t)(cbb + n) * a.ldw + k0;
+            if (k0 + 3 < K) {
+              v = ld4(p);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = k0 + u < K ? p[u] : 0.f;
+              for (int u = 0; u < 4; ++u) v[u] = k0 + u < K ? p[u] : 0.f;
+            }
           }
+          st4(&s_w[n * LD + c4 * 4], v);
         }
-        st4(&s_w[n * LD + c4 * 4], v);
+      } else {
+        // rows that are not 16-byte aligned (a column slice of a wider matrix): 4-byte loads with consecutive lanes on
+        // consecutive k -- two rows of 128 per wave instruction, every line fetched once
+        float t[64 * KC / 256];
+#pragma unroll
+        for (int i = 0; i < 64 * KC / 256; ++i) {
+          const int n = (tid >> 7) + 2 * i, k = kc + (tid & 127);
+          t[i] = (cbb + n < CO && k < K) ? Wb[(size_t)(cbb + n) * a.ldw + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 64 * KC / 256; ++i) s_w[((tid >> 7) + 2 * i) * LD + (tid & 127)] = t[i];
       }
     } else {         // W[k][n]: lane (l15, lg) takes column cb + l15 of the rows kc + 4 ks + lg
       const bool cok = cb + l15 < CO;
@@ -252,8 +265,14 @@ namespace {
 __global__ __launch_bounds__(256) void dense_wgrad_small_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X,
                                                                 long ldx, long x_grp, long x_gstride, long x_skip, long R, int M, int N,
                                                                 float *__restrict__ dW, float *__restrict__ db) {
+  // 16 rows of both operands at a time through LDS (coalesced 4-byte loads: the rows of G are not 16-byte aligned when M is odd),
+  // then every thread reads its 8 m and 4 n of a row as 16-byte pieces
+  constexpr int RB = 16;
+  __shared__ __attribute__((aligned(16))) float s_g[RB][64 + 4];
+  __shared__ __attribute__((aligned(16))) float s_x[RB][128 + 4];
   const int tid = threadIdx.x, n4 = tid & 31, mq = tid >> 5;
-  const int m0 = blockIdx.x * 64 + mq * 8, n0 = blockIdx.y * 128 + n4 * 4;
+  const int mb = blockIdx.x * 64, nb = blockIdx.y * 128;
+  const int m0 = mb + mq * 8, n0 = nb + n4 * 4;
   float acc[8][4], sb[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -261,25 +280,37 @@ __global__ __launch_bounds__(256) void dense_wgrad_small_kernel(const float *__r
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[i][u] = 0.f;
   }
-  const bool nok = n0 < N;
-  for (long r = 0; r < R; ++r) {
-    const float *g = G + (size_t)r * ldg + m0;
-    float gv[8];
+  for (long r0 = 0; r0 < R; r0 += RB) {
+    float tg[RB * 64 / 256], tx[RB * 128 / 256];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gv[i] = m0 + i < M ? g[i] : 0.f;
-    f32x4 x = {0.f, 0.f, 0.f, 0.f};
-    if (nok) {
-      const float *xp = X + row_off(r, x_grp, x_gstride, x_skip, ldx) + n0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = n0 + u < N ? xp[u] : 0.f;
+    for (int i = 0; i < RB * 64 / 256; ++i) {
+      const int e = tid + 256 * i, j = e >> 6, m = e & 63;
+      tg[i] = (r0 + j < R && mb + m < M) ? G[(size_t)(r0 + j) * ldg + mb + m] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sb[i] += gv[i];
+    for (int i = 0; i < RB * 128 / 256; ++i) {
+      const int e = tid + 256 * i, j = e >> 7, n = e & 127;
+      tx[i] = (r0 + j < R && nb + n < N) ? X[row_off(r0 + j, x_grp, x_gstride, x_skip, ldx) + nb + n] : 0.f;
+    }
+    __syncthreads();   // (the previous chunk's readers are done)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc[i][u] = __builtin_fmaf(gv[i], x[u], acc[i][u]);
+    for (int i = 0; i < RB * 64 / 256; ++i) s_g[(tid + 256 * i) >> 6][(tid + 256 * i) & 63] = tg[i];
+#pragma unroll
+    for (int i = 0; i < RB * 128 / 256; ++i) s_x[(tid + 256 * i) >> 7][(tid + 256 * i) & 127] = tx[i];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const f32x4 g0 = ld4(&s_g[j][mq * 8]), g1 = ld4(&s_g[j][mq * 8 + 4]), x = ld4(&s_x[j][n4 * 4]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float gv = i < 4 ? g0[i] : g1[i - 4];
+        sb[i] += gv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[i][u] = __builtin_fmaf(gv, x[u], acc[i][u]);
+      }
     }
   }
+  const bool nok = n0 < N;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (m0 + i < M) {
@@ -322,11 +353,20 @@ __global__ __launch_bounds__(256) void dense_wgrad_blocks_kernel(const float *__
       float acc[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-      for (long r = rbeg; r < rend; ++r) {
-        const float g = G[(size_t)r * ldg + (size_t)z * M + o];
-        const float *x = X + (size_t)r * ldx + (size_t)z * N + n0;
+      for (long rr = rbeg; rr < rend; rr += 8) {   // eight rows' operands in flight together
+        float g[8], xv[8][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = __builtin_fmaf(g, n0 + u < N ? x[u] : 0.f, acc[u]);
+        for (int j = 0; j < 8; ++j) {
+          const long r = rr + j < rend ? rr + j : rend - 1;
+          g[j] = rr + j < rend ? G[(size_t)r * ldg + (size_t)z * M + o] : 0.f;
+          const float *x = X + (size_t)r * ldx + (size_t)z * N + n0;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) xv[j][u] = n0 + u < N ? x[u] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[u] = __builtin_fmaf(g[j], xv[j][u], acc[u]);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)

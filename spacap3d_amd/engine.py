@@ -39,9 +39,20 @@ class Trainer:
         self._grad_slots = {}
         self.grad_scale = 1.0
         self._recapture = False
+        self._overlap_armed = False
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
+        # multi-rank tail: all-reduce the captioner's slice of the flat gradient bucket on a communication stream while the
+        # detector's backward is still running (see _boundary / _optimizer_step); SPACAP_OVERLAP_ALLREDUCE=0: one all-reduce
+        # after the whole backward
+        self.overlap_allreduce = os.environ.get("SPACAP_OVERLAP_ALLREDUCE", "1") != "0"
+        self._cap_start = None      # index into bucket.params where the captioner's parameters begin (a suffix of the bucket)
+        self._comm_stream = None
+        self._sig = None            # int64 [2] on the device: [0] = steps executed, [1] = "captioner gradients packed" flag
+        self._sig_host = 0          # host mirror of _sig[0]
+        self._boundary_done = False
+        self.boundary_launches = 0  # (tests: how many times the boundary actions ran)
         if next(model.parameters()).is_cuda:
             # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
             from ._native import check, lib
@@ -126,7 +137,15 @@ class Trainer:
         need = ("vote_label", "center_label")
         early = (lambda d: start_detection_losses(d, **kw)) if all(k in data_dict for k in need) else None
         d = self.model(dict(data_dict), after_proposal=early)
+        det_vec = d.get("_det_vec")
         d = get_scene_cap_loss(d, use_relation=self.use_relation, **kw)
+        if self._overlap_armed:
+            # The backward runs the captioner's nodes first (they were created last), then the detection losses, then the
+            # detector.  A hook on the first detector-side tensor therefore fires exactly when every captioner gradient exists.
+            marks = [t for t in (det_vec, d.get("aggregated_vote_features"), d.get("aggregated_vote_xyz"))
+                     if torch.is_tensor(t) and t.requires_grad]
+            for t in marks:
+                t.register_hook(self._boundary_hook)
         return d
 
     def _setup(self, data_dict):
@@ -150,6 +169,7 @@ class Trainer:
             self.optimizer = FlatAdam(self.bucket, **kw)
             self._attach_packed_qkv()
             self._register_grad_slots()
+            self._find_captioner_suffix()
         else:
             self.optimizer = torch.optim.Adam(used, **kw)
 
@@ -241,6 +261,10 @@ class Trainer:
         self.bucket.zero()
         if self._bn_counters is not None:
             self._bn_counters.add_(1)    # every BatchNorm layer's num_batches_tracked, one launch (see _adopt_bn_counters)
+        self._overlap_armed = self._overlap_possible(pc)
+        self._boundary_done = False
+        if self._overlap_armed:
+            self._sig[:1].add_(1)        # the step number the boundary will publish
         d = self.loss(data_dict)
         if pc.is_cuda:
             # the ~70 weight-gradient slab sums of the backward are only read by the optimizer: queue them and run them
@@ -275,6 +299,7 @@ class Trainer:
                 d["loss"].backward()
         else:
             d["loss"].backward()
+        self._overlap_armed = False
         if with_optimizer:
             self._optimizer_step(None)
         # the loss terms of this step as device scalars (no host sync; under graph replay: the static result tensors)
@@ -286,12 +311,96 @@ class Trainer:
         """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket and takes the
         1 / world of the mean as its gradient scale: no separate division pass over the 36 MB bucket."""
         flat = not isinstance(self.optimizer, torch.optim.Optimizer)
+        if flat and self._boundary_done:
+            # the captioner's slice was packed (and published) in the middle of the backward: its all-reduce goes to the
+            # communication stream behind a wait for that flag, the detector's slice follows on this stream
+            self._overlapped_tail(sources)
+            return
         scale = self.bucket.all_reduce(sources=sources, force_pack=self.split_optimizer or flat, average=not flat)
         self.grad_scale = scale            # bucket.flat * grad_scale = the mean gradient the optimizer applied
         if flat:
             self.optimizer.step(grad_scale=scale)
         else:
             self.optimizer.step()
+
+    # -- all-reduce overlapped with the backward ---------------------------------------------------------------------
+    # The flat bucket holds the detector's parameters first and the captioner's last (_find_captioner_suffix).  The backward
+    # finishes the captioner long before the backbone (it is ~40 % of the backward's time), so its slice can travel while
+    # the detector's backward still runs: at the boundary (a tensor hook, see loss()) the step flushes the deferred weight
+    # gradients queued so far, copies the captioner's stray gradients into the bucket and publishes the step number in a
+    # device word; the host, after launching the step, queues "wait for that word, all-reduce the captioner's slice" on a
+    # communication stream.  All of this is captured into the step's hipGraph like any other kernel; the collective
+    # itself stays outside (RCCL calls are not captured).  Values are those of the serial tail: an all-reduce is elementwise.
+    def _find_captioner_suffix(self):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        ps = self.bucket.params
+        i = len(ps)
+        while i > 0 and names.get(id(ps[i - 1]), "").startswith("caption."):
+            i -= 1
+        ok = 0 < i < len(ps) and not any(names.get(id(p), "").startswith("caption.") for p in ps[:i])
+        self._cap_start = i if ok else None
+
+    def _overlap_possible(self, pc):
+        if not (self.overlap_allreduce and pc.is_cuda and self._cap_start is not None and self.bucket is not None
+                and not self.bucket.views_mode and not isinstance(self.optimizer, torch.optim.Optimizer)):
+            return False
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not (multi or self.split_optimizer):
+            return False
+        if self._sig is None:
+            self._sig = torch.zeros(2, dtype=torch.int64, device=pc.device)
+            self._comm_stream = torch.cuda.Stream(device=pc.device)
+        return True
+
+    def _boundary_hook(self, grad):
+        if self._overlap_armed and not self._boundary_done:
+            self._boundary_done = True
+            self._boundary()
+        return None
+
+    def _boundary(self):
+        from . import _native
+        from ._native import check, copy_batched, lib
+        dq = _native._DEFERRED
+        if dq is not None:
+            dq.flush()             # the captioner's weight gradients and slab sums (one batched launch each)
+        b, i0 = self.bucket, self._cap_start
+        pairs = [(v, p.grad) for p, v in zip(b.params[i0:], b.views[i0:]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if pairs:
+            copy_batched([v for v, _ in pairs], [g.contiguous() for _, g in pairs])
+        dev = b.flat.device
+        check(lib.spacap_stream_signal(self._sig[1:].data_ptr(), self._sig[:1].data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "spacap_stream_signal")
+        self.boundary_launches += 1
+
+    def _overlapped_tail(self, sources):
+        import torch.distributed as dist
+        from ._native import check, copy_batched, lib
+        b, i0 = self.bucket, self._cap_start
+        dev = b.flat.device
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        off = b.offsets[i0]
+        self._sig_host += 1
+        main = torch.cuda.current_stream(dev)
+        if multi:
+            comm = self._comm_stream
+            with torch.cuda.stream(comm):
+                check(lib.spacap_stream_wait_ge(self._sig[1:].data_ptr(), self._sig_host, 2000, comm.cuda_stream), "spacap_stream_wait_ge")
+                dist.all_reduce(b.flat[off:], op=dist.ReduceOp.SUM)
+        # the detector's stray gradients (everything the captured step did not produce inside the bucket)
+        if sources is None:
+            sources = [p.grad for p in b.params]
+        pairs = [(v, s_) for v, s_ in zip(b.views[:i0], sources[:i0]) if s_ is not None and s_.data_ptr() != v.data_ptr()]
+        if pairs:
+            copy_batched([v for v, _ in pairs], [s_.contiguous() for _, s_ in pairs])
+        for p, v in zip(b.params, b.views):
+            p.grad = v
+        if multi:
+            dist.all_reduce(b.flat[:off], op=dist.ReduceOp.SUM)
+            main.wait_stream(self._comm_stream)
+        self.grad_scale = 1.0 / dist.get_world_size() if multi else 1.0
+        self.optimizer.step(grad_scale=self.grad_scale)
 
     # -- hipGraph mode ------------------------------------------------------------------------------------------
     # One training step is ~800 kernel launches (1 900 before the fused operators), most of them microseconds long; eager

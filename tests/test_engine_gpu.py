@@ -241,6 +241,54 @@ def test_geometry_pyramid_equals_what_the_modules_compute_themselves():
             assert torch.equal(a, b)
 
 
+def test_gradient_slices_published_mid_backward_give_the_serial_tail():
+    """The multi-rank tail overlapped with the backward (engine.Trainer._boundary / _overlapped_tail): at the captioner /
+    detector boundary of the backward the step flushes the deferred weight gradients, packs the captioner's slice of the flat
+    bucket and publishes the step number; the tail packs the detector's slice.  On one GPU (split_optimizer: the multi-rank code
+    path without a process group): after every step -- eager and replayed -- the flat bucket must hold, bit for bit, the FINAL
+    gradient of every parameter (a captioner gradient produced or changed after the boundary would leave a stale slice), and
+    the losses follow the serial tail's (two separate runs are not bitwise repeatable: the tolerance of the other mode
+    comparisons).  SURVEY.md section 8e; reference: one gradient exchange per step, scripts/train.py:198-200."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    losses = {}
+    for overlap in (True, False):
+        model = _make()
+        tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=True)
+        tr.overlap_allreduce = overlap
+        data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+        finals = []
+        if overlap:
+            real = tr._overlapped_tail
+
+            def spy(sources, real=real, tr=tr, finals=finals):
+                src = sources if sources is not None else [p.grad for p in tr.bucket.params]
+                finals.append([g.detach().clone() if g is not None else None for g in src])
+                real(sources)
+            tr._overlapped_tail = spy
+        out = [float(tr.step(data, next_data=data)) for _ in range(2)]
+        if overlap:
+            assert len(finals) == 2 and tr.boundary_launches == 2
+            for want, v in zip(finals[-1], tr.bucket.views):
+                if want is not None:
+                    assert torch.equal(want, v)
+        assert tr.enable_graph(data, warmup=1), tr.graph_error
+        out += [float(tr.step(data, next_data=data)) for _ in range(3)]
+        torch.cuda.synchronize()
+        if overlap:
+            assert tr._cap_start is not None and 0 < tr._cap_start < len(tr.bucket.params)
+            assert tr.boundary_launches == 4                      # two eager steps, the warm-up step, the capture
+            nz = 0
+            for want, v in zip(tr._graph_grads, tr.bucket.views):  # the replayed step's own gradient tensors
+                assert torch.equal(want, v)
+                nz += int(want.abs().max() > 0)
+            assert nz > len(tr.bucket.views) // 2
+        else:
+            assert tr.boundary_launches == 0
+        losses[overlap] = out
+    for i, (x, y) in enumerate(zip(losses[True], losses[False])):
+        assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (i, losses)
+
+
 def test_bench_runs_with_two_ranks_sharing_the_gpu():
     """The multi-rank path of bench.py end to end on a one-GPU box: two ranks launched exactly as the driver does
     (torch.distributed.run), both mapped onto cuda:0 and talking gloo instead of RCCL (test knobs SPACAP_SHARE_GPU /

@@ -96,7 +96,9 @@ def main():
                     rec[k] = c[k]
             if c.get("GRBM_GUI_ACTIVE"):
                 rec["mfma_util"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
-                if rec.get("profiled_us"):
+                # (GRBM_GUI_ACTIVE also counts the dispatch's ramp: for launches under ~50 us the quotient exceeds the chip's
+                # clock -- 3.3 "GHz" was reported for a 14 us launch in round 3 -- so it is only given for long ones)
+                if rec.get("profiled_us") and rec["profiled_us"] >= 50.0:
                     rec["clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / rec["profiled_us"] * 1e-3
             if "SQ_INSTS_VALU_MFMA_MOPS_F32" in c:
                 rec["mfma_flops_counted"] = c["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0
