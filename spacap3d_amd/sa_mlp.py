@@ -29,6 +29,53 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_SELFTESTED = set()
+
+
+def _selftest(dev):
+    """Once per process and device, before the first fused SA op: the streaming split-bf16 kernels (csrc/sa_bf3.inc,
+    sa_bf3_dgrad.inc) land their prefetched rows in AGPRs that are named inside inline asm and therefore invisible to the
+    register allocator.  The build checks the generated assembly for compiler uses of those registers
+    (tools/check_landing_regs.py); this is the matching check at RUN time, on the library that was actually loaded: a few
+    tiles through the forward layer kernel and the data-gradient kernel against float64 -- a clobbered landing register gives
+    errors of order one, the bar is 1e-4 of the result's scale.  Raises instead of training on garbage."""
+    key = (dev.type, dev.index)
+    if key in _SELFTESTED:
+        return
+    _SELFTESTED.add(key)
+    with torch.cuda.device(dev), torch.no_grad():
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if torch.cuda.is_current_stream_capturing():
+            _SELFTESTED.discard(key)   # (never inside a graph capture: it synchronises)
+            return
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        R, ci, co = 49152 + 96, 128, 128
+        zin, W = torch.randn(R, ci, generator=g).to(dev), (0.1 * torch.randn(co, ci, generator=g)).to(dev)
+        stats = torch.tensor([0.05, 1.0, 1.1, 0.02], device=dev).repeat(ci, 1).contiguous()
+        zout = torch.empty(R, co, dtype=torch.float32, device=dev)
+        part = torch.empty(int(lib.spacap_sa_nparts()) * 2 * max(ci, co), dtype=torch.float64, device=dev)
+        check(lib.spacap_sa_mid_fwd_f32(zin.data_ptr(), stats.data_ptr(), W.data_ptr(), R, ci, co, zout.data_ptr(), part.data_ptr(), st),
+              "spacap_sa_mid_fwd_f32 (self-test)")
+        a = ((zin.double() - 0.05) * 1.1 + 0.02).clamp_min(0)
+        ref = a @ W.double().t()
+        e1 = float((zout.double() - ref).abs().max() / ref.abs().max())
+        # data gradient: dy_prev = (dz W) * [relu(bn(z_prev)) > 0], dz = g dy + k0 - k1 z
+        dy, zk = torch.randn(R, co, generator=g).to(dev), torch.randn(R, co, generator=g).to(dev)
+        coef = torch.tensor([1.05, 0.01, 0.02, 0.0], device=dev).repeat(co, 1).contiguous()
+        dyp = torch.empty(R, ci, dtype=torch.float32, device=dev)
+        check(lib.spacap_sa_dgrad_f32(dy.data_ptr(), None, 0, zk.data_ptr(), coef.data_ptr(), W.data_ptr(), zin.data_ptr(), stats.data_ptr(),
+                                      R, co, ci, dyp.data_ptr(), part.data_ptr(), st), "spacap_sa_dgrad_f32 (self-test)")
+        dz = 1.05 * dy.double() + 0.01 - 0.02 * zk.double()
+        pre = (zin.double() - 0.05) * 1.1 + 0.02
+        ref2 = (dz @ W.double()) * (pre > 0)
+        near = pre.abs() < 1e-6
+        e2 = float(((dyp.double() - ref2).abs() * (~near)).max() / ref2.abs().max())
+    if not (e1 < 1e-4 and e2 < 1e-4):
+        raise RuntimeError(f"libspacap_hip.so self-test failed: streaming shared-MLP kernels differ from float64 by {e1:.2e} (forward) / "
+                           f"{e2:.2e} (data gradient) of the result's scale -- the landing registers of csrc/sa_bf3*.inc are not safe "
+                           f"in this build (tools/check_landing_regs.py); set SPACAP_SA_F32MFMA=1 to run the fp32-MFMA kernels")
+
+
 class _SAMLP(Function):
     """inputs: xyz (B,Np,3), new_xyz (B,N,3), idx (B,N,S) int32, feat (B,Np) or None [inline 1-channel feature],
     pm (B,Np,Cf) or None [point-major features of the source points: the first layer commutes with the gather, so
@@ -40,6 +87,7 @@ class _SAMLP(Function):
     @staticmethod
     def forward(ctx, xyz, new_xyz, idx, feat, pm, W1, W2, W3, g1, b1, g2, b2, g3, b3, bns, rdiv, rows_index=None):
         dev = xyz.device
+        _selftest(dev)
         B, Np, _ = xyz.shape
         N, S = idx.shape[1], idx.shape[2]
         C1, C2, C3 = W1.shape[0], W2.shape[0], W3.shape[0]

@@ -122,10 +122,11 @@ def test_train_step_matches_reference(kind):
                 # weight perturbation on the CPU leg alone already changes which votes become proposals (aggregated
                 # features move by 100 % of their scale).  With the sampled indices identical -- asserted above --
                 # the gradients agree to fp32 summation-order noise amplified by the BatchNorm backward's
-                # cancellations; measured on MI355X (tools/lab/golden_err.py): linf <= 1.2e-2, l2 <= 2.8e-3.
+                # cancellations; measured on MI355X in round 4 (tools/lab/golden_err.py, profiles/r04_golden_err.txt):
+                # linf <= 1.7e-2, l2 <= 2.84e-3 (relation_proposal.0.weight); the bars are 1.5 x that.
                 linf = np.abs(g - fx[k]).max() / (np.abs(fx[k]).max() + 1e-12)
                 l2 = np.linalg.norm(g - fx[k]) / (np.linalg.norm(fx[k]) + 1e-12)
-                assert linf < 3e-2 and l2 < 6e-3, (k, linf, l2)
+                assert linf < 2.6e-2 and l2 < 4.3e-3, (k, linf, l2)
     absent = sorted(n for n, p in model.named_parameters() if p.grad is None)
     assert absent == list(fx["grad_absent"])
 

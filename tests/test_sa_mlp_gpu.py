@@ -297,3 +297,14 @@ def test_eval_mode_fused_path_folds_the_running_statistics(mlp, Cf, Sn):
     assert point_major_of(plain) is None
     err = float((fused - plain).abs().max() / plain.abs().max())
     assert err < 2e-5, err
+
+
+def test_library_self_test_of_the_streaming_kernels():
+    """sa_mlp._selftest (run once per process and device before the first fused SA op): the streaming split-bf16 kernels, whose
+    prefetched rows land in registers the compiler does not know about, against float64 on the library that is loaded."""
+    from spacap3d_amd import sa_mlp
+    dev = torch.device(DEV)
+    sa_mlp._SELFTESTED.discard((dev.type, dev.index))
+    sa_mlp._selftest(dev)
+    assert (dev.type, dev.index) in sa_mlp._SELFTESTED
+    sa_mlp._selftest(dev)      # second call: nothing to do
