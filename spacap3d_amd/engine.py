@@ -52,6 +52,7 @@ class Trainer:
         self._sig = None            # int64 [2] on the device: [0] = steps executed, [1] = "captioner gradients packed" flag
         self._sig_host = 0          # host mirror of _sig[0]
         self._boundary_done = False
+        self._armed_step = False
         self.boundary_launches = 0  # (tests: how many times the boundary actions ran)
         if next(model.parameters()).is_cuda:
             # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
@@ -262,6 +263,7 @@ class Trainer:
         if self._bn_counters is not None:
             self._bn_counters.add_(1)    # every BatchNorm layer's num_batches_tracked, one launch (see _adopt_bn_counters)
         self._overlap_armed = self._overlap_possible(pc)
+        self._armed_step = self._overlap_armed   # (persists through graph replays: the tail counts the step, see _optimizer_step)
         self._boundary_done = False
         if self._overlap_armed:
             self._sig[:1].add_(1)        # the step number the boundary will publish
@@ -311,6 +313,8 @@ class Trainer:
         """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket and takes the
         1 / world of the mean as its gradient scale: no separate division pass over the 36 MB bucket."""
         flat = not isinstance(self.optimizer, torch.optim.Optimizer)
+        if getattr(self, "_armed_step", False):
+            self._sig_host += 1    # mirrors the device-side step counter: one increment per EXECUTED armed step, boundary or not
         if flat and self._boundary_done:
             # the captioner's slice was packed (and published) in the middle of the backward: its all-reduce goes to the
             # communication stream behind a wait for that flag, the detector's slice follows on this stream
@@ -381,7 +385,6 @@ class Trainer:
         dev = b.flat.device
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         off = b.offsets[i0]
-        self._sig_host += 1
         main = torch.cuda.current_stream(dev)
         if multi:
             comm = self._comm_stream

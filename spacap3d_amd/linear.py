@@ -1,7 +1,9 @@
 """y = x W^T + b with a one-launch weight + bias gradient (csrc/sa_mlp.hip: linear_wgrad_kernel).
 
 Counterpart of the ``nn.Linear`` projections / feed-forward layers of the reference Transformer
-(models/transformer_captioner.py:63-99, 117-126).  Forward and dX stay ordinary BLAS GEMMs; the backward's
+(models/transformer_captioner.py:63-99, 117-126).  Forward and dX run on the row-panel kernel up to 512 rows (the default
+model's fused Transformer stacks, tf_layer.py, do not come through here at all; wider models' larger products still use the BLAS
+GEMM, see _forward_product); the backward's
 ``dW = g^T x`` and ``db = sum_r g`` -- for <= 2 048 rows a memset + a split-K GEMM + a column-sum kernel of
 ~30 us of latency -- become one kernel producing per-slab partials of both plus one sum over the slabs.
 """
@@ -179,9 +181,10 @@ def packed_views(flat, params_w, params_b):
 
 class Conv1x1(Function):
     """nn.Conv1d / nn.Conv2d with a 1x1 kernel on channel-major (B, C, N[, 1]) tensors -- the vote net and the
-    feature-propagation MLPs (models/voting_module.py:33-60, lib/pointnet2/pointnet2_modules.py:376-421).  Forward and
-    input gradient stay the library's kernels; the weight gradient (an implicit-GEMM kernel of 46 - 60 us, or one small
-    GEMM per scene) is csrc/sa_mlp.hip: conv1x1_wgrad_kernel + one sum over its slabs."""
+    feature-propagation MLPs (models/voting_module.py:33-60, lib/pointnet2/pointnet2_modules.py:376-421), the proposal head and the
+    position embedding.  Forward (bias in the epilogue) and input gradient: csrc/conv1x1.hip (USE_OWN_CONV; point counts that are
+    not a multiple of 64 fall back to the convolution library); weight gradient: csrc/sa_mlp.hip: conv1x1_wgrad_kernel + one sum
+    over its slabs."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):

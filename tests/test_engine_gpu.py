@@ -491,3 +491,30 @@ def test_gradient_slots_are_scoped_to_the_step_and_accumulation_outside_it_is_pl
         if err > 1e-3 * max(float(2 * a.abs().max()), 1e-3 * gmax):
             bad.append((names[id(p)], err, float(a.abs().max()), float((p.grad / (a + 1e-30)).median())))
     assert not bad, bad[:8]
+
+
+def test_no_library_gemm_or_convolution_kernel_inside_a_training_step():
+    """Round 4: every dense product of the default model's training step is one of this repository's kernels -- no rocBLAS
+    (`Cijk_*`), MIOpen (`naive_conv*`, `miopen*`) or hipBLASLt kernel is launched between the start of a step and the end of
+    its optimizer update (vote / proposal / FP / position nets: models/voting_module.py:28-61, models/proposal_module.py:46-54,
+    lib/pointnet2/pointnet2_modules.py:376-421, models/transformer_captioner.py:149-164; vocabulary projection :93-100; the SA
+    modules' first-layer feature product).  Checked on the kernel names of one eager step under torch.profiler."""
+    from torch.profiler import ProfilerActivity, profile
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    from spacap3d_amd.spacapnet import build_default
+    torch.manual_seed(0)
+    model = build_default(vocab_size=3001, num_proposal=256).to(DEV).train()     # the benchmark's model (widths matter here)
+    tr = Trainer(model, S.mean_size_arr().numpy())
+    data = synthetic_batch(2, 8192, DEV, seed=1)
+    for _ in range(2):
+        tr.step(data, next_data=data)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        tr.step(data, next_data=data)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
+    assert len(names) > 100, len(names)     # the profiler saw the step's kernels
+    bad = [n for n in names if n.startswith("Cijk_") or "naive_conv" in n or "miopen" in n.lower() or "hipblaslt" in n.lower()
+           or "rocblas" in n.lower()]
+    assert not bad, bad
+    assert any("conv1x1_cm_kernel" in n for n in names) and any("dense_rows_kernel" in n for n in names)
