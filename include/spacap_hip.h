@@ -139,6 +139,14 @@ int spacap_three_interpolate_grad_f32(const float *grad_out, const int32_t *idx,
  * of one element per 4 KB row). */
 int spacap_three_interpolate_grad_pm_f32(const float *grad_pm, const int32_t *idx, const float *weight, int B, int C,
                                          int n, int m, float *grad_points_pm, spacap_stream_t stream);
+/* The input of a feature-propagation module's shared MLP in one launch each way (lib/pointnet2/pointnet2_modules.py:406-412:
+   three_interpolate + torch.cat with the skip features): cat f32 [B,K1+K2,n] channel-major; known f32 [B,m,K1] (known_pm != 0:
+   an SA module's point-major output) or [B,K1,m]; idx i32 [B,n,3], weight f32 [B,n,3]; skip f32 [B,n,K2] point-major; K1 % 32
+   == 0.  Same values as three_interpolate (products added left to right).  _bwd: the gradient of cat split into its halves,
+   both point-major: g1 f32 [B,n,K1] (feed spacap_three_interpolate_grad_pm_f32), g2 f32 [B,n,K2]. */
+int spacap_fp_concat_fwd_f32(const float *known, int known_pm, const int32_t *idx, const float *weight, const float *skip, int B,
+                             int K1, int K2, int m, int n, float *out, spacap_stream_t stream);
+int spacap_fp_concat_bwd_f32(const float *g, int B, int K1, int K2, int n, float *g1, float *g2, spacap_stream_t stream);
 
 /* ---- attention (replaces models/transformer_captioner.py:27-37) ------------------------------ */
 

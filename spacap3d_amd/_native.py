@@ -98,6 +98,8 @@ SIGNATURES = {
     "spacap_sa_mid_fwd_pool_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p]),
     "spacap_sa_pool_finalize_f32": (_i, [_p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_pool_bwd_f32": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_fp_concat_fwd_f32": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "spacap_fp_concat_bwd_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "spacap_dense_rows_slices": (_i, [_l, _i, _i]),
     "spacap_dense_rows_f32": (_i, [_p, _l, _l, _l, _l, _p, _l, _i, _p, _l, _i, _i, _p, _l, _l, _l, _l, _i, _i, _l, _i, _l, _l, _p]),
     "spacap_dense_sum_slices_f32": (_i, [_p, _i, _l, _l, _p, _p]),

@@ -316,3 +316,113 @@ extern "C" int spacap_three_interpolate_grad_f32(const float *grad_out, const in
   SPACAP_CHECK_LAUNCH("spacap_three_interpolate_grad_f32");
   return SPACAP_OK;
 }
+
+// ===========================================================================================================
+// The input of a feature-propagation module's shared MLP in one launch each way (lib/pointnet2/pointnet2_modules.py:406-412:
+//   interpolated = three_interpolate(known_feats, idx, weight);  new_features = torch.cat([interpolated, unknow_feats], dim=1)).
+// cat[b][c][j] (channel-major, what the 1x1 convolution reads), c < K1: sum_i w[b][j][i] * known[b][idx[b][j][i]][c] with the
+// known features either point-major (B, m, K1) -- an SA module's own output: three coalesced row reads per point -- or channel-
+// major (B, K1, m) -- a previous FP module's output --; c >= K1: the skip features, point-major (B, n, K2) (an SA module's output).
+// Replaces a transposed copy + three_interpolate + cat.  32 points x 32 channels per workgroup through an LDS tile: reads run
+// along the channels of point-major rows, writes along the points of channel-major rows.  The three products are added left to
+// right like three_interpolate_kernel (same values).  Backward: the gradient of cat is split into its two halves, both written
+// point-major (what three_interpolate_grad_pm and the SA modules' backward read): replaces two narrowed, transposed copies.
+namespace {
+__global__ __launch_bounds__(256) void fp_concat_fwd_kernel(const float *__restrict__ known, int known_pm, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ weight, const float *__restrict__ skip, int K1,
+                                                            int K2, int m, int n, float *__restrict__ out) {
+  __shared__ float s[32][33];
+  const int b = blockIdx.z, j0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+  const int jl = tid >> 3, cq = (tid & 7) * 4;       // load map: point jl, channels c0 + cq .. + 3
+  const int j = j0 + jl;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (j < n) {
+    if (c0 < K1) {
+      const size_t r = ((size_t)b * n + j) * 3;
+      const float w1 = weight[r], w2 = weight[r + 1], w3 = weight[r + 2];
+      const int i1 = idx[r], i2 = idx[r + 1], i3 = idx[r + 2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + cq + u;
+        if (c < K1) {
+          if (known_pm) {
+            const float *p = known + (size_t)b * m * K1 + c;
+            v[u] = p[(size_t)i1 * K1] * w1 + p[(size_t)i2 * K1] * w2 + p[(size_t)i3 * K1] * w3;
+          } else {
+            const float *p = known + ((size_t)b * K1 + c) * m;
+            v[u] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 - K1 + cq + u;
+        if (c < K2) v[u] = skip[((size_t)b * n + j) * K2 + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[jl][cq + u] = v[u];
+  __syncthreads();
+  const int cl = tid >> 3, jq = (tid & 7) * 4;        // store map: channel cl, points j0 + jq .. + 3
+  const int c = c0 + cl;
+  if (c < K1 + K2 && (c0 >= K1 || c < K1)) {
+    float *o = out + ((size_t)b * (K1 + K2) + c) * n + j0 + jq;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + jq + u < n) o[u] = s[jq + u][cl];
+  }
+}
+
+// g (B, K1 + K2, n) channel-major -> g1 (B, n, K1), g2 (B, n, K2) point-major
+__global__ __launch_bounds__(256) void fp_concat_bwd_kernel(const float *__restrict__ g, int K1, int K2, int n, float *__restrict__ g1,
+                                                            float *__restrict__ g2) {
+  __shared__ float s[32][33];
+  const int b = blockIdx.z, j0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tid = threadIdx.x;
+  const int cl = tid >> 3, jq = (tid & 7) * 4;        // load map: channel cl, points j0 + jq .. + 3
+  const int c = c0 + cl;
+  const bool cok = c < K1 + K2 && (c0 >= K1 || c < K1);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s[jq + u][cl] = (cok && j0 + jq + u < n) ? g[((size_t)b * (K1 + K2) + c) * n + j0 + jq + u] : 0.f;
+  __syncthreads();
+  const int jl = tid >> 3, cq = (tid & 7) * 4;        // store map: point jl, channels c0 + cq .. + 3
+  const int j = j0 + jl;
+  if (j >= n) return;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int cc = c0 + cq + u;
+    if (c0 < K1) {
+      if (cc < K1) g1[((size_t)b * n + j) * K1 + cc] = s[jl][cq + u];
+    } else if (cc - K1 < K2) {
+      g2[((size_t)b * n + j) * K2 + cc - K1] = s[jl][cq + u];
+    }
+  }
+}
+}  // namespace
+
+/* cat f32 [B, K1+K2, n] = [three_interpolate(known, idx, weight) ; skip^T]: known f32 [B,m,K1] (known_pm != 0) or [B,K1,m], idx
+   i32 [B,n,3], weight f32 [B,n,3], skip f32 [B,n,K2] point-major.  K1 a multiple of 32 (a tile never straddles the two halves). */
+extern "C" int spacap_fp_concat_fwd_f32(const float *known, int known_pm, const int32_t *idx, const float *weight, const float *skip,
+                                        int B, int K1, int K2, int m, int n, float *out, spacap_stream_t stream) {
+  const char *what = "spacap_fp_concat_fwd_f32";
+  SPACAP_REQUIRE(B >= 0 && K1 >= 32 && K1 % 32 == 0 && K2 >= 1 && m >= 1 && n >= 1 && B <= 65535, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(known && idx && weight && skip && out, "%s: null pointer", what);
+  hipLaunchKernelGGL(fp_concat_fwd_kernel, dim3((n + 31) / 32, (K1 + K2 + 31) / 32, B), dim3(256), 0, spacap::as_stream(stream), known,
+                     known_pm, idx, weight, skip, K1, K2, m, n, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* the gradient of that concatenation split into its halves, both point-major: g f32 [B,K1+K2,n] -> g1 f32 [B,n,K1], g2 f32 [B,n,K2] */
+extern "C" int spacap_fp_concat_bwd_f32(const float *g, int B, int K1, int K2, int n, float *g1, float *g2, spacap_stream_t stream) {
+  const char *what = "spacap_fp_concat_bwd_f32";
+  SPACAP_REQUIRE(B >= 0 && K1 >= 32 && K1 % 32 == 0 && K2 >= 1 && n >= 1 && B <= 65535, "%s: bad sizes", what);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(g && g1 && g2, "%s: null pointer", what);
+  hipLaunchKernelGGL(fp_concat_bwd_kernel, dim3((n + 31) / 32, (K1 + K2 + 31) / 32, B), dim3(256), 0, spacap::as_stream(stream), g, K1, K2, n,
+                     g1, g2);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

@@ -166,6 +166,11 @@ class PointnetFPModule(nn.Module):
         """``nn``: optionally the precomputed ``neighbours(unknown, known)`` (coordinates only)."""
         if known is not None:
             idx, weight = nn if nn is not None else self.neighbours(unknown, known)
+            if self.training and torch.is_grad_enabled() and unknow_feats is not None:
+                # interpolation + concatenation with the skip features in one launch each way (no transposed copies, no cat)
+                cat = pointnet2_utils.fp_concat_train(known_feats, idx, weight, unknow_feats)
+                if cat is not None:
+                    return self.mlp(cat.unsqueeze(-1)).squeeze(-1)
             if self.training and torch.is_grad_enabled():
                 interpolated = pointnet2_utils.three_interpolate_train(known_feats, idx, weight)
             else:

@@ -101,6 +101,59 @@ class ThreeInterpolatePM(Function):
         return (g if ctx.point_major else g.transpose(1, 2)), None, None, None
 
 
+class FPConcat(Function):
+    """``torch.cat([three_interpolate(known_feats, idx, weight), unknow_feats], dim=1)`` of PointnetFPModule.forward
+    (lib/pointnet2/pointnet2_modules.py:406-412) as ONE launch each way (csrc/interpolate.hip: fp_concat_*): ``known`` is the
+    point-major (B, m, K1) output of an SA module (``known_pm``) or a channel-major (B, K1, m) tensor, ``skip_pm`` the point-major
+    (B, n, K2) skip features; returns the channel-major (B, K1 + K2, n) input of the module's first 1x1 convolution.  The backward
+    splits the gradient into its two halves, both point-major, and gathers the interpolation's gradient on point-major rows."""
+
+    @staticmethod
+    def forward(ctx, known, idx, weight, skip_pm, known_pm):
+        from ._native import check, lib
+        known, idx, weight, skip_pm = known.contiguous(), idx.contiguous(), weight.contiguous(), skip_pm.contiguous()
+        B, n, K2 = skip_pm.shape
+        m, K1 = (known.shape[1], known.shape[2]) if known_pm else (known.shape[2], known.shape[1])
+        dev = known.device
+        with torch.cuda.device(dev):
+            out = torch.empty(B, K1 + K2, n, dtype=torch.float32, device=dev)
+            check(lib.spacap_fp_concat_fwd_f32(known.data_ptr(), 1 if known_pm else 0, idx.data_ptr(), weight.data_ptr(), skip_pm.data_ptr(),
+                                               B, K1, K2, m, n, out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                  "spacap_fp_concat_fwd_f32")
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (B, K1, K2, m, n, bool(known_pm))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._native import check, lib
+        idx, weight = ctx.saved_tensors
+        B, K1, K2, m, n, known_pm = ctx.dims
+        g = g.contiguous()
+        dev = g.device
+        with torch.cuda.device(dev):
+            g1 = torch.empty(B, n, K1, dtype=torch.float32, device=dev)
+            g2 = torch.empty(B, n, K2, dtype=torch.float32, device=dev)
+            check(lib.spacap_fp_concat_bwd_f32(g.data_ptr(), B, K1, K2, n, g1.data_ptr(), g2.data_ptr(),
+                                               torch.cuda.current_stream(dev).cuda_stream), "spacap_fp_concat_bwd_f32")
+        dk = ops().three_interpolate_grad_pm(g1, idx, weight, m) if ctx.needs_input_grad[0] else None     # (B, m, K1)
+        if dk is not None and not known_pm:
+            dk = dk.transpose(1, 2)
+        return dk, None, None, (g2 if ctx.needs_input_grad[3] else None), None
+
+
+def fp_concat_train(known_feats, idx, weight, unknow_feats):
+    """The concatenated input of a feature-propagation MLP (see FPConcat), or None when it does not apply (CPU, widths that are
+    not multiples of 32, skip features without a point-major twin)."""
+    if not (known_feats.is_cuda and known_feats.dtype == torch.float32 and getattr(ops(), "three_interpolate_grad_pm", None) is not None):
+        return None
+    skip_pm = point_major_of(unknow_feats)
+    if skip_pm is None or known_feats.shape[1] % 32:
+        return None
+    kpm = point_major_of(known_feats)
+    return FPConcat.apply(kpm if kpm is not None else known_feats, idx, weight, skip_pm, kpm is not None)
+
+
 def three_interpolate_train(features, idx, weight):
     """Training-path interpolation: point-major gradient gather when the backend has it (same values)."""
     if getattr(ops(), "three_interpolate_grad_pm", None) is None or not features.is_cuda:

@@ -177,3 +177,36 @@ def test_copy_batched_moves_every_tensor_in_one_launch():
     copy_batched([a], [bsrc.expand(4, 3)])
     assert bool((a == 1).all())
 
+
+
+@pytest.mark.parametrize("B,m,n,K1,K2,known_pm", [(8, 256, 512, 256, 256, True), (8, 512, 1024, 256, 256, False), (2, 37, 61, 64, 7, True),
+                                                  (3, 5, 33, 32, 40, False)])
+def test_feature_propagation_input_in_one_launch_each_way(B, m, n, K1, K2, known_pm):
+    """FPConcat (csrc/interpolate.hip: fp_concat_*) = torch.cat([three_interpolate(known, idx, weight), skip], 1) of
+    PointnetFPModule.forward (lib/pointnet2/pointnet2_modules.py:406-412): identical values (the three products are added in the
+    operator's order), gradients of both inputs against the composition of the separate operators."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd.layout import ChannelMajorOf
+    g = torch.Generator().manual_seed(B * n + K2)
+    known_pm_t = torch.randn(B, m, K1, generator=g).to(DEV)
+    skip_pm_t = torch.randn(B, n, K2, generator=g).to(DEV)
+    idx = torch.randint(0, m, (B, n, 3), generator=g, dtype=torch.int32).to(DEV)
+    w = torch.rand(B, n, 3, generator=g).to(DEV)
+    w = (w / w.sum(-1, keepdim=True)).contiguous()
+    go = torch.randn(B, K1 + K2, n, generator=g).to(DEV)
+    # fused
+    a1, s1 = known_pm_t.clone().requires_grad_(True), skip_pm_t.clone().requires_grad_(True)
+    known_arg = a1 if known_pm else a1.transpose(1, 2).contiguous()      # channel-major (B, K1, m) input in the second mode
+    if not known_pm:
+        known_arg = known_arg.detach().requires_grad_(True)
+    out = pu.FPConcat.apply(known_arg, idx, w, s1, known_pm)
+    out.backward(go)
+    # composition of the separate operators
+    kc = known_pm_t.transpose(1, 2).contiguous().requires_grad_(True)    # (B, K1, m)
+    sc = skip_pm_t.transpose(1, 2).contiguous().requires_grad_(True)     # (B, K2, n)
+    ref = torch.cat([pu.three_interpolate(kc, idx, w), sc], dim=1)
+    ref.backward(go)
+    assert torch.equal(out, ref)
+    dk = known_arg.grad if not known_pm else a1.grad.transpose(1, 2)
+    assert float((dk - kc.grad).abs().max()) <= 1e-5 * float(kc.grad.abs().max())
+    assert torch.equal(s1.grad.transpose(1, 2), sc.grad)
