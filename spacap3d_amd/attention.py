@@ -65,6 +65,9 @@ _CALL_COUNTER = [None]
 
 
 def rng_state(device):
+    device = torch.device(device)     # ("cuda:0" and torch.device("cuda", 0) must name the same word)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     st = _RNG_STATE.get(device)
     if st is None:
         st = torch.zeros(1, dtype=torch.int64, device=device)

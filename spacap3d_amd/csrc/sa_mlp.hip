@@ -1513,9 +1513,18 @@ extern "C" int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, 
     hipLaunchKernelGGL((sa_l3bwd_kernel<C2V, C3V, TV, PV>), dim3(grid), dim3(C2V * 4), l3bwd_lds_bytes(C2V, TV, PV), s, a);       \
   }
   // C2 = 64: one launch; C2 = 128: the data half, then the weight half (each streams z2; one register file holds either)
-  if (C2 == 64) L3(64, 128, 64, 0)
-  else if (C3 == 128) { L3(128, 128, 32, 1) L3(128, 128, 32, 2) }
-  else { L3(128, 256, 32, 1) L3(128, 256, 32, 2) }
+  const bool only_w = (a.dbg & 16) != 0, only_d = (a.dbg & 32) != 0;   // lab: the weight half / the data half alone
+  if (C2 == 64) {
+    if (only_w) L3(64, 128, 64, 2)
+    else if (only_d) L3(64, 128, 64, 1)
+    else L3(64, 128, 64, 0)
+  } else if (C3 == 128) {
+    if (!only_w) L3(128, 128, 32, 1)
+    if (!only_d) L3(128, 128, 32, 2)
+  } else {
+    if (!only_w) L3(128, 256, 32, 1)
+    if (!only_d) L3(128, 256, 32, 2)
+  }
 #undef L3
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
