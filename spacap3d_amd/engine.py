@@ -170,9 +170,9 @@ class Trainer:
             self.optimizer = FlatAdam(self.bucket, **kw)
             self._attach_packed_qkv()
             self._register_grad_slots()
-            self._find_captioner_suffix()
         else:
             self.optimizer = torch.optim.Adam(used, **kw)
+        self._find_captioner_suffix()
 
     def _adopt_bn_counters(self):
         """The ``num_batches_tracked`` buffers of the BatchNorm layers whose training forward runs through the fused ops

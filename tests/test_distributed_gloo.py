@@ -144,3 +144,28 @@ def test_real_training_step_on_two_rccl_ranks():
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     _launch_workers("cuda")
     _launch_workers("cuda", extra=("--graph", "--steps", "3"))
+
+
+def test_flat_bucket_keeps_the_captioner_parameters_as_one_suffix():
+    """The overlapped gradient exchange (engine.Trainer._boundary / _overlapped_tail) all-reduces the flat bucket in two slices:
+    [detector | captioner].  That needs the captioner's parameters -- the packed q | k | v groups included, which _group_qkv
+    moves to the end -- to form ONE suffix of the bucket, 16-byte aligned like every tensor of it."""
+    import torch
+    from spacap3d_amd import synthetic as S
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    from spacap3d_amd.spacapnet import build_default
+    from oracle.attention_ref import OracleBackend
+    from spacap3d_amd import backend
+    torch.manual_seed(0)
+    with backend.use_backend(OracleBackend()):
+        model = build_default(vocab_size=60, num_proposal=16, N=1, d_ff=64).train()
+        tr = Trainer(model, S.mean_size_arr().numpy())
+        tr._setup(synthetic_batch(1, 1024, "cpu", seed=0, vocab=60))
+    names = {id(p): n for n, p in model.named_parameters()}
+    i0 = tr._cap_start
+    ps = tr.bucket.params
+    assert i0 is not None and 0 < i0 < len(ps)
+    assert all(names[id(p)].startswith("caption.") for p in ps[i0:]) and not any(names[id(p)].startswith("caption.") for p in ps[:i0])
+    assert tr.bucket.offsets[i0] % 4 == 0
+    # the slices cover the bucket exactly
+    assert tr.bucket.flat[:tr.bucket.offsets[i0]].numel() + tr.bucket.flat[tr.bucket.offsets[i0]:].numel() == tr.bucket.flat.numel()
