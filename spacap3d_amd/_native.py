@@ -112,6 +112,9 @@ SIGNATURES = {
     "spacap_sa_l3bwd_prep_f32": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "spacap_sa_l3bwd_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_l3bwd_dw_f32": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "spacap_sa_wgrad_pool_supported": (_i, [_i, _i, _i]),
+    "spacap_sa_wgrad_pool_parts": (_i, [_l, _i, _i, _i]),
+    "spacap_sa_wgrad_pool_f32": (_i, [_p, _p, _i, _p, _p, _p, _l, _i, _i, _p, _p]),
     "spacap_sa_bwd_finalize_f32": (_i, [_p, _i, _l, _p, _p, _p, _p, _p]),
     "spacap_sa_dgrad_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_dgrad_l1_f32": (_i, [_p] * 10 + [_f] + [_i] * 6 + [_p, _p, _p]),

@@ -1545,6 +1545,43 @@ extern "C" int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const floa
   return SPACAP_OK;
 }
 
+// ---- pooled layer's weight gradient from z2 alone (sa_l3bwd.inc: sa_wgrad_pool_kernel) ------------------------------------
+extern "C" int spacap_sa_wgrad_pool_supported(int C2, int C3, int S) { return wgrad_pool_shape(C2, C3, S) ? 1 : 0; }
+namespace {
+int wgrad_pool_grid(long R, int C2, int S) {
+  // C2 = 64: two workgroups of four waves per CU; C2 = 128: one of eight (its partial is 197 KB: fewer, larger partials)
+  long g = (long)device_cus() * (C2 == 64 ? 2 : 1), tiles = (R + S - 1) / S;
+  if (g > NPART) g = NPART;
+  if (g > tiles) g = tiles;
+  return (int)(g < 1 ? 1 : g);
+}
+}  // namespace
+/* workgroups (= partials, each spacap_sa_l3bwd_part_floats(C2, C3) floats) of spacap_sa_wgrad_pool_f32 */
+extern "C" int spacap_sa_wgrad_pool_parts(long R, int C2, int C3, int S) {
+  return wgrad_pool_shape(C2, C3, S) && R >= 1 ? wgrad_pool_grid(R, C2, S) : 0;
+}
+/* partial sums of dW3 = (g d)^T a2 + k0 (x) colsum(a2) - diag(k1) W3 (a2^T a2) of a pooled layer from (dym, arg), z2 and layer
+   2's statistics: z3 is not read.  partW [spacap_sa_wgrad_pool_parts][spacap_sa_l3bwd_part_floats]; spacap_sa_l3bwd_dw_f32
+   turns it into dW3. */
+extern "C" int spacap_sa_wgrad_pool_f32(const float *dym, const uint8_t *arg, int S, const float *coef3, const float *z2,
+                                        const float *st2, long R, int C3, int C2, float *partW, spacap_stream_t stream) {
+  const char *what = "spacap_sa_wgrad_pool_f32";
+  SPACAP_REQUIRE(dym && arg && coef3 && z2 && st2 && partW && R >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(wgrad_pool_shape(C2, C3, S) && R % S == 0, "%s: (C2=%d, C3=%d, S=%d) unsupported", what, C2, C3, S);
+  SPACAP_REQUIRE((reinterpret_cast<uintptr_t>(arg) & 3) == 0 && (reinterpret_cast<uintptr_t>(z2) & 15) == 0, "%s: unaligned pointer", what);
+  const WPArgs a{dym, arg, coef3, z2, st2, R, partW};
+  const int grid = wgrad_pool_grid(R, C2, S);
+  hipStream_t s = spacap::as_stream(stream);
+#define WP(C2V, C3V, SV) \
+  hipLaunchKernelGGL((sa_wgrad_pool_kernel<C2V, C3V, SV, SV>), dim3(grid), dim3(C2V * 4), wgrad_pool_lds_bytes(C2V, C3V, SV, SV), s, a)
+  if (C2 == 64) WP(64, 128, 64);
+  else if (C3 == 128) WP(128, 128, 32);
+  else WP(128, 256, 32);
+#undef WP
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // dy: dense [R, CK] when arg == NULL, else the masked pooled gradient [R / S, CK] with its arg-max map
 extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                                    const float *Wk, const float *zp, const float *st_p, long R, int CK, int CP,

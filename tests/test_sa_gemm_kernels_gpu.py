@@ -333,3 +333,73 @@ def test_pooled_last_layer_backward_without_its_preactivation(R, c2, c3, S):
                                   z2.data_ptr(), st2.data_ptr(), R, c3, c2, dy2b.data_ptr(), part.data_ptr(), pwb.data_ptr(), s), "l3bwd")
     torch.cuda.synchronize()
     assert torch.equal(dy2, dy2b) and torch.equal(pw, pwb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,c2,c3,S", [(64 * 700, 64, 128, 64), (64 * 3, 64, 128, 64), (32 * 2100, 128, 256, 32), (32 * 517, 128, 128, 32),
+                                       (32, 128, 256, 32)])
+def test_pooled_layer_weight_gradient_from_z2_alone(R, c2, c3, S):
+    """csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel (spacap_sa_wgrad_pool_f32 + spacap_sa_l3bwd_dw_f32) against float64
+    dW3 = dz3^T a2 with dz3 = g d + k0 - k1 z3, z3 = a2 W3^T (lib/pointnet2/pytorch_utils.py:11-36 Conv2d -> BatchNorm2d -> ReLU,
+    lib/pointnet2/pointnet2_modules.py:256-259 max_pool2d; autograd backward), and against the dense kernel that reads z3."""
+    from spacap3d_amd._native import check, lib
+    assert lib.spacap_sa_wgrad_pool_supported(c2, c3, S)
+    dev = "cuda:0"
+    torch.manual_seed(R + c3)
+    G = R // S
+    dym = torch.randn(G, c3, device=dev)
+    dym[torch.rand(G, c3, device=dev) < 0.3] = 0.0
+    arg = torch.randint(0, S, (G, c3), dtype=torch.uint8, device=dev)
+    arg[::5] = 3
+    arg[1::7] = S - 1
+    z2 = torch.randn(R, c2, device=dev)
+    W3 = 0.2 * torch.randn(c3, c2, device=dev)
+    coef = torch.stack([1 + 0.1 * torch.rand(c3, device=dev), 0.02 * torch.randn(c3, device=dev), 0.02 * torch.randn(c3, device=dev),
+                        torch.zeros(c3, device=dev)], dim=1).contiguous()
+    st2 = torch.stack([0.05 * torch.randn(c2, device=dev), 1 + 0.1 * torch.rand(c2, device=dev), 1 + 0.2 * torch.rand(c2, device=dev),
+                       0.1 * torch.randn(c2, device=dev)], dim=1).contiguous()
+    s = torch.cuda.current_stream().cuda_stream
+    npw, nfl = int(lib.spacap_sa_wgrad_pool_parts(R, c2, c3, S)), int(lib.spacap_sa_l3bwd_part_floats(c2, c3))
+    assert 1 <= npw <= G
+
+    def run():
+        pw = torch.full((npw, nfl), float("nan"), device=dev)
+        check(lib.spacap_sa_wgrad_pool_f32(dym.data_ptr(), arg.data_ptr(), S, coef.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, c3, c2,
+                                           pw.data_ptr(), s), "wgrad_pool")
+        sums = torch.empty(nfl, dtype=torch.float64, device=dev)
+        dW3 = torch.empty(c3, c2, device=dev)
+        check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef.data_ptr(), W3.data_ptr(), c3, c2, sums.data_ptr(), dW3.data_ptr(), s), "dw")
+        torch.cuda.synchronize()
+        return pw, dW3
+
+    pw, dW3 = run()
+    assert torch.isfinite(pw).all()
+    z2d, W3d, cd, sd = z2.double(), W3.double(), coef.double(), st2.double()
+    a2 = ((z2d - sd[:, 0]) * sd[:, 2] + sd[:, 3]).clamp_min(0)
+    # the three partial sums themselves
+    tot = pw.double().sum(0)
+    d = torch.zeros(G, S, c3, dtype=torch.float64, device=dev)
+    d.scatter_(1, arg.long().unsqueeze(1), dym.double().unsqueeze(1))
+    sp_ref = (cd[:, 0] * d.view(R, c3)).t() @ a2
+    gram_ref = a2.t() @ a2
+    assert ((tot[:c3 * c2].view(c3, c2) - sp_ref).abs().max() / sp_ref.abs().max()).item() < 3e-6
+    gram = tot[c3 * c2:c3 * c2 + c2 * c2].view(c2, c2)
+    assert ((gram - gram_ref).abs().max() / gram_ref.abs().max()).item() < 3e-6
+    assert torch.equal(pw[:, c3 * c2:c3 * c2 + c2 * c2].view(npw, c2, c2), pw[:, c3 * c2:c3 * c2 + c2 * c2].view(npw, c2, c2).transpose(1, 2))
+    assert ((tot[c3 * c2 + c2 * c2:] - a2.sum(0)).abs().max() / a2.sum(0).abs().max()).item() < 3e-6
+    # the weight gradient
+    z3 = a2 @ W3d.t()
+    dz3 = cd[:, 0] * d.view(R, c3) + cd[:, 1] - cd[:, 2] * z3
+    dW3_ref = dz3.t() @ a2
+    errw = ((dW3.double() - dW3_ref).abs().max() / dW3_ref.abs().max()).item()
+    assert errw < 3e-6, errw
+    # the dense kernel on the same inputs (z3 as the forward stores it)
+    z3f = z3.float().contiguous()
+    pwo = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, c3, c2, 1)), c3, c2, device=dev)
+    check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3f.data_ptr(), coef.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, c3, c2,
+                                  pwo.data_ptr(), s), "wgrad")
+    torch.cuda.synchronize()
+    dW3_old = pwo.double().sum(0)
+    assert ((dW3.double() - dW3_old).abs().max() / dW3_old.abs().max()).item() < 1e-5
+    pw2, dW3b = run()
+    assert torch.equal(pw, pw2) and torch.equal(dW3, dW3b)
