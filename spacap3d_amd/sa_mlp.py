@@ -23,6 +23,12 @@ RECOMPUTE_Z1 = True
 # scatter of the sparse term through LDS float atomics costs 540 us there (ds_add_f32 runs at ~1 500 cycles per wave
 # instruction on gfx950), the streaming skeleton with one tile in flight another 240.  Off until that is fixed.
 Z3_FREE = os.environ.get("SPACAP_SA_Z3_FREE", "0") not in ("", "0")
+# pooled last layer with z3 stored: its WEIGHT gradient alone from z2 (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel -- the sparse
+# term (g d)^T a2 plus the Gram matrix a2^T a2) instead of the dense kernel that streams z3 and z2 and multiplies a [C3 x rows]
+# operand with one non-zero per group and channel.  SA1: 92 + 12 us against 249 + 12 us (tools/lab/wgrad_pool_bench.py).  Used
+# from POOL_WGRAD_MIN_ROWS rows on (below, the two extra launches of the reduction cost more than the pass saves).
+POOL_WGRAD = os.environ.get("SPACAP_SA_POOL_WGRAD", "1") not in ("", "0")
+POOL_WGRAD_MIN_ROWS = 131072
 
 
 def _ptr(t):
@@ -226,10 +232,21 @@ class _SAMLP(Function):
                                                  dW3.data_ptr(), st), "spacap_sa_l3bwd_dw_f32")
             else:
                 # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
-                pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
-                check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
-                                              z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-                dW3 = sum_slabs(pw, deferrable=True)
+                if POOL_WGRAD and R >= POOL_WGRAD_MIN_ROWS and lib.spacap_sa_wgrad_pool_supported(C2, C3, S):
+                    # from z2 alone: dW3 = (g d)^T a2 + k0 (x) colsum a2 - diag(k1) W3 a2^T a2
+                    npw, nfl = int(lib.spacap_sa_wgrad_pool_parts(R, C2, C3, S)), int(lib.spacap_sa_l3bwd_part_floats(C2, C3))
+                    pw = torch.empty(npw, nfl, **f32)
+                    check(lib.spacap_sa_wgrad_pool_f32(dym.data_ptr(), arg.data_ptr(), S, coef[2].data_ptr(), z2.data_ptr(),
+                                                       st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_pool_f32")
+                    sums = torch.empty(nfl, dtype=torch.float64, device=dev)
+                    dW3 = torch.empty(C3, C2, **f32)
+                    check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef[2].data_ptr(), W3.data_ptr(), C3, C2, sums.data_ptr(),
+                                                     dW3.data_ptr(), st), "spacap_sa_l3bwd_dw_f32")
+                else:
+                    pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
+                    check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                                  z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+                    dW3 = sum_slabs(pw, deferrable=True)
                 check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
                                               W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
                                               part.data_ptr(), st), "spacap_sa_dgrad_f32")

@@ -255,6 +255,45 @@ def test_pooled_layer_backward_without_z3_matches_the_stored_path(Cf, mlp, npoin
         assert torch.equal(ba, bb), na
 
 
+@pytest.mark.parametrize("Cf,mlp,npoint,nsample,n", [(1, [64, 64, 128], 512, 64, 6000), (128, [128, 128, 256], 300, 32, 2048),
+                                                     (256, [128, 128, 128], 65, 32, 1024)])
+def test_pooled_layer_weight_gradient_from_z2_matches_the_dense_kernel(Cf, mlp, npoint, nsample, n, monkeypatch):
+    """sa_mlp.POOL_WGRAD: the pooled layer's weight gradient from z2 alone (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel; sparse
+    term + Gram matrix) against the dense kernel that streams z3 and z2 (lib/pointnet2/pytorch_utils.py:11-36,
+    lib/pointnet2/pointnet2_modules.py:256-259; autograd backward).  Everything but dW3 is computed by the same kernels on the
+    same inputs: bit-identical; dW3 agrees at fp32 rounding level."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd import sa_mlp
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(5)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=0.4, nsample=nsample, mlp=[Cf] + mlp, use_xyz=True, normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    xyz = S.scene_batch(2, n, use_height=False, seed=4).to(DEV)[..., :3].contiguous()
+    feats = torch.randn(2, Cf, n, generator=torch.Generator().manual_seed(1)).to(DEV)
+    inds = pu.furthest_point_sample(xyz, npoint)
+    monkeypatch.setattr(sa_mlp, "POOL_WGRAD_MIN_ROWS", 0)
+    res, fg = [], []
+    for mod, flag in ((sa, True), (sb, False)):
+        monkeypatch.setattr(sa_mlp, "POOL_WGRAD", flag)
+        f = feats.clone().requires_grad_(Cf > 1)
+        _, out, _ = mod(xyz, f, inds)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        (out * w).sum().backward()
+        res.append(out)
+        fg.append(f.grad)
+    assert torch.equal(res[0], res[1])
+    last = [n_ for n_, _ in sa.named_parameters() if n_.endswith("conv.weight")][-1]
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+        if na == last:
+            assert not torch.equal(pa.grad, pb.grad), "the weight gradient did not come from the new kernel"
+            e = (pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-20)
+            assert e.item() < 2e-5, (na, e.item())
+        else:
+            assert torch.equal(pa.grad, pb.grad), na
+    if fg[0] is not None:
+        assert torch.equal(fg[0], fg[1])
+
+
 def test_unsupported_mlp_uses_the_per_operator_path():
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
     from spacap3d_amd import sa_mlp
