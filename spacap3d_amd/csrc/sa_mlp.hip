@@ -1535,11 +1535,12 @@ extern "C" int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, 
 extern "C" int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const float *coef3, const float *W3, int C3, int C2, double *sums,
                                       float *dW3, spacap_stream_t stream) {
   const char *what = "spacap_sa_l3bwd_dw_f32";
-  SPACAP_REQUIRE(partW && coef3 && W3 && sums && dW3 && nparts >= 1 && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
+  SPACAP_REQUIRE(partW && coef3 && W3 && sums && dW3 && nparts >= 1 && C3 >= 1 && C2 >= 4 && C2 % 4 == 0, "%s: bad arguments", what);
+  SPACAP_REQUIRE((reinterpret_cast<uintptr_t>(partW) & 15) == 0, "%s: partW must be 16-byte aligned", what);
   const long n = spacap_sa_l3bwd_part_floats(C2, C3);
   hipStream_t s = spacap::as_stream(stream);
   SPACAP_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "%s: C2=%d unsupported", what, C2);
-  hipLaunchKernelGGL(sa_l3_sum_kernel, dim3(nblocks(n, 16)), dim3(256), 0, s, partW, nparts, n, sums);
+  hipLaunchKernelGGL(sa_l3_sum_kernel, dim3(nblocks(n, 64)), dim3(256), 0, s, partW, nparts, n, sums);
   hipLaunchKernelGGL(sa_l3_dw_kernel, dim3(C3), dim3(1024), 0, s, sums, coef3, W3, C3, C2, dW3);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;

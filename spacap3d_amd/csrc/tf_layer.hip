@@ -117,7 +117,14 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
       const size_t ps = (size_t)P.R * D;
       f32x4 a = ld4(pp);
       int sidx = 1;
-      for (; sidx + 3 < P.nparts; sidx += 4) {   // four loads in flight, added in slice order
+      for (; sidx + 7 < P.nparts; sidx += 8) {   // eight loads in flight (one round trip for d_ff = 2048's 16 slices, both column
+        f32x4 t[8];                              // groups interleaved), added in slice order
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ld4(pp + (sidx + u) * ps);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += t[u];
+      }
+      for (; sidx + 3 < P.nparts; sidx += 4) {   // four loads in flight
         const f32x4 t0 = ld4(pp + sidx * ps), t1 = ld4(pp + (sidx + 1) * ps), t2 = ld4(pp + (sidx + 2) * ps),
                     t3 = ld4(pp + (sidx + 3) * ps);
         a += t0, a += t1, a += t2, a += t3;
@@ -205,7 +212,10 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
   // latency runs under the row epilogue (three barriers and a round of global loads) instead of after it.
   f32x4 x0[8], y0[8];   // FWD: first pair of 16-column tiles of W2
   f32x2 wv2[32];        // BWD: W2 [128][128], the wave's two interleaved tiles
-  const int nw2 = P.N2 >> 2, n00 = w * nw2;
+  // forward with N2 > 128: blockIdx.y owns N2 / gridDim.y of the second product's columns (the rows' first part is then formed
+  // by every one of those workgroups, stored by the first)
+  const int n2y = P.N2 / (int)gridDim.y, nw2 = n2y >> 2, n00 = (int)blockIdx.y * n2y + w * nw2;
+  const bool first_y = blockIdx.y == 0;
   const float *wp2 = BWD ? P.W2 + (size_t)(4 * lg) * D + 32 * w + 2 * l15 : P.W2 + (size_t)(n00 + l15) * D + 4 * lg;
   if (P.N2 != 0) {
     if (!BWD) {
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) xo[g][t] = r4[t];
       }
-      if (P.x_out && valid) st4(P.x_out + (size_t)row * D + cb[g], f32x4{xo[g][0], xo[g][1], xo[g][2], xo[g][3]});
+      if (P.x_out && valid && first_y) st4(P.x_out + (size_t)row * D + cb[g], f32x4{xo[g][0], xo[g][1], xo[g][2], xo[g][3]});
 #pragma unroll
       for (int t = 0; t < 4; ++t) s += xo[g][t];
     }
@@ -272,10 +282,10 @@ __global__ __launch_bounds__(256) void tf_rows_kernel(const TfRowsArgs P) {
       const f32x4 a4 = ld4(P.ln_a + cb[g]), b4 = ld4(P.ln_b + cb[g]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) t_out[g][t] = a4[t] * ((xo[g][t] - mu) * r) + b4[t];
-      if (P.n_out && valid)
+      if (P.n_out && valid && first_y)
         st4(P.n_out + (size_t)row * D + cb[g], f32x4{t_out[g][0], t_out[g][1], t_out[g][2], t_out[g][3]});
     }
-    if (P.stats && valid && w == 0 && lg == 0) {
+    if (P.stats && valid && w == 0 && lg == 0 && first_y) {
       P.stats[row * 2] = mu;
       P.stats[row * 2 + 1] = r;
     }
@@ -765,8 +775,12 @@ extern "C" int spacap_tf_rows_f32(const spacap_tf_rows_args *a, spacap_stream_t 
   const long tiles = (P.R + BM - 1) / BM;
   SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
   hipStream_t s = spacap::as_stream(stream);
+  // forward, N2 = 384 (the next attention's packed q|k|v) on FEW row tiles (the decoder's 8 x ~30 tokens = 16 tiles): its three
+  // 128-column blocks on three workgroups per row tile -- 17 -> 11 us per launch there; with the encoder's 128 row tiles the
+  // repeated first part costs what the shorter second part saves (measured 17.5 us both ways), so those stay one workgroup
+  const unsigned ny = (!bwd && P.N2 > 128 && tiles <= 64) ? (unsigned)(P.N2 / 128) : 1u;
   if (bwd) hipLaunchKernelGGL((tf_rows_kernel<true>), dim3((unsigned)tiles), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL((tf_rows_kernel<false>), dim3((unsigned)tiles), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((tf_rows_kernel<false>), dim3((unsigned)tiles, ny), dim3(256), 0, s, P);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

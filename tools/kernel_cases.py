@@ -229,6 +229,35 @@ def tf_ffn(R, dff, mode, dev):
                      "dhidden = (dy W2) * mask stored + partial sums of dhidden W1 per slice of d_ff, one launch (fp32 MFMA)")
 
 
+def tf_rows(R, dff, dev):
+    """The row-tile kernel between two attention calls (csrc/tf_layer.hip: tf_rows_kernel<FWD>) at its largest launch of a step:
+    the feed-forward block's second half of an encoder layer -- add the d_ff / 128 partial products of w_2, dropout, residual,
+    LayerNorm, then the NEXT layer's packed q|k|v projection (128 -> 384)."""
+    import ctypes
+    from spacap3d_amd._native import TfRowsArgs
+    nparts = dff // 128
+    part, res = _rand(nparts, R, 128, dev=dev), _rand(R, 128, dev=dev)
+    ln_a, ln_b, W2, b2 = 1 + 0.1 * _rand(128, dev=dev), 0.1 * _rand(128, dev=dev), 0.1 * _rand(384, 128, dev=dev), 0.1 * _rand(384, dev=dev)
+    x_out, n_out, stats = torch.empty(R, 128, device=dev), torch.empty(R, 128, device=dev), torch.empty(R, 2, device=dev)
+    out2 = torch.empty(R, 384, device=dev)
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    a = TfRowsArgs()
+    a.mode, a.R, a.k1, a.n2, a.nparts, a.lq, a.drop_p, a.eps, a.seed = 0, R, 0, 384, nparts, 0, 0.1, 1e-6, 11
+    a.seed_dev = seed_dev.data_ptr()
+    a.a1, a.res, a.x_out, a.ln_a, a.ln_b, a.n_out, a.stats = (part.data_ptr(), res.data_ptr(), x_out.data_ptr(), ln_a.data_ptr(),
+                                                               ln_b.data_ptr(), n_out.data_ptr(), stats.data_ptr())
+    a.w2, a.bias2, a.out2 = W2.data_ptr(), b2.data_ptr(), out2.data_ptr()
+
+    def run():
+        check(lib.spacap_tf_rows_f32(ctypes.byref(a), _st(dev)), "tf_rows")
+    byts = 4.0 * (nparts * R * 128 + R * 128 * 3 + R * 2 + R * 384 + 384 * 128)
+    return dict(name=f"tf_rows fwd R={R} (w_2 partials of d_ff={dff} -> residual -> LayerNorm -> q|k|v 128->384)", kernel="tf_rows_kernel",
+                run=run, flops=2.0 * R * 128 * 384, bytes=byts, keep=(part, res, ln_a, ln_b, W2, b2, x_out, n_out, stats, out2, seed_dev, a),
+                what=f"{R // 16} workgroups of 16 rows: {nparts} partial products added in order, dropout + residual + LayerNorm (two "
+                     "barriers), then 16 x 384 outputs per workgroup as fp32 MFMA; 52 such launches per step (12 us average): a chain "
+                     "of dependent phases on half the chip's CUs -- latency-bound, priced here against the HBM roof its bytes imply")
+
+
 def fps(B, N, m, dev):
     from spacap3d_amd import synthetic as S
     xyz = S.scene_batch(B, N, use_height=False, seed=1000).to(dev)
