@@ -461,6 +461,16 @@ int spacap_sa_rows_scatter_f32(const float *dz, const int32_t *idx, int B, int N
 int spacap_sa_rows_index_f32(const int32_t *idx, int B, int Np, long E, void *workspace, spacap_stream_t stream);
 int spacap_sa_rows_gather_f32(const float *dz, int B, int Np, long E, int C, const void *workspace, float *out,
                               spacap_stream_t stream);
+/* Gradient of the grouped relative coordinates (lib/pointnet2/pointnet2_utils.py:350-355 QueryAndGroup: grouped_xyz -= new_xyz, /= radius;
+   autograd backward) routed to both sources in one launch: drel f32 [B, N*S, 3] -> dxyz f32 [B, Np, 3] (sum over the rows
+   referencing each source point, ascending row order, from the index spacap_sa_rows_index_f32 left in workspace) and
+   dnew f32 [B, N, 3] = -sum over each group's S rows.  Either output may be NULL (workspace may be NULL without dxyz). */
+int spacap_sa_drel_sums_f32(const float *drel, int B, int Np, int N, int S, const void *workspace, float *dxyz, float *dnew,
+                            spacap_stream_t stream);
+/* First-layer weight gradient dW1 f32 [C1, 3+Cf] of a set-abstraction module with point features from its two sets of partial
+   results: pw1 f32 [n1][C1][4] (spacap_sa_l1_bwd_f32: relative coordinates) and pf f32 [nf][C1*Cf] (spacap_linear_wgrad_f32 of
+   the feature product); same values as spacap_sum_slabs_f32 on each followed by a concatenation. */
+int spacap_sa_dw1_assemble_f32(const float *pw1, int n1, const float *pf, int nf, int C1, int Cf, float *dW1, spacap_stream_t stream);
 
 /* ---- Linear layers of the Transformer: weight + bias gradient in one launch ------------------------------------
  * dW[ck,cp] = sum_r g[r,ck] x[r,cp], db[ck] = sum_r g[r,ck]  (backward of torch.nn.Linear as used by

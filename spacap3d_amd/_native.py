@@ -124,6 +124,8 @@ SIGNATURES = {
     "spacap_sa_rows_scatter_f32": (_i, [_p, _p, _i, _i, _l, _i, _p, _p, _p]),
     "spacap_sa_rows_index_f32": (_i, [_p, _i, _i, _l, _p, _p]),
     "spacap_sa_rows_gather_f32": (_i, [_p, _i, _i, _l, _i, _p, _p, _p]),
+    "spacap_sa_drel_sums_f32": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "spacap_sa_dw1_assemble_f32": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
     "spacap_relu_dropout_fwd_f32": (_i, [_p, _l, _f, _u64, _p, _p, _p]),
     "spacap_relu_dropout_bwd_f32": (_i, [_p, _p, _l, _f, _p, _p]),
     "spacap_dropout_add_fwd_f32": (_i, [_p, _p, _l, _f, _u64, _p, _p, _p]),

@@ -1067,6 +1067,68 @@ __global__ __launch_bounds__(256) void rows_gather_sum_kernel(const float *__res
   st4(out + (size_t)k * C + c4 * 4, a);
 }
 
+// Gradient of the relative coordinates (rel = (xyz[idx] - new_xyz) / r, drel [B * E][3], E = N S rows per scene) routed to
+// both of its sources in one launch, fixed summation orders (the autograd composition is a zero-fill + an int64 copy of idx +
+// an atomic scatter_add_ + a sum + a neg):
+//   threads 0 .. K-1 (K = B Np):   dxyz[k][:] = sum of drel[r][:] over the rows r that reference source point k, ascending r
+//   threads K .. K + B N - 1:      dnew[g][:] = - sum_s drel[g S + s][:]
+__global__ __launch_bounds__(256) void sa_drel_sums_kernel(const float *__restrict__ drel, const int *__restrict__ off,
+                                                           const int *__restrict__ order, long K, long G, int S,
+                                                           float *__restrict__ dxyz, float *__restrict__ dnew) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < K) {
+    if (!dxyz) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const int beg = off[i], end = off[i + 1];
+    int p = beg;
+    for (; p + 3 < end; p += 4) {   // (order[p] -> row is a dependent chain: four in flight, the sum keeps its order)
+      const float *r0 = drel + (size_t)order[p] * 3, *r1 = drel + (size_t)order[p + 1] * 3, *r2 = drel + (size_t)order[p + 2] * 3,
+                  *r3 = drel + (size_t)order[p + 3] * 3;
+      const float x0 = r0[0], y0 = r0[1], z0 = r0[2], x1 = r1[0], y1 = r1[1], z1 = r1[2];
+      const float x2 = r2[0], y2 = r2[1], z2 = r2[2], x3 = r3[0], y3 = r3[1], z3 = r3[2];
+      ax += x0, ay += y0, az += z0;
+      ax += x1, ay += y1, az += z1;
+      ax += x2, ay += y2, az += z2;
+      ax += x3, ay += y3, az += z3;
+    }
+    for (; p < end; ++p) {
+      const float *r = drel + (size_t)order[p] * 3;
+      ax += r[0], ay += r[1], az += r[2];
+    }
+    dxyz[i * 3] = ax, dxyz[i * 3 + 1] = ay, dxyz[i * 3 + 2] = az;
+  } else if (i < K + G && dnew) {
+    const long g = i - K;
+    const float *r = drel + (size_t)g * S * 3;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int sidx = 0; sidx < S; ++sidx) ax += r[sidx * 3], ay += r[sidx * 3 + 1], az += r[sidx * 3 + 2];
+    dnew[g * 3] = -ax, dnew[g * 3 + 1] = -ay, dnew[g * 3 + 2] = -az;
+  }
+}
+
+// First-layer weight gradient of a module with point features, assembled in one launch from the two sets of partial results:
+//   dW1[c][0..2]    = sum over the n1 slabs of pw1 [n1][C1][4]   (relative coordinates; column 3 = the inline feature, unused here)
+//   dW1[c][3 + j]   = sum over the nf slabs of pf  [nf][C1][Cf]  (the feature product over the source points)
+// with sum_slabs_kernel's grouping (four runs of slabs, combined as (s0 + s1) + (s2 + s3)): the same values as the two slab sums
+// and the concatenation it replaces.
+__global__ __launch_bounds__(256) void sa_dw1_assemble_kernel(const float *__restrict__ pw1, int n1, const float *__restrict__ pf, int nf,
+                                                              int C1, int Cf, float *__restrict__ out) {
+  __shared__ float s_g[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long e = (long)blockIdx.x * 64 + c, ne = (long)C1 * (3 + Cf);
+  float a = 0.f;
+  if (e < ne) {
+    const int ch = (int)(e / (3 + Cf)), j = (int)(e % (3 + Cf));
+    const float *src = j < 3 ? pw1 + (size_t)ch * 4 + j : pf + (size_t)ch * Cf + (j - 3);
+    const size_t stride = j < 3 ? (size_t)C1 * 4 : (size_t)C1 * Cf;
+    const int ns = j < 3 ? n1 : nf, per = (ns + 3) / 4, s0 = grp * per, s1 = min(ns, s0 + per);
+#pragma unroll 8
+    for (int k = s0; k < s1; ++k) a += src[(size_t)k * stride];
+  }
+  s_g[grp][c] = a;
+  __syncthreads();
+  if (grp == 0 && e < ne) out[e] = (s_g[0][c] + s_g[1][c]) + (s_g[2][c] + s_g[3][c]);
+}
+
 struct RowsLayout {
   size_t total, K, keys_in, keys_out, vals_in, vals_out, off, cub, cub_bytes, bytes;
   int bits;
@@ -1802,6 +1864,35 @@ extern "C" int spacap_sa_rows_gather_f32(const float *dz, int B, int Np, long E,
   const char *ws = reinterpret_cast<const char *>(workspace);
   hipLaunchKernelGGL(rows_gather_sum_kernel, dim3(nblocks((long)L.K * (C / 4), 256)), dim3(256), 0, spacap::as_stream(stream), dz,
                      reinterpret_cast<const int *>(ws + L.off), reinterpret_cast<const int *>(ws + L.vals_out), (long)L.K, C, out);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// drel f32 [B, N S, 3] -> dxyz f32 [B, Np, 3] (sum over the rows that reference each source point, ascending, from the index
+// spacap_sa_rows_index_f32 left in `workspace`; may be NULL) and dnew f32 [B, N, 3] = - sum over each group's S rows (may be NULL)
+extern "C" int spacap_sa_drel_sums_f32(const float *drel, int B, int Np, int N, int S, const void *workspace, float *dxyz, float *dnew,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_sa_drel_sums_f32";
+  RowsLayout L;
+  SPACAP_REQUIRE(drel && (dxyz || dnew) && N >= 1 && S >= 1 && rows_layout(B, Np, (long)N * S, L) && (!dxyz || workspace),
+                 "%s: bad arguments", what);
+  const char *ws = reinterpret_cast<const char *>(workspace);
+  const long K = (long)L.K, G = (long)B * N;
+  hipLaunchKernelGGL(sa_drel_sums_kernel, dim3(nblocks(K + G, 256)), dim3(256), 0, spacap::as_stream(stream), drel,
+                     ws ? reinterpret_cast<const int *>(ws + L.off) : nullptr, ws ? reinterpret_cast<const int *>(ws + L.vals_out) : nullptr,
+                     K, G, S, dxyz, dnew);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// dW1 f32 [C1, 3 + Cf] from pw1 f32 [n1][C1][4] (spacap_sa_l1_bwd_f32) and pf f32 [nf][C1 * Cf] (spacap_linear_wgrad_f32 of the
+// feature product): columns 0..2 and 3.. in one launch, the values of spacap_sum_slabs_f32 on each + a concatenation
+extern "C" int spacap_sa_dw1_assemble_f32(const float *pw1, int n1, const float *pf, int nf, int C1, int Cf, float *dW1,
+                                          spacap_stream_t stream) {
+  const char *what = "spacap_sa_dw1_assemble_f32";
+  SPACAP_REQUIRE(pw1 && pf && dW1 && n1 >= 1 && nf >= 1 && C1 >= 1 && Cf >= 1, "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_dw1_assemble_kernel, dim3(nblocks((long)C1 * (3 + Cf), 64)), dim3(256), 0, spacap::as_stream(stream), pw1, n1, pf,
+                     nf, C1, Cf, dW1);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -295,13 +295,14 @@ class _SAMLP(Function):
                                            new_xyz.data_ptr(), idx.data_ptr(), W1.data_ptr(), W1.shape[1], ctx.rdiv, B, Np,
                                            N, S, C1, pw1.data_ptr(), _ptr(drel), int(ctx.has_Y), st),
                   "spacap_sa_l1_bwd_f32")
-            dWx = sum_slabs(pw1)                      # (C1, 4): rel x, y, z, inline feature
-            dY = None
+            dY = ws = None
+            nbytes = int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S))
+            ri = ctx.rows_index
+            if ri is not None and not (ri.numel() == nbytes and ri.device == dev):
+                ri = None
             if ctx.has_Y:
                 dY = torch.empty(B, Np, C1, **f32)
-                nbytes = int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, N * S))
-                ri = ctx.rows_index
-                if ri is not None and ri.numel() == nbytes and ri.device == dev:
+                if ri is not None:
                     # the inverted index came with the geometry pyramid: only the gather is left
                     check(lib.spacap_sa_rows_gather_f32(dy1.data_ptr(), B, Np, N * S, C1, ri.data_ptr(), dY.data_ptr(), st),
                           "spacap_sa_rows_gather_f32")
@@ -318,17 +319,33 @@ class _SAMLP(Function):
                 if ctx.needs_input_grad[4]:
                     from .linear import dense_product
                     dpm = dense_product(g2, W1, False, col0=3).view_as(pm)    # dY W1[:, 3:]
-                dW1 = torch.cat([dWx[:, :3], _feature_weight_gradient(g2, x2)], 1)
+                nslab = int(lib.spacap_linear_wgrad_slabs(B * Np, C1, Cf))
+                if nslab:
+                    # [rel columns | feature columns] from the two sets of partial results in one launch (the values of the two
+                    # slab sums + the concatenation)
+                    pf = torch.empty(nslab, C1 * Cf, **f32)
+                    check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.contiguous().data_ptr(), B * Np, C1, Cf, 0, pf.data_ptr(), st),
+                          "spacap_linear_wgrad_f32")
+                    dW1 = torch.empty(C1, 3 + Cf, **f32)
+                    check(lib.spacap_sa_dw1_assemble_f32(pw1.data_ptr(), nparts, pf.data_ptr(), nslab, C1, Cf, dW1.data_ptr(), st),
+                          "spacap_sa_dw1_assemble_f32")
+                else:
+                    dW1 = torch.cat([sum_slabs(pw1)[:, :3], _feature_weight_gradient(g2, x2)], 1)
             else:
-                dW1 = dWx[:, :W1.shape[1]].contiguous()
+                dW1 = sum_slabs(pw1)[:, :W1.shape[1]].contiguous()    # (C1, 4): rel x, y, z, inline feature
             dxyz = dnew = None
             if drel is not None:
-                d3 = drel.view(B, N * S, 3)
-                if ctx.needs_input_grad[0]:
-                    dxyz = torch.zeros(B, Np, 3, **f32)
-                    dxyz.scatter_add_(1, idx.view(B, N * S, 1).expand(-1, -1, 3).long(), d3)
-                if ctx.needs_input_grad[1]:
-                    dnew = -drel.view(B, N, S, 3).sum(2)
+                # gradient of rel = (xyz[idx] - new_xyz) / r to both sources, one launch, fixed summation orders
+                want_x, want_n = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+                if want_x and ri is None and ws is None:
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    check(lib.spacap_sa_rows_index_f32(idx.data_ptr(), B, Np, N * S, ws.data_ptr(), st), "spacap_sa_rows_index_f32")
+                index = ri if ri is not None else ws
+                dxyz = torch.empty(B, Np, 3, **f32) if want_x else None
+                dnew = torch.empty(B, N, 3, **f32) if want_n else None
+                if want_x or want_n:
+                    check(lib.spacap_sa_drel_sums_f32(drel.data_ptr(), B, Np, N, S, _ptr(index) if want_x else None, _ptr(dxyz), _ptr(dnew),
+                                                      st), "spacap_sa_drel_sums_f32")
         return (dxyz, dnew, None, None, dpm, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
 
 

@@ -189,6 +189,54 @@ def test_rows_scatter_sums_in_ascending_row_order(B, Np, E):
     assert np.array_equal(out.cpu().numpy().reshape(B * Np, C), want)
 
 
+@pytest.mark.parametrize("B,Np,N,Sn", [(8, 1024, 256, 16), (2, 300, 37, 32), (1, 5000, 64, 64), (3, 40, 40, 16)])
+def test_relative_coordinate_gradient_in_one_launch(B, Np, N, Sn):
+    """spacap_sa_drel_sums_f32: the gradient of rel = (xyz[idx] - new_xyz) / r (lib/pointnet2/pointnet2_utils.py:350-355) to the
+    source points (rows that reference a point, ascending: bit-identical to numpy's sequential add.at) and to the centres
+    (minus the sum over each group's rows, in row order), in one launch; either output alone as well."""
+    from spacap3d_amd._native import check, lib
+    g = torch.Generator().manual_seed(B + Np + N)
+    E = N * Sn
+    idx = torch.randint(0, Np, (B, E), generator=g, dtype=torch.int32)
+    run = torch.randint(0, Np, (B, (E + 15) // 16), generator=g, dtype=torch.int32).repeat_interleave(16, 1)[:, :E]
+    idx = torch.where(torch.rand(B, E, generator=g) < 0.5, run, idx)
+    drel = torch.randn(B * E, 3, generator=g)
+    want_x = np.zeros((B * Np, 3), np.float32)
+    np.add.at(want_x, (idx.long() + torch.arange(B).view(B, 1) * Np).reshape(-1).numpy(), drel.numpy())
+    want_n = np.zeros((B * N, 3), np.float32)
+    d4 = drel.numpy().reshape(B * N, Sn, 3)
+    for s_ in range(Sn):
+        want_n += d4[:, s_]
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(int(lib.spacap_sa_rows_scatter_workspace_bytes(B, Np, E)), dtype=torch.uint8, device=DEV)
+    idx_d, drel_d = idx.to(DEV), drel.to(DEV)
+    check(lib.spacap_sa_rows_index_f32(idx_d.data_ptr(), B, Np, E, ws.data_ptr(), st), "rows_index")
+    dxyz, dnew = torch.full((B, Np, 3), float("nan"), device=DEV), torch.full((B, N, 3), float("nan"), device=DEV)
+    check(lib.spacap_sa_drel_sums_f32(drel_d.data_ptr(), B, Np, N, Sn, ws.data_ptr(), dxyz.data_ptr(), dnew.data_ptr(), st), "drel_sums")
+    assert np.array_equal(dxyz.cpu().numpy().reshape(-1, 3), want_x)
+    assert np.array_equal(dnew.cpu().numpy().reshape(-1, 3), -want_n)
+    only_n = torch.full((B, N, 3), float("nan"), device=DEV)
+    check(lib.spacap_sa_drel_sums_f32(drel_d.data_ptr(), B, Np, N, Sn, None, None, only_n.data_ptr(), st), "drel_sums")
+    only_x = torch.full((B, Np, 3), float("nan"), device=DEV)
+    check(lib.spacap_sa_drel_sums_f32(drel_d.data_ptr(), B, Np, N, Sn, ws.data_ptr(), only_x.data_ptr(), None, st), "drel_sums")
+    assert torch.equal(only_n, dnew) and torch.equal(only_x, dxyz)
+
+
+@pytest.mark.parametrize("C1,Cf,n1,nf", [(128, 256, 1024, 64), (128, 128, 1024, 7), (64, 128, 3, 1), (128, 256, 1, 130)])
+def test_first_layer_weight_gradient_assembled_in_one_launch(C1, Cf, n1, nf):
+    """spacap_sa_dw1_assemble_f32 = spacap_sum_slabs_f32 on the coordinate partials and on the feature-product partials + the
+    concatenation [rel columns | feature columns], bit for bit."""
+    from spacap3d_amd._native import check, lib, sum_slabs
+    g = torch.Generator().manual_seed(C1 + Cf + n1)
+    pw1 = torch.randn(n1, C1, 4, generator=g).to(DEV)
+    pf = torch.randn(nf, C1 * Cf, generator=g).to(DEV)
+    out = torch.full((C1, 3 + Cf), float("nan"), device=DEV)
+    check(lib.spacap_sa_dw1_assemble_f32(pw1.data_ptr(), n1, pf.data_ptr(), nf, C1, Cf, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "dw1_assemble")
+    want = torch.cat([sum_slabs(pw1)[:, :3], sum_slabs(pf).view(C1, Cf)], 1)
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("C,npoint,nsample,n", [(1, 512, 64, 6000), (0, 200, 32, 3000), (1, 77, 16, 1000)])
 def test_first_layer_rebuilt_instead_of_stored(C, npoint, nsample, n, monkeypatch):
     """SA1-shaped modules (3 relative coordinates + at most one inline feature, 64 -> 64 -> 128): with sa_mlp.RECOMPUTE_Z1 the
