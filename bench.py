@@ -544,6 +544,9 @@ def main():
         del c_dg
         c_ffn = KC.tf_ffn(B * 256, 2048, 0, dev)
         roof_ffn = KC.roofline_entry(c_ffn, KC.time_case(c_ffn), pmc)
+        c_wp = KC.sa_wgrad_pool(R1, 64, 128, 64, dev, "SA1 layer 3")
+        roof_wp = KC.roofline_entry(c_wp, KC.time_case(c_wp), pmc)
+        del c_wp
         del c_ffn
         c_fps = KC.fps(B, N, m, dev)
         t_fps_us = KC.time_case(c_fps, iters=5, warm=1)
@@ -582,7 +585,7 @@ def main():
                        "sa_forward_gemm": ("fp32 MFMA (v_mfma_f32_16x16x4_f32)" if os.environ.get("SPACAP_SA_F32MFMA", "0") not in ("", "0") else
                                            "split-bf16 x3 streaming kernel: 6 bf16 MFMA products per fp32 product, fp32 accumulate"),
                        "params": n_params, "allreduce_bytes": allreduce_bytes},
-            "roofline": roof, "roofline_more": [roof_sa, roof_relb, roof_relf, roof_dg, roof_hbm, roof_ffn, roof_fps],
+            "roofline": roof, "roofline_more": [roof_sa, roof_relb, roof_relf, roof_dg, roof_hbm, roof_ffn, roof_wp, roof_fps],
             "step": {"algorithmic_flops": fl, "achieved_TFLOPs": fl / (ms_per_step * 1e-3) * 1e-12,
                      "frac_of_fp32_mfma_peak": fl / (ms_per_step * 1e-3) * 1e-12 / KC.PEAK_MFMA_F32_TFLOPS},
             "ops": ops, "final_loss": loss_val,

@@ -131,6 +131,26 @@ def sa_l3bwd(R, c2, c3, S, dev, label):
                      f"z2, no z3 (the stored-z3 kernels read 4 R (2 c3 + 2 c2) + write 4 R c2 bytes)")
 
 
+def sa_wgrad_pool(R, c2, c3, S, dev, label):
+    """The pooled layer's weight gradient from z2 alone (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel): sparse term + Gram matrix."""
+    G = R // S
+    dym, arg = _rand(G, c3, dev=dev), torch.randint(0, S, (G, c3), dtype=torch.uint8, device=dev)
+    z2, coef, st2 = _rand(R, c2, dev=dev), _stats(c3, dev), _stats(c2, dev)
+    npw, nfl = int(lib.spacap_sa_wgrad_pool_parts(R, c2, c3, S)), int(lib.spacap_sa_l3bwd_part_floats(c2, c3))
+    pw = torch.empty(npw, nfl, dtype=torch.float32, device=dev)
+
+    def run():
+        check(lib.spacap_sa_wgrad_pool_f32(dym.data_ptr(), arg.data_ptr(), S, coef.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, c3, c2,
+                                           pw.data_ptr(), _st(dev)), "sa_wgrad_pool")
+    # matrix work actually issued: the Gram matrix's upper class pairs (3/4 at C2 = 64, 5/8 at C2 = 128) + the sparse FMAs
+    frac = 0.75 if c2 == 64 else 0.625
+    return dict(name=f"sa_wgrad_pool {c2}->{c3} R={R} ({label})", kernel="sa_wgrad_pool_kernel", run=run,
+                flops=2.0 * R * c2 * c2 * frac + 2.0 * G * c3 * c2, bytes=4.0 * (R * c2 + G * c3 * 1.25 + npw * nfl),
+                keep=(dym, arg, z2, coef, st2, pw),
+                what=f"{label}: dW3 partials = (g d)^T a2 (one row per group and channel) + Gram a2^T a2 + colsum a2 from ONE pass "
+                     f"over z2 ({c2} floats per row; the dense kernel streams z3 and z2 = {c2 + c3} floats per row), {npw} workgroups")
+
+
 def sa_mid_fwd_pool(R, cin, cout, S, dev, label, store):
     """The pooled last layer's forward with / without storing its output (the z3-free backward needs none of it)."""
     zin, st, W, g3 = _rand(R, cin, dev=dev), _stats(cin, dev), _rand(cout, cin, dev=dev) * 0.1, torch.ones(cout, dtype=torch.float32, device=dev)
@@ -287,6 +307,8 @@ def cases(dev, B=8):
         lambda: sa_wgrad(R2, 128, 128, False, 32, dev, "SA2 layer 2"),
         lambda: sa_wgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
         lambda: sa_wgrad(R1, 64, 64, False, 64, dev, "SA1 layer 2"),
+        lambda: sa_wgrad_pool(R1, 64, 128, 64, dev, "SA1 layer 3"),
+        lambda: sa_wgrad_pool(R2, 128, 256, 32, dev, "SA2 layer 3"),
         lambda: sa_l3bwd(R1, 64, 128, 64, dev, "SA1 layer 3"),
         lambda: sa_l3bwd(R2, 128, 256, 32, dev, "SA2 layer 3"),
         lambda: sa_mid_fwd_pool(R1, 64, 128, 64, dev, "SA1 layer 3", True),
@@ -296,6 +318,7 @@ def cases(dev, B=8):
         lambda: mha_fwd(B, 8, 256, 16, dev, True),
         lambda: tf_ffn(B * 256, 2048, 0, dev),
         lambda: tf_ffn(B * 256, 2048, 1, dev),
+        lambda: tf_rows(B * 256, 2048, dev),
         lambda: fps(B, 40000, 2048, dev),
     ]
 

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 csv.field_size_limit(1 << 30)
-KEEP = ("sa_mid_fwd", "sa_dgrad", "sa_wgrad", "mha_", "fps_", "rel_tail", "rel_fused", "relation_", "sa_l1", "sa_l3", "sa_pool", "tf_ffn")
+KEEP = ("sa_mid_fwd", "sa_dgrad", "sa_wgrad", "mha_", "fps_", "rel_tail", "rel_fused", "relation_", "sa_l1", "sa_l3", "sa_pool", "tf_ffn", "tf_rows")
 
 
 def main():
