@@ -400,7 +400,7 @@ int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const float *coef3, c
                            float *dW3, spacap_stream_t stream);
 /* Weight gradient of a POOLED last layer from z2 alone (same reference lines as above; replaces spacap_sa_wgrad_f32 with
    arg != NULL, which streams z3 and z2): partial sums of (g d)^T a2, a2^T a2 and colsum(a2) per workgroup; spacap_sa_l3bwd_dw_f32
-   combines them into dW3.  _supported: (C2, C3, S) in {(64,128,64), (128,128,32), (128,256,32)}.  arg 4-byte, z2 16-byte aligned.
+   combines them into dW3.  _supported: (C2, C3, S) in {(64,128,64), (128,128,32), (128,256,32)}.  arg 4-byte, z2 and dym 16-byte aligned.
    partW f32 [_parts][spacap_sa_l3bwd_part_floats(C2, C3)]. */
 int spacap_sa_wgrad_pool_supported(int C2, int C3, int S);
 int spacap_sa_wgrad_pool_parts(long R, int C2, int C3, int S);

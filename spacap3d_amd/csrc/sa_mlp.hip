@@ -1631,7 +1631,8 @@ extern "C" int spacap_sa_wgrad_pool_f32(const float *dym, const uint8_t *arg, in
   const char *what = "spacap_sa_wgrad_pool_f32";
   SPACAP_REQUIRE(dym && arg && coef3 && z2 && st2 && partW && R >= 1, "%s: bad arguments", what);
   SPACAP_REQUIRE(wgrad_pool_shape(C2, C3, S) && R % S == 0, "%s: (C2=%d, C3=%d, S=%d) unsupported", what, C2, C3, S);
-  SPACAP_REQUIRE((reinterpret_cast<uintptr_t>(arg) & 3) == 0 && (reinterpret_cast<uintptr_t>(z2) & 15) == 0, "%s: unaligned pointer", what);
+  SPACAP_REQUIRE((reinterpret_cast<uintptr_t>(arg) & 3) == 0 && ((reinterpret_cast<uintptr_t>(z2) | reinterpret_cast<uintptr_t>(dym)) & 15) == 0,
+                 "%s: unaligned pointer (arg: 4 bytes, z2 / dym: 16 bytes)", what);
   const WPArgs a{dym, arg, coef3, z2, st2, R, partW};
   const int grid = wgrad_pool_grid(R, C2, S);
   hipStream_t s = spacap::as_stream(stream);
