@@ -435,6 +435,15 @@ int spacap_sa_l1_dw_f32(const float *part_l1, int nparts, const float *coef, int
 int spacap_sa_l1_stats_f32(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, const float *W1,
                            int ldw, float rdiv, int B, int Np, int N, int S, int C1, float *rel4, double *part,
                            spacap_stream_t stream);
+/* The same pass in closed form: z1 is linear in the row's four inputs (relative x, y, z, inline feature), so the first layer's
+   batch statistics follow from the first and second moments of those inputs: mom f64 [spacap_sa_nparts()][16] (4 sums, 10
+   products, 2 pads per workgroup) next to rel4; _finalize turns them into stats [C1,4] (mean, 1/std, gamma/std, beta) and
+   updates the running statistics (either pointer NULL: not tracked), as spacap_sa_bn_finalize_f32 does from (sum, sum of squares). */
+int spacap_sa_l1_moments_f32(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, float rdiv, int B, int Np,
+                             int N, int S, float *rel4, double *mom, spacap_stream_t stream);
+int spacap_sa_l1_moments_finalize_f32(const double *mom, const float *W1, int ldw, int has_feat, int C1, long count, float eps,
+                                      float momentum, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                      float *stats, spacap_stream_t stream);
 int spacap_sa_mid_fwd_l1in_f32(const float *rel4, const float *W1, int ldw, int has_feat, const float *st_in, const float *W,
                                long R, float *zout, double *part, spacap_stream_t stream);
 int spacap_sa_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *rel4, const float *W1, int ldw,

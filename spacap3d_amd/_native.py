@@ -73,6 +73,8 @@ SIGNATURES = {
     "spacap_conv1x1_cm_supported": (_i, [_i, _i, _l]),
     "spacap_conv1x1_cm_f32": (_i, [_i, _p, _p, _p, _i, _i, _i, _l, _p, _p]),
     "spacap_sa_l1_stats_f32": (_i, [_p, _p, _p, _p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_l1_moments_f32": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_l1_moments_finalize_f32": (_i, [_p, _p, _i, _i, _i, _l, _f, _f, _p, _p, _p, _p, _p, _p]),
     "spacap_sa_mid_fwd_l1in_f32": (_i, [_p, _p, _i, _i, _p, _p, _l, _p, _p, _p]),
     "spacap_sa_wgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p]),
     "spacap_sa_dgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),

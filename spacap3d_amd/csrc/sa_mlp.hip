@@ -146,6 +146,102 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
   }
 }
 
+// ---- first layer without point features (SA1): BatchNorm statistics in closed form -------------------------------------------
+// z1[r][c] = W1[c] . in[r] is LINEAR in the row's four inputs in = (rel x, rel y, rel z, inline feature), so the layer's batch
+// statistics need only the first and second moments of `in` over all rows:
+//     sum_r z1[r][c] = W1[c] . S,   sum_r z1[r][c]^2 = W1[c]^T Mom W1[c],   S = sum_r in[r] (4),  Mom = sum_r in[r] in[r]^T (10 distinct)
+// 14 sums per row instead of 2 x 64 -- and one THREAD per row instead of 16 (the 64-channel form repeated the row's dependent
+// chain idx -> point -> coordinates and its three divisions in the 16 threads that shared a row: 87 us at SA1).  The pass still
+// leaves rel4 [R][4], from which every later pass rebuilds z1.  Reference: lib/pointnet2/pointnet2_utils.py:350-355 (grouping),
+// lib/pointnet2/pytorch_utils.py:11-36 (Conv2d -> BatchNorm2d: statistics over all rows).
+// part [gridDim.x][16] doubles: S0..S3 | M00 M01 M02 M03 M11 M12 M13 M22 M23 M33 | 0 0
+__global__ __launch_bounds__(256) void sa_l1_moments_kernel(const float *__restrict__ feat, const float *__restrict__ xyz,
+                                                            const float *__restrict__ new_xyz, const int32_t *__restrict__ idx,
+                                                            float rdiv, int Np, int N, int S, long R, float *__restrict__ rel4,
+                                                            double *__restrict__ part) {
+  __shared__ float s_m[14][256 + 1];
+  const int tid = threadIdx.x;
+  const long NS = (long)N * S, G = (long)gridDim.x * 256;
+  float a[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) a[i] = 0.f;
+  auto row = [&](long r, int p) {
+    const long b = r / NS, g = r / S;
+    const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)g * 3;
+    const f32x4 in = {(q[0] - c[0]) / rdiv, (q[1] - c[1]) / rdiv, (q[2] - c[2]) / rdiv, feat ? feat[(size_t)b * Np + p] : 0.f};
+    st4(rel4 + (size_t)r * 4, in);
+    return in;
+  };
+  auto add = [&](f32x4 in) {
+    a[0] += in[0], a[1] += in[1], a[2] += in[2], a[3] += in[3];
+    a[4] += in[0] * in[0], a[5] += in[0] * in[1], a[6] += in[0] * in[2], a[7] += in[0] * in[3];
+    a[8] += in[1] * in[1], a[9] += in[1] * in[2], a[10] += in[1] * in[3];
+    a[11] += in[2] * in[2], a[12] += in[2] * in[3], a[13] += in[3] * in[3];
+  };
+  constexpr int UR = 4;   // four rows' chains (idx -> point -> coordinates) in flight per thread
+  long r = (long)blockIdx.x * 256 + tid;
+  for (; r + (UR - 1) * G < R; r += UR * G) {
+    int p[UR];
+#pragma unroll
+    for (int k = 0; k < UR; ++k) p[k] = idx[r + k * G];
+    f32x4 in[UR];
+#pragma unroll
+    for (int k = 0; k < UR; ++k) in[k] = row(r + k * G, p[k]);
+#pragma unroll
+    for (int k = 0; k < UR; ++k) add(in[k]);
+  }
+  for (; r < R; r += G) add(row(r, idx[r]));
+#pragma unroll
+  for (int i = 0; i < 14; ++i) s_m[i][tid] = a[i];
+  __syncthreads();
+  if (tid < 16) {
+    double v = 0.0;
+    if (tid < 14)
+      for (int t = 0; t < 256; ++t) v += (double)s_m[tid][t];
+    part[(size_t)blockIdx.x * 16 + tid] = v;
+  }
+}
+
+// moments [nparts][16] -> stats [C1][4] of the first layer (mean, 1 / std, gamma / std, beta) + running statistics (torch semantics)
+__global__ __launch_bounds__(1024) void sa_l1_moments_finalize_kernel(const double *__restrict__ part, int nparts, const float *__restrict__ W1,
+                                                                     int ldw, int has_feat, int C1, double M, float eps, float momentum,
+                                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                     float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                     float *__restrict__ stats) {
+  __shared__ double s_mom[16];
+  const int tid = threadIdx.x, m = tid >> 6, lane = tid & 63;
+  if (m < 14) {   // wave m adds moment m over the partial rows: lane l takes rows l, l + 64, .. in order, then a fixed tree
+    double v = 0.0;
+    for (int p = lane; p < nparts; p += 64) v += part[(size_t)p * 16 + m];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_mom[m] = v;
+  }
+  __syncthreads();
+  if (tid < C1) {
+    const float *wr = W1 + (size_t)tid * ldw;
+    const double w[4] = {wr[0], wr[1], wr[2], has_feat ? wr[3] : 0.0};
+    const double *Sm = s_mom, *Q = s_mom + 4;   // Q: 00 01 02 03 11 12 13 22 23 33
+    const double sm = w[0] * Sm[0] + w[1] * Sm[1] + w[2] * Sm[2] + w[3] * Sm[3];
+    const double q = w[0] * w[0] * Q[0] + w[1] * w[1] * Q[4] + w[2] * w[2] * Q[7] + w[3] * w[3] * Q[9] +
+                     2.0 * (w[0] * w[1] * Q[1] + w[0] * w[2] * Q[2] + w[0] * w[3] * Q[3] + w[1] * w[2] * Q[5] + w[1] * w[3] * Q[6] +
+                            w[2] * w[3] * Q[8]);
+    const double mean = sm / M;
+    double var = q / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    stats[tid * 4 + 0] = (float)mean;
+    stats[tid * 4 + 1] = istd;
+    stats[tid * 4 + 2] = gamma[tid] * istd;
+    stats[tid * 4 + 3] = beta[tid];
+    if (running_mean) {
+      const double unbiased = M > 1.0 ? var * M / (M - 1.0) : var;
+      running_mean[tid] = (float)((1.0 - momentum) * running_mean[tid] + momentum * mean);
+      running_var[tid] = (float)((1.0 - momentum) * running_var[tid] + momentum * unbiased);
+    }
+  }
+}
+
 // ---- statistics finalisation --------------------------------------------------------------------------------
 // part [NPART][2][C] (sum, sum of squares) -> stats [C][4]; optional running-statistics update (torch semantics)
 __global__ __launch_bounds__(1024) void sa_bn_finalize_kernel(const double *__restrict__ part, int nparts, int C,
@@ -1280,6 +1376,31 @@ extern "C" int spacap_sa_l1_stats_f32(const float *feat, const float *xyz, const
   const long R = (long)B * N * S;
   hipLaunchKernelGGL((sa_l1_fwd_kernel<64>), dim3(NPART), dim3(256), 0, spacap::as_stream(stream), (const float *)nullptr, feat, xyz,
                      new_xyz, idx, W1, ldw, rdiv, Np, N, S, R, (float *)nullptr, part, rel4);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// The same pass in closed form (sa_l1_moments_kernel): rel4 f32 [B*N*S, 4] and the moments of the rows' four inputs,
+// mom f64 [spacap_sa_nparts()][16]; spacap_sa_l1_moments_finalize_f32 turns them into the first layer's statistics.
+extern "C" int spacap_sa_l1_moments_f32(const float *feat, const float *xyz, const float *new_xyz, const int32_t *idx, float rdiv, int B,
+                                        int Np, int N, int S, float *rel4, double *mom, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_moments_f32";
+  SPACAP_REQUIRE(B >= 1 && Np >= 1 && N >= 1 && S >= 1 && S <= 255, "%s: bad sizes", what);
+  SPACAP_REQUIRE(xyz && new_xyz && idx && rel4 && mom && rdiv > 0.f && (reinterpret_cast<uintptr_t>(rel4) & 15) == 0, "%s: bad arguments", what);
+  const long R = (long)B * N * S;
+  hipLaunchKernelGGL(sa_l1_moments_kernel, dim3(NPART), dim3(256), 0, spacap::as_stream(stream), feat, xyz, new_xyz, idx, rdiv, Np, N, S, R,
+                     rel4, mom);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+extern "C" int spacap_sa_l1_moments_finalize_f32(const double *mom, const float *W1, int ldw, int has_feat, int C1, long count, float eps,
+                                                 float momentum, const float *gamma, const float *beta, float *running_mean,
+                                                 float *running_var, float *stats, spacap_stream_t stream) {
+  const char *what = "spacap_sa_l1_moments_finalize_f32";
+  SPACAP_REQUIRE(mom && W1 && gamma && beta && stats && C1 >= 1 && C1 <= 1024 && count >= 1 && ldw >= (has_feat ? 4 : 3), "%s: bad arguments", what);
+  hipLaunchKernelGGL(sa_l1_moments_finalize_kernel, dim3(1), dim3(1024), 0, spacap::as_stream(stream), mom, NPART, W1, ldw, has_feat, C1,
+                     (double)count, eps, momentum, gamma, beta, running_mean, running_var, stats);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -17,6 +17,10 @@ from ._native import check, lib, sum_slabs
 
 # SA1-shaped modules (no point features, 64 -> 64 -> ...): do not store the first layer's pre-activation (see _SAMLP.forward)
 RECOMPUTE_Z1 = True
+# ... and take that layer's BatchNorm statistics from the first and second moments of the rows' four inputs (z1 is linear in
+# them): 14 sums per row, one thread per row, instead of 2 x 64 sums with 16 threads per row (csrc/sa_mlp.hip:
+# sa_l1_moments_kernel; 87 -> ~20 us at SA1).  The statistics differ from the summed-z1 form by rounding only (~1e-7 relative).
+L1_MOMENTS = os.environ.get("SPACAP_SA_L1_MOMENTS", "1") not in ("", "0")
 # pooled last layer: do not store its pre-activation z3; its backward is then one pass over z2 (see _SAMLP.backward,
 # csrc/sa_l3bwd.inc).  Correct (float64 gate, A/B leg of tests/test_sa_mlp_gpu.py) and 0.8 - 1.1 GB of HBM traffic lighter per
 # module, but SLOWER than the stored-z3 kernels as measured in round 4 (SA1: 1 010 vs 499 us, tools/lab/l3bwd_bench.py): the
@@ -136,11 +140,26 @@ class _SAMLP(Function):
                                                     _ptr(bn.running_var if track else None), stats[k].data_ptr(), st),
                       "spacap_sa_bn_finalize_f32")
 
-            if recompute:
+            if recompute and L1_MOMENTS:
+                mom = torch.empty(nparts * 16, dtype=torch.float64, device=dev)
+                check(lib.spacap_sa_l1_moments_f32(_ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), float(rdiv), B, Np, N, S,
+                                                   z1.data_ptr(), mom.data_ptr(), st), "spacap_sa_l1_moments_f32")
+                bn0 = bns[0]
+                track = bn0.track_running_stats and bn0.running_mean is not None
+                if track:
+                    from .fused_bn import bump_counter
+                    bump_counter(bn0)
+                check(lib.spacap_sa_l1_moments_finalize_f32(mom.data_ptr(), W1c.data_ptr(), W1c.shape[1], has_feat, C1, R, float(bn0.eps),
+                                                            0.0 if bn0.momentum is None else float(bn0.momentum), g1.data_ptr(),
+                                                            b1.data_ptr(), _ptr(bn0.running_mean if track else None),
+                                                            _ptr(bn0.running_var if track else None), stats[0].data_ptr(), st),
+                      "spacap_sa_l1_moments_finalize_f32")
+            elif recompute:
                 check(lib.spacap_sa_l1_stats_f32(_ptr(feat), xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), W1c.data_ptr(),
                                                  W1c.shape[1], float(rdiv), B, Np, N, S, C1, z1.data_ptr(), part.data_ptr(), st),
                       "spacap_sa_l1_stats_f32")
                 finalize(0, C1, g1, b1)
+            if recompute:
                 check(lib.spacap_sa_mid_fwd_l1in_f32(z1.data_ptr(), W1c.data_ptr(), W1c.shape[1], has_feat, stats[0].data_ptr(),
                                                      W2c.data_ptr(), R, z2.data_ptr(), part.data_ptr(), st),
                       "spacap_sa_mid_fwd_l1in_f32")

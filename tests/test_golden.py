@@ -121,12 +121,18 @@ def test_train_step_matches_reference(kind):
                 # discrete step: the vote-aggregation FPS runs on network outputs (vote_xyz), and a 3e-6 relative
                 # weight perturbation on the CPU leg alone already changes which votes become proposals (aggregated
                 # features move by 100 % of their scale).  With the sampled indices identical -- asserted above --
-                # the gradients agree to fp32 summation-order noise amplified by the BatchNorm backward's
-                # cancellations; measured on MI355X in round 4 (tools/lab/golden_err.py, profiles/r04_golden_err.txt):
-                # linf <= 1.7e-2, l2 <= 2.84e-3 (relation_proposal.0.weight); the bars are 1.5 x that.
+                # the gradients agree to fp32 rounding noise amplified by the gates downstream (ReLU, the max-pool's arg-max
+                # routing) and the BatchNorm backward's cancellations.  How large that noise is was measured by moving ONE
+                # fp32 statistic of SA1's first BatchNorm by one unit in the last place (profiles/r04d_golden_sensitivity.txt,
+                # tools/lab/golden_err.py): l2 of relation_proposal.0.weight 2.8e-3 -> 9.0e-3, of sa1 layer 0 1.5e-3 ->
+                # 2.4e-3; with that layer's statistics in closed form (sa_mlp.L1_MOMENTS: as close to float64 as the summed
+                # form, one ulp apart from it) sa1 layer 0 lands at 1.14e-2, fp1 layer 0 at 6.2e-3, the relation head at
+                # 1.5e-3; linf <= 1.7e-2 throughout.  The bars are 1.5 x the largest of those realisations: what this
+                # comparison can resolve.  The gate that resolves fp32 level is the frozen-selection step of
+                # tests/test_configs_gpu.py (5e-5).
                 linf = np.abs(g - fx[k]).max() / (np.abs(fx[k]).max() + 1e-12)
                 l2 = np.linalg.norm(g - fx[k]) / (np.linalg.norm(fx[k]) + 1e-12)
-                assert linf < 2.6e-2 and l2 < 4.3e-3, (k, linf, l2)
+                assert linf < 2.6e-2 and l2 < 1.7e-2, (k, linf, l2)
     absent = sorted(n for n, p in model.named_parameters() if p.grad is None)
     assert absent == list(fx["grad_absent"])
 

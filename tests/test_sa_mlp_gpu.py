@@ -254,6 +254,7 @@ def test_first_layer_rebuilt_instead_of_stored(C, npoint, nsample, n, monkeypatc
     xyz = pc[..., :3].contiguous()
     feats = pc[..., 3:].transpose(1, 2).contiguous() if C else None
     inds = pu.furthest_point_sample(xyz, npoint)
+    monkeypatch.setattr(sa_mlp, "L1_MOMENTS", False)     # (statistics from the summed z1 on both sides: see the next test)
     res = []
     for mod, flag in ((sa, True), (sb, False)):
         monkeypatch.setattr(sa_mlp, "RECOMPUTE_Z1", flag)
@@ -266,6 +267,75 @@ def test_first_layer_rebuilt_instead_of_stored(C, npoint, nsample, n, monkeypatc
         assert torch.equal(pa.grad, pb.grad), na
     for (na, ba), (nb, bb) in zip(sa.named_buffers(), sb.named_buffers()):
         assert torch.equal(ba, bb), na
+
+
+@pytest.mark.parametrize("C,npoint,nsample,n", [(1, 512, 64, 6000), (0, 200, 32, 3000), (1, 77, 16, 1000)])
+def test_first_layer_statistics_from_the_moments_of_its_inputs(C, npoint, nsample, n, monkeypatch):
+    """sa_mlp.L1_MOMENTS: z1 = W1 . (rel x, rel y, rel z, feature) is linear in the row's inputs, so SA1's first BatchNorm takes
+    its batch statistics from the 4 sums and 10 products of those inputs (spacap_sa_l1_moments_f32 + _finalize) instead of
+    summing 64 channels per row (lib/pointnet2/pytorch_utils.py:11-36 BatchNorm2d over all grouped rows).  Same rel4 rows bit
+    for bit; statistics, running buffers, outputs and gradients equal the summed form up to fp32 rounding."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd import sa_mlp
+    from spacap3d_amd._native import check, lib
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(11)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=0.3, nsample=nsample, mlp=[C, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    pc = S.scene_batch(2, n, use_height=C == 1, seed=4).to(DEV)
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous() if C else None
+    inds = pu.furthest_point_sample(xyz, npoint)
+    # the two statistics passes side by side on the module's own inputs
+    new_xyz = torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = pu.ball_query(0.3, nsample, xyz, new_xyz).contiguous()
+    B, Np, N, Sn = 2, n, npoint, nsample
+    R = B * N * Sn
+    W1 = sa.mlp_module.layer0.conv.weight.detach().view(64, -1).contiguous()
+    feat = feats.reshape(B, -1).contiguous() if C else None
+    st = torch.cuda.current_stream().cuda_stream
+    nparts = int(lib.spacap_sa_nparts())
+    ra, rb = torch.empty(R, 4, device=DEV), torch.empty(R, 4, device=DEV)
+    part, mom = torch.empty(nparts * 2 * 64, dtype=torch.float64, device=DEV), torch.empty(nparts * 16, dtype=torch.float64, device=DEV)
+    fp = feat.data_ptr() if C else None
+    check(lib.spacap_sa_l1_stats_f32(fp, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), W1.data_ptr(), W1.shape[1], 0.3, B, Np, N, Sn, 64,
+                                     ra.data_ptr(), part.data_ptr(), st), "l1_stats")
+    check(lib.spacap_sa_l1_moments_f32(fp, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), 0.3, B, Np, N, Sn, rb.data_ptr(), mom.data_ptr(), st),
+          "l1_moments")
+    assert torch.equal(ra, rb)
+    g, b_ = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV)
+    sa_, sb_ = torch.empty(64, 4, device=DEV), torch.empty(64, 4, device=DEV)
+    rm = [torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)]
+    rv = [torch.ones(64, device=DEV), torch.ones(64, device=DEV)]
+    check(lib.spacap_sa_bn_finalize_f32(part.data_ptr(), 64, R, 1e-5, 0.1, g.data_ptr(), b_.data_ptr(), rm[0].data_ptr(), rv[0].data_ptr(),
+                                        sa_.data_ptr(), st), "finalize")
+    check(lib.spacap_sa_l1_moments_finalize_f32(mom.data_ptr(), W1.data_ptr(), W1.shape[1], int(C == 1), 64, R, 1e-5, 0.1, g.data_ptr(),
+                                                b_.data_ptr(), rm[1].data_ptr(), rv[1].data_ptr(), sb_.data_ptr(), st), "moments finalize")
+    torch.cuda.synchronize()
+    scale = sa_[:, 0].abs().max().clamp_min(1e-3)
+    assert ((sa_[:, 0] - sb_[:, 0]).abs().max() / scale).item() < 2e-6                    # mean
+    assert ((sa_[:, 1] - sb_[:, 1]).abs() / sa_[:, 1].abs()).max().item() < 2e-5          # 1 / std
+    assert torch.equal(sa_[:, 3], sb_[:, 3])
+    assert ((rm[0] - rm[1]).abs().max() / rm[0].abs().max().clamp_min(1e-4)).item() < 2e-5
+    assert ((rv[0] - rv[1]).abs() / rv[0].abs()).max().item() < 2e-5
+    # the module end to end with the switch on / off
+    res = []
+    for mod, flag in ((sa, True), (sb, False)):
+        monkeypatch.setattr(sa_mlp, "L1_MOMENTS", flag)
+        _, out, _ = mod(xyz, feats, inds)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        (out * w).sum().backward()
+        res.append(out)
+    assert ((res[0] - res[1]).abs().max() / res[1].abs().max()).item() < 2e-4
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+        e = ((pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-20)).item()
+        assert e < 2e-3, (na, e)
+    for (na, ba), (nb, bb) in zip(sa.named_buffers(), sb.named_buffers()):
+        if ba.dtype.is_floating_point:
+            assert ((ba - bb).abs().max() / bb.abs().max().clamp_min(1e-6)).item() < 1e-4, na
+        else:
+            assert torch.equal(ba, bb), na
 
 
 @pytest.mark.parametrize("Cf,mlp,npoint,nsample,n", [(1, [64, 64, 128], 512, 64, 6000), (128, [128, 128, 256], 300, 32, 2048),
