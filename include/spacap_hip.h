@@ -375,7 +375,8 @@ int spacap_sa_pool_finalize_f32(const float *cand_v, const uint8_t *cand_i, cons
 int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, int C, float *out, uint8_t *arg,
                            spacap_stream_t stream);
 /* dym = (out > 0) ? dout : 0; part receives (sum dy, sum dy*xhat) of the pooled layer.  xhat at the arg-max rows comes from
-   zmax [G,C] (spacap_sa_pool_finalize_f32) when given, else from z [G*S,C]. */
+   zmax [G,C] (spacap_sa_pool_finalize_f32) when given, else from z [G*S,C] (a 4-byte gather per element); with both, z serves
+   only the channels whose BatchNorm weight is exactly 0 (every row ties there and zmax is not the arg-max row's value). */
 int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z, const float *zmax,
                            const float *stats, long G, int S, int C, float *dym, double *part,
                            spacap_stream_t stream);

@@ -582,12 +582,16 @@ __global__ __launch_bounds__(256) void sa_pool_bwd_kernel(const float *__restric
   const int c = tid % C;           // C in {64, 128, 256}: 256 / C groups per pass
   const int gs = tid / C, GP = 256 / C;
   const float mean = st[c * 4], istd = st[c * 4 + 1];
+  // zmax [G][C] (the forward's pooling pass kept the arg-max rows' pre-activations) replaces a 4-byte gather per element out of
+  // z [G S][C]; it equals z at the arg-max row wherever a gradient passes, except in a channel whose BatchNorm weight is exactly 0
+  // (every row ties): such a channel reads z when z is given
+  const bool from_max = zmax && (st[c * 4 + 2] != 0.f || !z);
   float s1 = 0.f, s2 = 0.f;
   for (long g = (long)blockIdx.x * GP + gs; g < G; g += (long)gridDim.x * GP) {
     const size_t o = (size_t)g * C + c;
     const float dy = out[o] > 0.f ? dout[o] : 0.f;
     dym[o] = dy;
-    const float zz = zmax ? zmax[o] : z[((size_t)g * S + arg[o]) * C + c];
+    const float zz = from_max ? zmax[o] : z[((size_t)g * S + arg[o]) * C + c];
     s1 += dy;
     s2 += dy * ((zz - mean) * istd);
   }

@@ -126,7 +126,9 @@ class _SAMLP(Function):
             pool_fused = bool(lib.spacap_sa_mid_fwd_pool_supported(C2, C3, S))
             z3_free = Z3_FREE and pool_fused and bool(lib.spacap_sa_l3bwd_supported(C2, C3, S))
             z3 = None if z3_free else torch.empty(R, C3, **f32)
-            zmax = torch.empty(B, N, C3, **f32) if z3_free else None
+            # (the arg-max rows' pre-activations: the pooled layer's BatchNorm sums in the backward read them instead of
+            # gathering 4 bytes per element out of z3)
+            zmax = torch.empty(B, N, C3, **f32) if pool_fused else None
 
             def finalize(k, C, gamma, beta):
                 bn = bns[k]
@@ -194,7 +196,7 @@ class _SAMLP(Function):
                 check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
                                                  st), "spacap_sa_pool_fwd_f32")
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3 if z3 is not None else zmax, stats[0], stats[1],
-                              stats[2], out, arg)
+                              stats[2], out, arg, zmax if z3 is not None else None)
         ctx.z3_free = z3_free         # the saved "z3" is then zmax (B, N, C3): the arg-max rows' pre-activations
         ctx.pm = pmc                  # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)
@@ -206,7 +208,7 @@ class _SAMLP(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        xyz, new_xyz, idx, feat, W1, W2, W3, z1, z2, z3, st1, st2, st3, out, arg = ctx.saved_tensors
+        xyz, new_xyz, idx, feat, W1, W2, W3, z1, z2, z3, st1, st2, st3, out, arg, zmax = ctx.saved_tensors
         dev = xyz.device
         B, Np, _ = xyz.shape
         N, S = idx.shape[1], idx.shape[2]
@@ -230,7 +232,7 @@ class _SAMLP(Function):
             dym = torch.empty(G, C3, **f32)
             z3_free = ctx.z3_free
             check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), None if z3_free else z3.data_ptr(),
-                                             z3.data_ptr() if z3_free else None, st3.data_ptr(), G, S, C3, dym.data_ptr(),
+                                             z3.data_ptr() if z3_free else _ptr(zmax), st3.data_ptr(), G, S, C3, dym.data_ptr(),
                                              part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
             finalize(2, C3, st3)
             dy2 = torch.empty(R, C2, **f32)

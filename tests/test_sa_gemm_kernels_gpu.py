@@ -403,3 +403,47 @@ def test_pooled_layer_weight_gradient_from_z2_alone(R, c2, c3, S):
     assert ((dW3.double() - dW3_old).abs().max() / dW3_old.abs().max()).item() < 1e-5
     pw2, dW3b = run()
     assert torch.equal(pw, pw2) and torch.equal(dW3, dW3b)
+
+
+@pytest.mark.parametrize("G,S,C", [(700, 64, 128), (513, 32, 256), (40, 16, 64)])
+def test_pooled_layer_batchnorm_sums_from_the_kept_argmax_values(G, S, C):
+    """spacap_sa_pool_bwd_f32 with zmax [G, C] (the arg-max rows' pre-activations kept by the forward's pooling pass) next to
+    z [G S, C]: the same masked gradient and the same BatchNorm sums, bit for bit, as gathering z at the arg-max rows -- where no
+    gradient passes zmax is never used in a product that matters, and channels whose BatchNorm weight is exactly 0 (zmax is not
+    the arg-max row's value there: planted garbage) still read z."""
+    from spacap3d_amd._native import check, lib
+    dev = "cuda:0"
+    torch.manual_seed(G + C)
+    z = torch.randn(G, S, C, device=dev)
+    mean, istd = z.view(-1, C).mean(0), 1.0 / torch.sqrt(z.view(-1, C).var(0, unbiased=False) + 1e-5)
+    gamma = torch.rand(C, device=dev) + 0.5
+    gamma[::5] *= -1.0
+    gamma[3::11] = 0.0
+    beta = 0.3 * torch.randn(C, device=dev)
+    stats = torch.stack([mean, istd, gamma * istd, beta], dim=1).contiguous()
+    act = torch.relu((z - mean) * (gamma * istd) + beta)
+    out, arg = act.max(dim=1)
+    zmax = torch.gather(z, 1, arg.unsqueeze(1)).squeeze(1).contiguous()
+    zmax[:, 3::11] = 1e30                                   # zero-weight channels: not the arg-max row's value
+    zmax[out <= 0] = -777.0                                 # no gradient passes: any finite value
+    arg8 = arg.to(torch.uint8).contiguous()
+    dout = torch.randn(G, C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nparts = int(lib.spacap_sa_nparts())
+
+    def run(zp, mp):
+        dym = torch.full((G, C), float("nan"), device=dev)
+        part = torch.full((nparts * 2 * C,), float("nan"), dtype=torch.float64, device=dev)
+        check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.contiguous().data_ptr(), arg8.data_ptr(), zp, mp, stats.data_ptr(), G, S, C,
+                                         dym.data_ptr(), part.data_ptr(), st), "pool_bwd")
+        torch.cuda.synchronize()
+        return dym, part
+
+    d0, p0 = run(z.data_ptr(), None)
+    d1, p1 = run(z.data_ptr(), zmax.data_ptr())
+    assert torch.equal(d0, d1) and torch.equal(p0, p1)
+    live = (gamma != 0)
+    zm2 = zmax.clone()
+    d2, p2 = run(None, zm2.data_ptr())                       # zmax alone (the z3-free path): equal on the channels with a weight
+    pv0, pv2 = p0.view(nparts, 2, C), p2.view(nparts, 2, C)
+    assert torch.equal(d0, d2) and torch.equal(pv0[:, :, live], pv2[:, :, live])
