@@ -139,11 +139,11 @@ struct PrepBwdArgs {
 
 __global__ __launch_bounds__(128) void cap_prep_bwd_kernel(PrepBwdArgs a) {
   const int tid = threadIdx.x, L = a.T - 1, D = a.D;
-  if ((int)blockIdx.x >= a.V) {   // one scene's (K, D) slab of d src = d memory
-    const int b = blockIdx.x - a.V;
+  if ((int)blockIdx.x >= a.V) {   // 2 048 elements of one scene's (K, D) slab of d src = d memory (was one block per scene: 39 us)
+    const int per = (a.K * D + 2047) / 2048, q = blockIdx.x - a.V, b = q / per, e0 = (q - b * per) * 2048;
     const int kb = (int)a.idx[b];
     float *o = a.d_rows + (size_t)b * a.K * D;
-    for (int e = tid; e < a.K * D; e += 128) {
+    for (int e = e0 + tid; e < min(e0 + 2048, a.K * D); e += 128) {
       const int k = e / D, c = e - k * D;
       o[e] = k == kb ? a.g[((size_t)b * L) * D + c] : 0.f;
     }
@@ -157,6 +157,20 @@ __global__ __launch_bounds__(128) void cap_prep_bwd_kernel(PrepBwdArgs a) {
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  // most rows of the table hold no token of this batch (a few hundred positions against V rows): one vote, then zeros
+  bool mine = false;
+  for (int i = tid; i < NP; i += 128) {
+    const int b = i / (L - 1), row = 1 + i - b * (L - 1);
+    long long t = a.tok[(size_t)b * a.T + row];
+    t = t < 0 ? 0 : (t >= a.V ? a.V - 1 : t);
+    mine |= t == v;
+  }
+  if (!__syncthreads_or(mine)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (tid + 128 * j < D) a.d_emb[(size_t)v * D + tid + 128 * j] = 0.f;
+    return;
+  }
   for (int base = 0; base < NP; base += 1024) {
     __syncthreads();
     if (tid == 0) s_n = 0;
@@ -239,7 +253,7 @@ extern "C" int spacap_caption_prep_bwd_f32(const float *g, const int64_t *tok, c
   a.sqrt_d = (float)sqrt((double)D);
   a.seed = seed, a.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   a.d_rows = d_rows, a.d_emb = d_emb;
-  hipLaunchKernelGGL(cap_prep_bwd_kernel, dim3(V + (d_rows ? B : 0)), dim3(128), 0, spacap::as_stream(stream), a);
+  hipLaunchKernelGGL(cap_prep_bwd_kernel, dim3(V + (d_rows ? B * ((K * D + 2047) / 2048) : 0)), dim3(128), 0, spacap::as_stream(stream), a);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -45,7 +45,13 @@ struct RowsArgs {
 
 __device__ __forceinline__ size_t row_off(long r, long grp, long gstride, long skip, long ld) {
   if (grp <= 0) return (size_t)r * ld;
-  const long g = r / grp, t = r - g * grp;
+  long g, t;
+  if (((unsigned long long)r | (unsigned long long)grp) >> 32) {
+    g = r / grp, t = r - g * grp;
+  } else {   // (a 64-bit division is ~200 instructions on this chip and sat on every element load of the small weight gradient: 35 of its 45 us)
+    const unsigned rr = (unsigned)r, gg = (unsigned)grp, q = rr / gg;
+    g = q, t = rr - q * gg;
+  }
   return (size_t)g * gstride + (size_t)(t + skip) * ld;
 }
 
@@ -262,57 +268,86 @@ extern "C" int spacap_dense_sum_slices_f32(const float *parts, int S, long n, lo
 // One 64 (m) x 128 (n) tile per workgroup, thread = 8 m x 4 n, the rows added in ascending order (no partial results).  X rows may
 // be two-level (positions 1.. of every sequence).  Plain fp32 FMAs: 0.2 GFLOP, a latency-bound launch either way.
 namespace {
+template <int MT>   // m per thread: a workgroup covers 8 MT rows of dW x 128 columns
 __global__ __launch_bounds__(256) void dense_wgrad_small_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X,
                                                                 long ldx, long x_grp, long x_gstride, long x_skip, long R, int M, int N,
                                                                 float *__restrict__ dW, float *__restrict__ db) {
-  // 16 rows of both operands at a time through LDS (coalesced 4-byte loads: the rows of G are not 16-byte aligned when M is odd),
-  // then every thread reads its 8 m and 4 n of a row as 16-byte pieces
-  constexpr int RB = 16;
-  __shared__ __attribute__((aligned(16))) float s_g[RB][64 + 4];
+  // 64 rows of both operands at a time through LDS (coalesced 4-byte loads: the rows of G are not 16-byte aligned when M is odd),
+  // the next chunk's loads in flight while this one is multiplied (a chunk costs one round trip whatever its size: a few hundred
+  // rows are four of them).  The launch is VALU work on few workgroups: with 8 m per
+  // thread the vocabulary projection (M = 3 001) ran on 47 CUs for 54 us; 2 m per thread puts it on 188.
+  constexpr int RB = 64, MB = 8 * MT, NG = (RB * MB + 255) / 256, NX = RB * 128 / 256;
+  __shared__ __attribute__((aligned(16))) float s_g[RB][MB + 4];
   __shared__ __attribute__((aligned(16))) float s_x[RB][128 + 4];
   const int tid = threadIdx.x, n4 = tid & 31, mq = tid >> 5;
-  const int mb = blockIdx.x * 64, nb = blockIdx.y * 128;
-  const int m0 = mb + mq * 8, n0 = nb + n4 * 4;
-  float acc[8][4], sb[8];
+  const int mb = blockIdx.x * MB, nb = blockIdx.y * 128;
+  const int m0 = mb + mq * MT, n0 = nb + n4 * 4;
+  float acc[MT][4], sb[MT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < MT; ++i) {
     sb[i] = 0.f;
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[i][u] = 0.f;
   }
-  for (long r0 = 0; r0 < R; r0 += RB) {
-    float tg[RB * 64 / 256], tx[RB * 128 / 256];
+  float tg[NG], tx[NX];
+  __shared__ size_t s_off[2][RB];   // element offset of the chunk's rows of X: one division per ROW (two-level rows), not per element
+  auto offsets = [&](long r0, int buf) {
+    if (tid < RB) s_off[buf][tid] = row_off(r0 + tid < R ? r0 + tid : R - 1, x_grp, x_gstride, x_skip, ldx);
+  };
+  auto request = [&](long r0, int buf) {
 #pragma unroll
-    for (int i = 0; i < RB * 64 / 256; ++i) {
-      const int e = tid + 256 * i, j = e >> 6, m = e & 63;
-      tg[i] = (r0 + j < R && mb + m < M) ? G[(size_t)(r0 + j) * ldg + mb + m] : 0.f;
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + 256 * i, j = e / MB, m = e % MB;
+      tg[i] = (e < RB * MB && r0 + j < R && mb + m < M) ? G[(size_t)(r0 + j) * ldg + mb + m] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < RB * 128 / 256; ++i) {
+    for (int i = 0; i < NX; ++i) {
       const int e = tid + 256 * i, j = e >> 7, n = e & 127;
-      tx[i] = (r0 + j < R && nb + n < N) ? X[row_off(r0 + j, x_grp, x_gstride, x_skip, ldx) + nb + n] : 0.f;
+      tx[i] = (r0 + j < R && nb + n < N) ? X[s_off[buf][j] + nb + n] : 0.f;
     }
-    __syncthreads();   // (the previous chunk's readers are done)
-#pragma unroll
-    for (int i = 0; i < RB * 64 / 256; ++i) s_g[(tid + 256 * i) >> 6][(tid + 256 * i) & 63] = tg[i];
-#pragma unroll
-    for (int i = 0; i < RB * 128 / 256; ++i) s_x[(tid + 256 * i) >> 7][(tid + 256 * i) & 127] = tx[i];
+  };
+  int buf = 0;
+  if (R > 0) {
+    offsets(0, 0);
     __syncthreads();
+    request(0, 0);
+  }
+  for (long r0 = 0; r0 < R; r0 += RB, buf ^= 1) {
+    if (r0 + RB < R) offsets(r0 + RB, buf ^ 1);
+    __syncthreads();   // (the previous chunk's readers are done; the next chunk's row offsets are written)
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const f32x4 g0 = ld4(&s_g[j][mq * 8]), g1 = ld4(&s_g[j][mq * 8 + 4]), x = ld4(&s_x[j][n4 * 4]);
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + 256 * i;
+      if (e < RB * MB) s_g[e / MB][e % MB] = tg[i];
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float gv = i < 4 ? g0[i] : g1[i - 4];
-        sb[i] += gv;
+    for (int i = 0; i < NX; ++i) s_x[(tid + 256 * i) >> 7][(tid + 256 * i) & 127] = tx[i];
+    __syncthreads();
+    if (r0 + RB < R) request(r0 + RB, buf ^ 1);
+    // eight rows' operands out of LDS first, then their products (issued one row at a time the compiler waits out an LDS
+    // round trip per row: 11 us of this kernel's 25 at 248 rows); same order of additions
+    for (int j0 = 0; j0 < RB; j0 += 8) {
+      f32x4 x[8];
+      float gv[8][MT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[i][u] = __builtin_fmaf(gv, x[u], acc[i][u]);
+      for (int j = 0; j < 8; ++j) {
+        x[j] = ld4(&s_x[j0 + j][n4 * 4]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) gv[j][i] = s_g[j0 + j][mq * MT + i];
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          sb[i] += gv[j][i];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[i][u] = __builtin_fmaf(gv[j][i], x[j][u], acc[i][u]);
+        }
     }
   }
   const bool nok = n0 < N;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < MT; ++i) {
     if (m0 + i < M) {
       if (nok) {
 #pragma unroll
@@ -332,8 +367,13 @@ extern "C" int spacap_dense_wgrad_small_f32(const float *G, long ldg, const floa
   const char *what = "spacap_dense_wgrad_small_f32";
   SPACAP_REQUIRE(R >= 0 && M >= 1 && N >= 1 && ldg >= M && ldx >= N && x_grp >= 0 && x_skip >= 0, "%s: bad sizes", what);
   SPACAP_REQUIRE(G && X && dW, "%s: null pointer", what);
-  hipLaunchKernelGGL(dense_wgrad_small_kernel, dim3((unsigned)((M + 63) / 64), (unsigned)((N + 127) / 128)), dim3(256), 0,
-                     spacap::as_stream(stream), G, ldg, X, ldx, x_grp, x_gstride, x_skip, R, M, N, dW, db);
+  const unsigned gy = (unsigned)((N + 127) / 128);
+  if ((long)((M + 63) / 64) * gy >= 200)   // enough workgroups already: 8 m per thread (fewer LDS reads per product)
+    hipLaunchKernelGGL(dense_wgrad_small_kernel<8>, dim3((unsigned)((M + 63) / 64), gy), dim3(256), 0, spacap::as_stream(stream), G, ldg, X,
+                       ldx, x_grp, x_gstride, x_skip, R, M, N, dW, db);
+  else
+    hipLaunchKernelGGL(dense_wgrad_small_kernel<2>, dim3((unsigned)((M + 15) / 16), gy), dim3(256), 0, spacap::as_stream(stream), G, ldg, X,
+                       ldx, x_grp, x_gstride, x_skip, R, M, N, dW, db);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

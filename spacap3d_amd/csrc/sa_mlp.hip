@@ -44,6 +44,13 @@ constexpr int NPART = 1024; // partial-sum rows (= persistent workgroups) of eve
 __device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f32x4 v) { *reinterpret_cast<f32x4 *>(p) = v; }
 
+// r / d for row indices: a 64-bit division is ~200 instructions on this chip and the first-layer passes paid two of them per
+// row and thread; row counts fit 32 bits on the model's path (one 32-bit division, ~30 instructions), the general case stays
+__device__ __forceinline__ long row_div(long r, long d) {
+  if (((unsigned long long)r | (unsigned long long)d) >> 32) return r / d;
+  return (long)((unsigned)r / (unsigned)d);
+}
+
 // ---- layer 1 forward --------------------------------------------------------------------------------------
 // z1[r, :] = Y[b, idx[r], :] + W1[:, 0:3] rel(r) + W1[:, 3] feat[b, idx[r]]      (Y and feat optional)
 // rel(r) = (xyz[b, idx[r]] - new_xyz[b, n]) / rdiv
@@ -98,11 +105,11 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
   const long G = (long)gridDim.x * RP;
   long r = (long)blockIdx.x * RP + rs;
   auto row_in = [&](long rr, int &p, long &b) {
-    b = rr / NS;
+    b = row_div(rr, NS);
     p = idx[rr];
   };
   auto row_z = [&](long rr, int p, long b) {
-    const long g = rr / S;
+    const long g = row_div(rr, S);
     const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)g * 3;
     const f32x4 in = {(q[0] - c[0]) / rdiv, (q[1] - c[1]) / rdiv, (q[2] - c[2]) / rdiv, feat ? feat[(size_t)b * Np + p] : 0.f};
     if (rel4 && c4 == 0) st4(rel4 + (size_t)rr * 4, in);   // the row's four inputs: what the later passes rebuild z1 from
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void sa_l1_moments_kernel(const float *__restr
 #pragma unroll
   for (int i = 0; i < 14; ++i) a[i] = 0.f;
   auto row = [&](long r, int p) {
-    const long b = r / NS, g = r / S;
+    const long b = row_div(r, NS), g = row_div(r, S);
     const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)g * 3;
     const f32x4 in = {(q[0] - c[0]) / rdiv, (q[1] - c[1]) / rdiv, (q[2] - c[2]) / rdiv, feat ? feat[(size_t)b * Np + p] : 0.f};
     st4(rel4 + (size_t)r * 4, in);
@@ -746,7 +753,7 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
       if ((FULL || grow < R) && L.rel4) {
         in = ld4(L.rel4 + (size_t)grow * 4);
       } else if (FULL || grow < R) {
-        const long b = grow / ((long)L.N * L.S), gi = grow / L.S;
+        const long b = row_div(grow, (long)L.N * L.S), gi = row_div(grow, L.S);
         const int p = L.idx[grow];
         const float *q = L.xyz + ((size_t)b * L.Np + p) * 3, *c = L.new_xyz + (size_t)gi * 3;
         in[0] = (q[0] - c[0]) / L.rdiv, in[1] = (q[1] - c[1]) / L.rdiv, in[2] = (q[2] - c[2]) / L.rdiv;
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__(256) void sa_l1_bwd_kernel(float *__restrict__ dy1,
     const long r = r0 + rs;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (r < R) {
-      const long b = r / NS, gi = r / S;
+      const long b = row_div(r, NS), gi = row_div(r, S);
       const int p = idx[r];
       const float *q = xyz + ((size_t)b * Np + p) * 3, *c = new_xyz + (size_t)gi * 3;
       const float rx = (q[0] - c[0]) / rdiv, ry = (q[1] - c[1]) / rdiv, rz = (q[2] - c[2]) / rdiv;
