@@ -49,24 +49,80 @@ def spawn_ranks(n):
     one per GPU, the reference's one-command multi-GPU mode (scripts/train.py:198-200) -- BEFORE anything in this process
     has touched the GPU (nothing has been imported yet but the standard library).  The parent never initialises HIP and never
     re-execs; it relays rank 0's JSON line and exits non-zero when any rank fails."""
+    import collections
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, tails, out0, threads = [], [], [], []
+
+    def drain(stream, keep, limit=None):
+        # a reader thread per pipe: no child can ever block on a full pipe while the parent looks elsewhere
+        for line in iter(stream.readline, b""):
+            keep.append(line)
+            if limit is not None:            # a rank's stderr: passed through as it comes, the last lines kept for the report
+                sys.stderr.buffer.write(line)
+                sys.stderr.buffer.flush()
+                if len(keep) > limit:
+                    keep.popleft()
+        stream.close()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE,
+                             start_new_session=True)
+        procs.append(p)
+        tails.append(collections.deque())
+        threads.append(threading.Thread(target=drain, args=(p.stderr, tails[-1], 60), daemon=True))
+        if r == 0:
+            threads.append(threading.Thread(target=drain, args=(p.stdout, out0), daemon=True))
+    for t in threads:
+        t.start()
+    # poll ALL ranks: the first non-zero exit ends the job within seconds (the survivors would otherwise sit in
+    # init_process_group / their next collective until the store's 10 - 30 min timeout)
+    first_bad = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            first_bad = bad
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        time.sleep(0.05)
+    if first_bad:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)      # exactly the process group this function started
+                except ProcessLookupError:
+                    pass
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                p.wait()
+    for t in threads:
+        t.join(timeout=5.0)
+    sys.stdout.write(b"".join(out0).decode(errors="replace"))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit(f"bench.py: rank(s) failed (rank, exit code): {bad}")
+    if first_bad:
+        for r, tail in enumerate(tails):
+            text = b"".join(tail).decode(errors="replace")
+            sys.stderr.write(f"---- rank {r} (exit code {procs[r].returncode}) last stderr lines ----\n{text}")
+    sys.stderr.flush()
+    if first_bad:
+        raise SystemExit(f"bench.py: rank(s) failed first (rank, exit code): {first_bad}; the other ranks were terminated")
 
 
 if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
@@ -349,6 +405,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the short cfg3 / cfg4 / cfg5 sub-records and the eval record")
     args = ap.parse_args()
 
+    # (read and validated on EVERY rank before any rank joins the process group: a bad table ends all ranks at once instead
+    # of leaving the others in their next collective)
+    top_fn, top_file, top_rows = window_table_top()
+    if os.environ.get("SPACAP_BENCH_FAIL_RANK") is not None and os.environ.get("SPACAP_BENCH_FAIL_RANK") == os.environ.get("RANK"):
+        raise SystemExit("bench.py: injected failure of this rank (test knob SPACAP_BENCH_FAIL_RANK)")
     rank, local_rank, world = init_from_env()
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
@@ -411,16 +472,14 @@ def main():
 
     # -- the roofline kernel's duration INSIDE a step (beside the side-stream sampling chain, with the step's grid) ----------
     in_step = in_step_top = None
-    top_fn = top_file = top_rows = None
-    if rank == 0:
-        top_fn, top_file, top_rows = window_table_top()
     # (function of the window table) -> (module whose `lib` launches it, C entry point, selector of its LARGEST launch in the step)
     R1_, R2_ = per_gpu * 2048 * 64, per_gpu * 1024 * 32
     import spacap3d_amd.linear as lin
     import spacap3d_amd.sa_mlp as sam
     import spacap3d_amd.tf_layer as tfl
     TOP = {
-        "sa_wgrad_kernel": (sam, "spacap_sa_wgrad_f32", lambda a: (a[7], a[8], a[9]) == (R1_, 128, 64)),
+        # (SA1 layer 2: the pooled layer 3 runs sa_wgrad_pool_kernel, so (R1, 64, 64) is the largest launch of THIS function in the step)
+        "sa_wgrad_kernel": (sam, "spacap_sa_wgrad_f32", lambda a: (a[7], a[8], a[9]) == (R1_, 64, 64)),
         "rel_fused_bwd_kernel": (lin, "spacap_relation_fused_bwd_f32", lambda a: True),
         "sa_mid_fwd_bf3s_kernel": (sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)),
         "sa_dgrad_bf3s_kernel": (sam, "spacap_sa_dgrad_f32", lambda a: (a[8], a[9], a[10]) == (R2_, 256, 128)),
@@ -441,7 +500,11 @@ def main():
             torch.cuda.synchronize()
         if ist.events:
             in_step = {"us": ist.mean_us(), "launches": len(ist.events)}
-        in_step_top = {"us": itop.mean_us(), "launches": len(itop.events)} if itop.events else None
+        if not itop.events:
+            # the roofline line must price a launch the step really makes, never an isolated stand-in for one it does not
+            raise SystemExit(f"bench.py: eight eager steps launched `{top_fn}` ({tname}) at no shape its TOP selector accepts: "
+                             "the selector / case no longer match what the step runs")
+        in_step_top = {"us": itop.mean_us(), "launches": len(itop.events)}
         trainer.graph = keep_graph
 
     # -- inference forward (greedy decoding) -------------------------------------------------------------------------------
@@ -496,7 +559,7 @@ def main():
                     + (os.path.basename(pmc_files[-1]) if pmc else "no tracked PMC file for this shape"))
         R1 = B * 2048 * 64
         top_case = {
-            "sa_wgrad_kernel": lambda: KC.sa_wgrad(R1, 128, 64, True, 64, dev, "SA1 layer 3"),
+            "sa_wgrad_kernel": lambda: KC.sa_wgrad(R1, 64, 64, False, 64, dev, "SA1 layer 2"),
             "rel_fused_bwd_kernel": lambda: KC.rel_fused(B, cfg["proposals"], 1, dev),
             "sa_mid_fwd_bf3s_kernel": lambda: KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3"),
             "sa_dgrad_bf3s_kernel": lambda: KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SPACAP_ABI_VERSION 3
+#define SPACAP_ABI_VERSION 4
 
 #define SPACAP_OK 0
 #define SPACAP_E_INVALID (-1)   /* bad argument (null pointer, negative size, unsupported shape) */
@@ -547,9 +547,12 @@ int spacap_scene_votes_f32(const float *pc, const int32_t *ins, const uint8_t *i
 
 /* ---- optimizer: torch.optim.Adam (scripts/train.py:262) over one flat parameter buffer, one launch ---------------
  * g' = grad_scale*g + weight_decay*p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
- * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step (device f32, 1-based).  All f32 [n], 16-byte aligned. */
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step (device f32, 1-based).  All f32 [n], 16-byte aligned.
+ * skip_if_nonzero: NULL, or a device int64 that turns the whole update off when it is non-zero at launch (the sticky error
+ * word of spacap_stream_wait_ge: a gradient that a timed-out wait may have let through half-written is never applied). */
 int spacap_adam_flat_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1, float beta2,
-                         float eps, float weight_decay, const float *step, float grad_scale, spacap_stream_t stream);
+                         float eps, float weight_decay, const float *step, float grad_scale,
+                         const int64_t *skip_if_nonzero, spacap_stream_t stream);
 
 /* ---- detection losses of the training step (csrc/losses.hip) ----------------------------------------------------
  * Replaces compute_vote_loss / compute_objectness_loss / compute_box_and_sem_cls_loss (lib/loss_helper.py:35-197,
@@ -817,9 +820,12 @@ int spacap_copy_batched(const void *const *src, void *const *dst, const long *nb
 /* The stream idles for about `microseconds` (one wave spinning on the device's wall clock; 0 .. 100 000). */
 int spacap_stream_delay(int microseconds, spacap_stream_t stream);
 /* A dependency from inside a captured step to a stream outside it (events cannot express one): spacap_stream_signal writes
-   *flag = *value (device words) in stream order; spacap_stream_wait_ge holds its stream (one spinning wave) until *flag >= value,
-   at most timeout_ms.  engine.py: the all-reduce of the captioner's gradient slice starts while the detector's backward runs. */
-int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, spacap_stream_t stream);
+   *flag = *value (device words) in stream order; spacap_stream_wait_ge holds its stream (one spinning wave) until *flag >= value.
+   A wait that lasts longer than timeout_ms (1 .. 600 000) gives up LOUDLY: it stores `value` into the sticky device word *err
+   (compare-and-swap against 0: the first failure stays; the library never clears it).  Work queued behind the wait still
+   runs, so its consumer must be gated on *err (spacap_adam_flat_f32's skip_if_nonzero) and the host must read the word.
+   engine.py: the all-reduce of the captioner's gradient slice starts while the detector's backward runs. */
+int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, int64_t *err, spacap_stream_t stream);
 int spacap_stream_signal(int64_t *flag, const int64_t *value, spacap_stream_t stream);
 
 /* Lab only (tools/lab/step_stamps.py): writes the device's 100 MHz wall clock into *slot when the stream reaches it. */

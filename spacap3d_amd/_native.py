@@ -15,7 +15,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspacap_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i = ctypes.c_int
 _l = ctypes.c_long
@@ -84,7 +84,7 @@ SIGNATURES = {
     "spacap_copy_batched": (_i, [_p, _p, _p, _i, _p]),
     "spacap_lab_stamp": (_i, [_p, _p]),
     "spacap_stream_delay": (_i, [_i, _p]),
-    "spacap_stream_wait_ge": (_i, [_p, _l, _i, _p]),
+    "spacap_stream_wait_ge": (_i, [_p, _l, _i, _p, _p]),
     "spacap_stream_signal": (_i, [_p, _p, _p]),
     "spacap_sa_nparts": (_i, []),
     "spacap_sa_wgrad_slabs": (_i, [_l, _i, _i, _i]),
@@ -150,7 +150,7 @@ SIGNATURES = {
     "spacap_rel_loss_bwd_f32": (_i, [_p] * 3 + [_i] * 2 + [_p, _p]),
     "spacap_sum_slabs_f32": (_i, [_p, _i, _l, _p, _p]),
     "spacap_sum_slabs_batched_f32": (_i, [_p, _p, _p, _p, _i, _p]),
-    "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p]),
+    "spacap_adam_flat_f32": (_i, [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _f, _p, _p]),
     "spacap_linear_dgrad_mask_f32": (_i, [_p, _p, _p, _f, _l, _i, _i, _p, _p]),
     "spacap_rel_tail_fwd_f32": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p]),
     "spacap_rel_tail_bwd_nparts": (_i, [_l]),

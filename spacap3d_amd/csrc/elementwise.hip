@@ -145,7 +145,10 @@ namespace {
 __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                         float *__restrict__ m, float *__restrict__ v, long n, float lr,
                                                         float b1, float b2, float eps, float wd,
-                                                        const float *__restrict__ step, float grad_scale) {
+                                                        const float *__restrict__ step, float grad_scale,
+                                                        const long long *__restrict__ skip_if_nonzero) {
+  // (a gradient that a timed-out stream wait may have let through half-written is never applied: see wait_ge_kernel)
+  if (skip_if_nonzero && __hip_atomic_load(skip_if_nonzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const float t = *step;
   const float c1 = 1.0f - powf(b1, t), c2 = 1.0f - powf(b2, t);
   const float step_size = lr / c1, rs2 = 1.0f / sqrtf(c2);
@@ -177,16 +180,18 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(float *__restrict__ p, c
 
 // p, g, m, v: f32 [n] (16-byte aligned); step: device f32 holding the 1-based step count of THIS update;
 // grad_scale multiplies the gradient first (1 / world size after a summing all-reduce, else 1).
+// skip_if_nonzero (nullable): a device int64; when it is non-zero at launch the update is skipped entirely (the sticky
+// error word of spacap_stream_wait_ge: gradients behind a timed-out wait are never applied).
 extern "C" int spacap_adam_flat_f32(float *p, const float *g, float *m, float *v, long n, float lr, float beta1,
                                     float beta2, float eps, float weight_decay, const float *step, float grad_scale,
-                                    spacap_stream_t stream) {
+                                    const int64_t *skip_if_nonzero, spacap_stream_t stream) {
   SPACAP_REQUIRE(n >= 0, "spacap_adam_flat_f32: bad size");
   if (n == 0) return SPACAP_OK;
   SPACAP_REQUIRE(p && g && m && v && step, "spacap_adam_flat_f32: null pointer");
   SPACAP_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                    reinterpret_cast<uintptr_t>(v)) & 15) == 0, "spacap_adam_flat_f32: unaligned pointer");
   hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for(n)), dim3(256), 0, spacap::as_stream(stream), p, g, m, v, n, lr, beta1,
-                     beta2, eps, weight_decay, step, grad_scale);
+                     beta2, eps, weight_decay, step, grad_scale, reinterpret_cast<const long long *>(skip_if_nonzero));
   SPACAP_CHECK_LAUNCH("spacap_adam_flat_f32");
   return SPACAP_OK;
 }
@@ -436,12 +441,19 @@ extern "C" int spacap_stream_delay(int microseconds, spacap_stream_t stream) {
 // ---- a stream waits for a word in device memory: one wave spins until *flag >= value (engine.py: the gradient all-reduce of
 // the captioner's slice starts on the communication stream as soon as the captured step, in the middle of its backward, has
 // written the step number there -- a dependency from INSIDE a hipGraph to a stream outside it, which events cannot express).
-// Gives up after `timeout_ms` of wall clock (the caller then simply runs later than it could have).
+// A wait that runs out of time does NOT fall through silently: it leaves `value` in the sticky word *err (first failure
+// wins; never cleared by the library).  What is queued behind the wait on that stream still runs -- the device cannot
+// un-queue it -- so the consumer of that work must be gated on *err: spacap_adam_flat_f32 skips its update when the word
+// it is given is non-zero, and the host raises when it reads the word (engine.Trainer.check_health / the next step()).
 namespace {
-__global__ void wait_ge_kernel(const long long *flag, long long value, unsigned long long ticks) {
+__global__ void wait_ge_kernel(const long long *flag, long long value, unsigned long long ticks, unsigned long long *err) {
   const unsigned long long t0 = wall_clock64();
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < value) {
-    if (wall_clock64() - t0 > ticks) break;
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < value) {
+    if (wall_clock64() - t0 > ticks) {
+      atomicCAS(err, 0ull, (unsigned long long)(value > 0 ? value : 1));
+      __threadfence_system();
+      return;
+    }
     __builtin_amdgcn_s_sleep(16);
   }
 }
@@ -449,10 +461,10 @@ __global__ void signal_set_kernel(long long *flag, const long long *value) {
   __hip_atomic_store(flag, *value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
-extern "C" int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, spacap_stream_t stream) {
-  SPACAP_REQUIRE(flag && timeout_ms >= 1 && timeout_ms <= 60000, "spacap_stream_wait_ge: bad arguments");
+extern "C" int spacap_stream_wait_ge(const int64_t *flag, int64_t value, int timeout_ms, int64_t *err, spacap_stream_t stream) {
+  SPACAP_REQUIRE(flag && err && timeout_ms >= 1 && timeout_ms <= 600000, "spacap_stream_wait_ge: bad arguments");
   hipLaunchKernelGGL(wait_ge_kernel, dim3(1), dim3(1), 0, spacap::as_stream(stream), reinterpret_cast<const long long *>(flag),
-                     (long long)value, (unsigned long long)timeout_ms * 100000ull);
+                     (long long)value, (unsigned long long)timeout_ms * 100000ull, reinterpret_cast<unsigned long long *>(err));
   SPACAP_CHECK_LAUNCH("spacap_stream_wait_ge");
   return SPACAP_OK;
 }

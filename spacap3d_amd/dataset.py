@@ -54,7 +54,7 @@ class DeviceSceneDataset:
                  use_multiview=False, color_renorm="once"):
         if color_renorm not in ("once", "per_access"):
             raise ValueError("color_renorm must be 'once' or 'per_access'")
-        self.color_renorm = color_renorm
+        self._color_renorm = color_renorm   # fixed at construction: which copies a scene keeps in HBM depends on it (add_scene)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("CPU not supported")
@@ -87,6 +87,12 @@ class DeviceSceneDataset:
         if self.use_color and self.color_renorm == "once":   # (without use_color the reference never normalises: pcl_color stays raw)
             col = ((col.double() - self._mean_rgb) / 256.0).float()
         return col
+
+    @property
+    def color_renorm(self):
+        """Read-only: "once" scenes are normalised when added and keep no raw copy, "per_access" scenes keep ``color0`` for
+        reset_colors(); switching the mode of a loaded dataset would leave scenes without the copy the other mode needs."""
+        return self._color_renorm
 
     def reset_colors(self):
         """``color_renorm="per_access"``: back to the colours as loaded (the reference's state at the start of every epoch)."""

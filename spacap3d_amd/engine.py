@@ -43,17 +43,26 @@ class Trainer:
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
-        # multi-rank tail: all-reduce the captioner's slice of the flat gradient bucket on a communication stream while the
-        # detector's backward is still running (see _boundary / _optimizer_step); SPACAP_OVERLAP_ALLREDUCE=0: one all-reduce
-        # after the whole backward
-        self.overlap_allreduce = os.environ.get("SPACAP_OVERLAP_ALLREDUCE", "1") != "0"
+        # multi-rank tail: SPACAP_OVERLAP_ALLREDUCE=1 all-reduces the captioner's slice of the flat gradient bucket on a
+        # communication stream while the detector's backward is still running (see _boundary / _optimizer_step).  OFF by
+        # default -- one all-reduce after the whole backward -- until the RCCL leg has passed the bitwise bucket test on a
+        # box with two GPUs (tests/dist_worker.py; no such box in this pool so far: only the gloo shared-GPU leg has run).
+        self.overlap_allreduce = os.environ.get("SPACAP_OVERLAP_ALLREDUCE", "0") == "1"
+        self.overlap_timeout_ms = 20000   # a boundary that never arrives within this is an error, never a fall-through
         self._cap_start = None      # index into bucket.params where the captioner's parameters begin (a suffix of the bucket)
         self._comm_stream = None
-        self._sig = None            # int64 [2] on the device: [0] = steps executed, [1] = "captioner gradients packed" flag
+        # int64 [4] on the device (allocated in _setup, outside any capture): [0] = armed steps begun, [1] = "captioner
+        # gradients packed" flag = the value of [0] its step published, [2] = STICKY error word (a stream wait timed out:
+        # spacap_stream_wait_ge; max over the ranks), [3] unused
+        self._sig = None
         self._sig_host = 0          # host mirror of _sig[0]
+        self._sig_resync = False    # an exception may have separated the two: re-read the device word at the next tail
+        self._err_host = None       # pinned int64 [1]: the error word as of the previous overlapped tail (+ its event)
+        self._err_event = None
         self._boundary_done = False
         self._armed_step = False
         self.boundary_launches = 0  # (tests: how many times the boundary actions ran)
+        self.force_comm_wait = False  # (tests: queue the communication stream's wait on one rank too)
         if next(model.parameters()).is_cuda:
             # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
             from ._native import check, lib
@@ -173,6 +182,11 @@ class Trainer:
         else:
             self.optimizer = torch.optim.Adam(used, **kw)
         self._find_captioner_suffix()
+        if used[0].is_cuda and self._sig is None:
+            # here and not at first use: a zero-fill issued inside enable_graph's capture would be replayed every step
+            self._sig = torch.zeros(4, dtype=torch.int64, device=used[0].device)
+            self._comm_stream = torch.cuda.Stream(device=used[0].device)
+            self._err_host = torch.zeros(1, dtype=torch.int64).pin_memory()
 
     def _adopt_bn_counters(self):
         """The ``num_batches_tracked`` buffers of the BatchNorm layers whose training forward runs through the fused ops
@@ -314,7 +328,14 @@ class Trainer:
         1 / world of the mean as its gradient scale: no separate division pass over the 36 MB bucket."""
         flat = not isinstance(self.optimizer, torch.optim.Optimizer)
         if getattr(self, "_armed_step", False):
-            self._sig_host += 1    # mirrors the device-side step counter: one increment per EXECUTED armed step, boundary or not
+            if self._sig_resync:
+                # a step that raised between the device-side increment and this point left the mirror behind: a wait for the
+                # stale value would pass at once.  Re-read the device word (it already counts the step being finished).
+                torch.cuda.synchronize(self._sig.device)
+                self._sig_host = int(self._sig[0].item())
+                self._sig_resync = False
+            else:
+                self._sig_host += 1    # mirrors the device-side step counter: one increment per EXECUTED armed step, boundary or not
         if flat and self._boundary_done:
             # the captioner's slice was packed (and published) in the middle of the backward: its all-reduce goes to the
             # communication stream behind a wait for that flag, the detector's slice follows on this stream
@@ -352,10 +373,7 @@ class Trainer:
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if not (multi or self.split_optimizer):
             return False
-        if self._sig is None:
-            self._sig = torch.zeros(2, dtype=torch.int64, device=pc.device)
-            self._comm_stream = torch.cuda.Stream(device=pc.device)
-        return True
+        return self._sig is not None      # (allocated by _setup)
 
     def _boundary_hook(self, grad):
         if self._overlap_armed and not self._boundary_done:
@@ -373,8 +391,13 @@ class Trainer:
         pairs = [(v, p.grad) for p, v in zip(b.params[i0:], b.views[i0:]) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if pairs:
             copy_batched([v for v, _ in pairs], [g.contiguous() for _, g in pairs])
+        # a parameter this step produced no gradient for contributes zeros, as FlatGradBucket.pack writes them (its slice
+        # still holds the previous step's reduced gradient: bucket.zero() does not clear the flat buffer in this mode)
+        none = [v for p, v in zip(b.params[i0:], b.views[i0:]) if p.grad is None]
+        if none:
+            torch._foreach_zero_(none)
         dev = b.flat.device
-        check(lib.spacap_stream_signal(self._sig[1:].data_ptr(), self._sig[:1].data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+        check(lib.spacap_stream_signal(self._sig[1:2].data_ptr(), self._sig[:1].data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
               "spacap_stream_signal")
         self.boundary_launches += 1
 
@@ -386,24 +409,57 @@ class Trainer:
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         off = b.offsets[i0]
         main = torch.cuda.current_stream(dev)
-        if multi:
+        err = self._sig[2:3]
+        if multi or self.force_comm_wait:
             comm = self._comm_stream
             with torch.cuda.stream(comm):
-                check(lib.spacap_stream_wait_ge(self._sig[1:].data_ptr(), self._sig_host, 2000, comm.cuda_stream), "spacap_stream_wait_ge")
-                dist.all_reduce(b.flat[off:], op=dist.ReduceOp.SUM)
+                # Nothing else orders this stream against the step: the wait IS the dependency.  If it times out, the
+                # collective behind it runs on a half-written slice -- the device cannot un-queue it -- so a timeout (a) sets
+                # the sticky error word, (b) reaches every rank (MAX all-reduce of the word), (c) turns this step's Adam
+                # off on the device (skip_word) and (d) raises on the host at the next step() / check_health().
+                check(lib.spacap_stream_wait_ge(self._sig[1:2].data_ptr(), self._sig_host, int(self.overlap_timeout_ms),
+                                                err.data_ptr(), comm.cuda_stream), "spacap_stream_wait_ge")
+                if multi:
+                    dist.all_reduce(b.flat[off:], op=dist.ReduceOp.SUM)
+                    dist.all_reduce(err, op=dist.ReduceOp.MAX)
         # the detector's stray gradients (everything the captured step did not produce inside the bucket)
         if sources is None:
             sources = [p.grad for p in b.params]
         pairs = [(v, s_) for v, s_ in zip(b.views[:i0], sources[:i0]) if s_ is not None and s_.data_ptr() != v.data_ptr()]
         if pairs:
             copy_batched([v for v, _ in pairs], [s_.contiguous() for _, s_ in pairs])
+        none = [v for v, s_ in zip(b.views[:i0], sources[:i0]) if s_ is None]
+        if none:
+            torch._foreach_zero_(none)     # (as FlatGradBucket.pack: no gradient this step = zeros, not last step's)
         for p, v in zip(b.params, b.views):
             p.grad = v
         if multi:
             dist.all_reduce(b.flat[:off], op=dist.ReduceOp.SUM)
+        if multi or self.force_comm_wait:
             main.wait_stream(self._comm_stream)
         self.grad_scale = 1.0 / dist.get_world_size() if multi else 1.0
-        self.optimizer.step(grad_scale=self.grad_scale)
+        self.optimizer.step(grad_scale=self.grad_scale, skip_word=err)
+        # the error word travels to pinned host memory behind Adam; step() looks at it once the copy has landed
+        self._err_host.copy_(err, non_blocking=True)
+        self._err_event = torch.cuda.Event()
+        self._err_event.record(main)
+
+    def check_health(self, wait=True):
+        """Raises if a stream wait of the overlapped gradient exchange ever timed out on any rank (the sticky error word; the
+        optimizer update of that step was skipped on the device).  ``wait=False``: only looks at what has already reached
+        the host (step() does this every time, one step behind, without stalling the stream)."""
+        if self._sig is None or self._err_event is None:
+            return
+        if wait:
+            self._err_event.synchronize()
+        elif not self._err_event.query():
+            return
+        bad = int(self._err_host[0])
+        if bad:
+            raise RuntimeError(
+                f"overlapped gradient all-reduce: the wait for step {bad}'s captioner gradients timed out after "
+                f"{self.overlap_timeout_ms} ms on some rank; that step's optimizer update was skipped on every rank and "
+                "the exchange cannot be trusted any more (set SPACAP_OVERLAP_ALLREDUCE=0 for the serial tail)")
 
     # -- hipGraph mode ------------------------------------------------------------------------------------------
     # One training step is ~800 kernel launches (1 900 before the fused operators), most of them microseconds long; eager
@@ -560,14 +616,19 @@ class Trainer:
     def step(self, data_dict, next_data=None):
         """One full training step; returns the (device) loss tensor, no host sync.  ``next_data``: the batch of
         the following step, whose sampling pyramid is started on the side stream first."""
-        if self.graph is not None:
-            return self._graph_step(data_dict, next_data)
-        if self.bucket is None:
-            self._setup({k: v for k, v in data_dict.items() if k != "_fps_prefetch"})
-        data_dict = self._consume_prefetch(data_dict)  # pops what the previous step prefetched for this batch
-        if next_data is not None:
-            self.prefetch(next_data)                   # may be the same dict object: order matters
-        return self._core(data_dict)
+        self.check_health(wait=False)
+        try:
+            if self.graph is not None:
+                return self._graph_step(data_dict, next_data)
+            if self.bucket is None:
+                self._setup({k: v for k, v in data_dict.items() if k != "_fps_prefetch"})
+            data_dict = self._consume_prefetch(data_dict)  # pops what the previous step prefetched for this batch
+            if next_data is not None:
+                self.prefetch(next_data)                   # may be the same dict object: order matters
+            return self._core(data_dict)
+        except BaseException:
+            self._sig_resync = self._sig is not None   # the device-side step counter may be ahead of its host mirror now
+            raise
 
 
 def synthetic_batch(batch: int, n_points: int, device, seed: int = 0, vocab: int = 3001, use_color=False,

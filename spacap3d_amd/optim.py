@@ -31,12 +31,15 @@ class FlatAdam:
         self.step_t = torch.zeros((), dtype=torch.float32, device=flat_g.device)
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
-        """One update from the gradients currently in ``bucket.flat`` (pack them first)."""
+    def step(self, grad_scale=1.0, skip_word=None):
+        """One update from the gradients currently in ``bucket.flat`` (pack them first).  ``skip_word``: a device int64
+        tensor; the kernel leaves parameters and moments untouched when it is non-zero (engine.Trainer: the sticky error
+        word of a timed-out stream wait)."""
         dev = self.flat_p.device
         self.step_t += 1
         with torch.cuda.device(dev):
             check(lib.spacap_adam_flat_f32(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.m.data_ptr(),
                                            self.v.data_ptr(), self.flat_p.numel(), self.lr, self.betas[0], self.betas[1],
                                            self.eps, self.weight_decay, self.step_t.data_ptr(), float(grad_scale),
+                                           skip_word.data_ptr() if skip_word is not None else None,
                                            torch.cuda.current_stream(dev).cuda_stream), "spacap_adam_flat_f32")

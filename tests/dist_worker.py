@@ -20,12 +20,16 @@ def main():
     ap.add_argument("--device", default="cpu")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--overlap", action="store_true", help="all-reduce the captioner's slice beside the detector's backward")
+    ap.add_argument("--share-gpu", action="store_true", help="--device cuda with every rank on cuda:0 over gloo (1-GPU boxes)")
     a = ap.parse_args()
     from spacap3d_amd import backend, synthetic as S
     from spacap3d_amd.distributed import init_from_env
     from spacap3d_amd.engine import Trainer, synthetic_batch
     from spacap3d_amd.spacapnet import build_default
-    rank, local_rank, world = init_from_env("gloo" if a.device == "cpu" else "nccl")
+    rank, local_rank, world = init_from_env("gloo" if (a.device == "cpu" or a.share_gpu) else "nccl")
+    if a.share_gpu:
+        local_rank = 0
     assert world >= 2
     if a.device == "cpu":
         from oracle.attention_ref import OracleBackend
@@ -41,12 +45,21 @@ def main():
             if isinstance(m, torch.nn.Dropout):
                 m.p = 0.0
         tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-3)
+        tr.overlap_allreduce = a.overlap
         data = synthetic_batch(1, 2048, dev, seed=7 + rank, vocab=60)     # each rank its own scene
         if a.graph and dev.type == "cuda":
             tr.step(data, next_data=data)
             assert tr.enable_graph(data, warmup=1), tr.graph_error
             for _ in range(a.steps):
                 tr.step(data, next_data=data)
+            tr.check_health()
+            if a.overlap:
+                assert tr.boundary_launches >= 3, tr.boundary_launches   # eager step, warm-up, capture: the overlapped tail ran
+                # every rank's bucket holds the same reduced gradient, bit for bit (both slices travelled)
+                torch.cuda.synchronize()
+                red = [torch.empty_like(tr.bucket.flat) for _ in range(world)]
+                dist.all_gather(red, tr.bucket.flat.clone())
+                assert all(torch.equal(red[0], r) for r in red), "reduced buckets differ between ranks"
         else:
             tr._setup(dict(data))
             for _ in range(a.steps):

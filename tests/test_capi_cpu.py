@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(raw, s), f"{s} declared in include/spacap_hip.h but not exported"
         assert s in _native.SIGNATURES, f"{s} has no ctypes signature in spacap3d_amd/_native.py"
-    assert _native.lib.spacap_abi_version() == _native.ABI_VERSION == 3
+    assert _native.lib.spacap_abi_version() == _native.ABI_VERSION == 4
 
 
 def test_opt_n_threads_restated_exactly(oracle_ext):

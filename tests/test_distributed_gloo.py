@@ -144,6 +144,16 @@ def test_real_training_step_on_two_rccl_ranks():
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     _launch_workers("cuda")
     _launch_workers("cuda", extra=("--graph", "--steps", "3"))
+    _launch_workers("cuda", extra=("--graph", "--steps", "3", "--overlap"))
+
+
+@pytest.mark.gpu
+def test_overlapped_exchange_on_two_ranks_sharing_the_gpu():
+    """The overlapped tail with a REAL process group on a one-GPU box: two ranks on cuda:0 over gloo, hipGraph step, the
+    captioner's slice all-reduced on the communication stream behind the device-side wait, the error word's MAX all-reduce,
+    the detector's slice on the main stream -- reduced buckets and parameters bit-identical on both ranks, no timeout."""
+    _launch_workers("cuda", extra=("--graph", "--steps", "3", "--overlap", "--share-gpu"))
+    _launch_workers("cuda", extra=("--graph", "--steps", "3", "--share-gpu"))
 
 
 def test_flat_bucket_keeps_the_captioner_parameters_as_one_suffix():

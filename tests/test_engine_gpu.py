@@ -289,6 +289,119 @@ def test_gradient_slices_published_mid_backward_give_the_serial_tail():
         assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (i, losses)
 
 
+def test_timed_out_gradient_wait_raises_and_never_applies_the_update():
+    """The overlapped exchange's stream wait (csrc/elementwise.hip: wait_ge_kernel) must not fall through silently: armed for a
+    step number nobody will publish, it (a) leaves that number in the sticky error word, (b) turns the step's Adam off ON THE
+    DEVICE -- parameters and moments bit-identical to before the step -- and (c) makes check_health() and the next step()
+    raise.  One GPU, split_optimizer (the multi-rank code path without a process group) with the communication stream's wait
+    forced on.  SURVEY.md section 8e; reference: one gradient exchange per step, scripts/train.py:198-200."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    model = _make()
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-3, split_optimizer=True)
+    tr.overlap_allreduce, tr.force_comm_wait, tr.overlap_timeout_ms = True, True, 2000
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    for _ in range(2):                                   # healthy steps: the wait is satisfied by the boundary's signal
+        tr.step(data, next_data=data)
+    tr.check_health()
+    assert tr.boundary_launches == 2 and int(tr._sig[2]) == 0
+    before = [t.clone() for t in (tr.optimizer.flat_p, tr.optimizer.m, tr.optimizer.v)]
+    tr._sig_host += 7                                    # the host now waits for a step number the device will not reach
+    tr.overlap_timeout_ms = 50
+    tr.step(data, next_data=data)                        # (returns: the failure is on the device, one step behind on the host)
+    torch.cuda.synchronize()
+    assert int(tr._sig[2]) == tr._sig_host               # sticky word = the value the wait gave up on
+    for a, b in zip(before, (tr.optimizer.flat_p, tr.optimizer.m, tr.optimizer.v)):
+        assert torch.equal(a, b)                         # the update was skipped, not applied to half-written gradients
+    with pytest.raises(RuntimeError, match="timed out"):
+        tr.check_health()
+    with pytest.raises(RuntimeError, match="timed out"):
+        tr.step(data, next_data=data)
+
+
+def test_step_counter_survives_an_aborted_step():
+    """An exception between the device-side increment of the step counter and the optimizer tail used to leave the host's
+    mirror one behind, so the NEXT wait passed at once on the old flag value.  The mirror is re-read from the device after any
+    failed step: the following steps wait for the right number (no timeout, updates applied)."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    model = _make()
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-3, split_optimizer=True)
+    tr.overlap_allreduce, tr.force_comm_wait, tr.overlap_timeout_ms = True, True, 3000
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    tr.step(data, next_data=data)
+    real = tr.loss
+
+    def broken(d):
+        real(d)
+        raise ValueError("injected")
+    tr.loss = broken
+    with pytest.raises(ValueError):
+        tr.step(data, next_data=data)
+    tr.loss = real
+    torch.cuda.synchronize()
+    assert int(tr._sig[0]) == tr._sig_host + 1 and tr._sig_resync
+    p0 = tr.optimizer.flat_p.clone()
+    for _ in range(2):
+        tr.step(data, next_data=data)
+    tr.check_health()
+    assert int(tr._sig[0]) == tr._sig_host == int(tr._sig[1]) and int(tr._sig[2]) == 0
+    assert not torch.equal(p0, tr.optimizer.flat_p)
+
+
+def test_overlapped_tail_zeroes_the_slices_of_parameters_without_a_gradient():
+    """with autograd-assigned gradients the flat bucket is not cleared between steps; a used parameter that gets no
+    gradient in some step must contribute zeros (as FlatGradBucket.pack writes them), not the previous step's reduced values."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    model = _make()
+    tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6, split_optimizer=True)
+    tr.overlap_allreduce = True
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    tr.step(data, next_data=data)
+    i0 = tr._cap_start
+    victims = [0, i0 - 1, i0, len(tr.bucket.params) - 1]       # two on the detector's side of the bucket, two on the captioner's
+    assert all(float(tr.bucket.views[i].abs().max()) > 0 for i in victims)
+    real_tail, real_boundary = tr._overlapped_tail, tr._boundary
+
+    def boundary():
+        for i in victims[2:]:
+            tr.bucket.params[i].grad = None
+        real_boundary()
+
+    def tail(sources):
+        for i in victims[:2]:
+            tr.bucket.params[i].grad = None
+        real_tail(sources)
+    tr._boundary, tr._overlapped_tail = boundary, tail
+    tr.step(data, next_data=data)
+    torch.cuda.synchronize()
+    assert tr.boundary_launches == 2
+    for i in victims:
+        assert float(tr.bucket.views[i].abs().max()) == 0.0
+    others = [v for i, v in enumerate(tr.bucket.views) if i not in victims]
+    assert sum(int(v.abs().max() > 0) for v in others) > len(others) // 2
+
+
+def test_bench_ends_within_seconds_when_one_rank_dies_at_start():
+    """`python bench.py --gpus 2` (the driver's form) with rank 1 exiting before it joins the process group: the launcher polls
+    all ranks, terminates rank 0 (which would sit in init_process_group for the store's 10 - 30 min timeout), prints every
+    rank's last stderr lines and exits non-zero."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SPACAP_SHARE_GPU="1", SPACAP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SPACAP_BENCH_FAIL_RANK="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                          "--batch", "2", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    took = time.time() - t0
+    assert out.returncode != 0
+    assert "rank(s) failed first (rank, exit code): [(1, 1)]" in out.stderr, out.stderr[-2000:]
+    assert "---- rank 0 (exit code -" in out.stderr, out.stderr[-2000:]
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert took < 30, took
+
+
 def test_bench_runs_with_two_ranks_sharing_the_gpu():
     """The multi-rank path of bench.py end to end on a one-GPU box: two ranks launched exactly as the driver does
     (torch.distributed.run), both mapped onto cuda:0 and talking gloo instead of RCCL (test knobs SPACAP_SHARE_GPU /

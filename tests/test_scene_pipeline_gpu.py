@@ -175,19 +175,19 @@ def test_colours_normalised_once_by_default_and_resettable_in_the_parity_mode():
     parity mode normalises once more per visit and ``reset_colors()`` restores the loaded state."""
     fx, _ = load_fixture()
     kw = dict(use_color=True, use_normal=True, use_multiview=False)
-    ds = _device_dataset_feats(fx, 2000, **kw)
-    ds.color_renorm = "once"          # rebuild the colour tensors the way the default does
-    for sc in ds._scenes:
-        sc["color"].copy_(((sc["color0"].double() - ds._mean_rgb) / 256.0).float())
-    g = torch.Generator(device=DEV).manual_seed(1)
-    draws = ds.draw([0], g)
-    a = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
-    b = ds.batch([0], draws=draws)["point_clouds"][..., 3:6]
-    assert torch.equal(a, b) and float(a.abs().max()) <= 1.0
     once = _device_dataset_feats(fx, 2000, color_renorm="once", **kw)      # the default mode keeps no raw copy
     assert all("color0" not in sc for sc in once._scenes)
-    assert torch.equal(once.batch([0], draws=draws)["point_clouds"][..., 3:6], a)
-    ds.color_renorm = "per_access"
+    g = torch.Generator(device=DEV).manual_seed(1)
+    draws = once.draw([0], g)
+    a = once.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
+    b = once.batch([0], draws=draws)["point_clouds"][..., 3:6]
+    assert torch.equal(a, b) and float(a.abs().max()) <= 1.0
+    with pytest.raises(AttributeError):                # the mode is fixed at construction (which copies a scene keeps depends on it)
+        once.color_renorm = "per_access"
+    once.reset_colors()                                # a no-op in this mode, never a KeyError
+    ds = _device_dataset_feats(fx, 2000, **kw)         # the parity mode
+    first = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
+    assert torch.equal(first, a)                       # first visit: (raw - mean) / 256, what "once" serves every time
     c = ds.batch([0], draws=draws)["point_clouds"][..., 3:6].clone()
     assert not torch.equal(a, c)                       # normalised a second time
     ds.reset_colors()
