@@ -7,6 +7,7 @@ Counterpart of the tail of every ``SharedMLP`` layer of the reference (lib/point
 import torch
 from torch.autograd import Function
 
+from . import selections
 from ._native import check, lib
 
 
@@ -35,6 +36,7 @@ class BNReLU(Function):
                 check(lib.spacap_bn_relu_train_f32(z.data_ptr(), B, C, L, float(eps), float(momentum), rm, rv, gamma.data_ptr(),
                                                    beta.data_ptr(), stats.data_ptr(), out.data_ptr(), ws.data_ptr(), st),
                       "spacap_bn_relu_train_f32")
+                selections.visit("bn_relu", gammas=[gamma], zs=[z], stats=[stats], beta=beta)
                 ctx.save_for_backward(z, stats, gamma, beta)
                 ctx.pool_S = 0
                 return out
@@ -52,6 +54,7 @@ class BNReLU(Function):
                 out = torch.empty_like(z)
                 check(lib.spacap_bn_relu_apply_f32(z.data_ptr(), stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), B,
                                                    C, L, out.data_ptr(), st), "spacap_bn_relu_apply_f32")
+                selections.visit("bn_relu", gammas=[gamma], zs=[z], stats=[stats], beta=beta)
                 ctx.save_for_backward(z, stats, gamma, beta)
         ctx.pool_S = int(pool_S) if pool_S else 0
         return out

@@ -195,6 +195,10 @@ class _SAMLP(Function):
                 finalize(2, C3, g3, b3)
                 check(lib.spacap_sa_pool_fwd_f32(z3.data_ptr(), stats[2].data_ptr(), G, S, C3, out.data_ptr(), arg.data_ptr(),
                                                  st), "spacap_sa_pool_fwd_f32")
+        from . import selections
+        if selections.HOOK is not None:    # tests only: see selections.py
+            selections.visit("sa", gammas=[g1, g2, g3], zs=[None if recompute else z1, z2, z3], stats=stats, arg=arg, out=out,
+                             zmax=zmax, dims=(B, N, S))
         ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3 if z3 is not None else zmax, stats[0], stats[1],
                               stats[2], out, arg, zmax if z3 is not None else None)
         ctx.z3_free = z3_free         # the saved "z3" is then zmax (B, N, C3): the arg-max rows' pre-activations
