@@ -666,6 +666,15 @@ int spacap_dense_wgrad_blocks_slabs(long R);
 int spacap_dense_wgrad_blocks_f32(const float *G, long ldg, const float *X, long ldx, long R, int Z, int M, int N, int nslab,
                                   float *part, spacap_stream_t stream);
 
+/* Weight gradient of a row product with MANY rows and a narrow / odd-width result (the feature columns of an SA module's first
+   layer at 7 or 132 input channels, lib/pointnet2/pytorch_utils.py:11-36): part f32 [nslab][M][N], per row slab
+   dW[m][n] = sum_r G[r][m] X[r][n]; G rows of M floats at stride ldg, X rows of N floats at stride ldx, any sizes >= 1.
+   nslab = spacap_dense_wgrad_tall_slabs(R, M, N) or any count >= 1; the caller adds the slabs in order
+   (spacap_sum_slabs_f32, spacap_sa_dw1_assemble_f32). */
+int spacap_dense_wgrad_tall_slabs(long R, int M, int N);
+int spacap_dense_wgrad_tall_f32(const float *G, long ldg, const float *X, long ldx, long R, int M, int N, int nslab, float *part,
+                                spacap_stream_t stream);
+
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
  * a f32 [R,K], Wop[k,n] = trans_w ? W[n,k] (W f32 [CO,K]: y = x W^T) : W[k,n] (W f32 [K,CO]: dx = g W), bias f32 [CO]

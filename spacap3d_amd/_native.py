@@ -108,6 +108,8 @@ SIGNATURES = {
     "spacap_dense_wgrad_small_f32": (_i, [_p, _l, _p, _l, _l, _l, _l, _l, _i, _i, _p, _p, _p]),
     "spacap_dense_wgrad_blocks_slabs": (_i, [_l]),
     "spacap_dense_wgrad_blocks_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _p]),
+    "spacap_dense_wgrad_tall_slabs": (_i, [_l, _i, _i]),
+    "spacap_dense_wgrad_tall_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p]),
     "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
     "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
     "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),

@@ -435,3 +435,100 @@ extern "C" int spacap_dense_wgrad_blocks_f32(const float *G, long ldg, const flo
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
+
+// ---- weight gradient of a row product with MANY rows and a narrow / odd-width result:  dW[m][n] = sum_r G[r][m] X[r][n] -------
+// (the feature columns of a set-abstraction module's first layer when the source points carry 7 or 132 feature channels,
+// BASELINE configs 3 and 4: G = dY [B Np][64], X = the point-major features [B Np][Cf], 320 000 rows into a 64 x Cf matrix;
+// lib/pointnet2/pytorch_utils.py:11-36 -- the first Conv2d of SharedMLP.  Round 4 sent this shape to torch.bmm.)
+// One row slab per workgroup (grid.x), 64 rows of dW per grid.y block, 16 NT columns per grid.z block: 32-row tiles of both
+// operands through LDS with the next tile's loads in flight (coalesced 4-byte loads: rows of 7 or 132 floats are not 16-byte
+// aligned), v_mfma_f32_16x16x4_f32 (exact fp32 products), wave w owns rows 16 w .. 16 w + 15 of the block.  Per-slab partial
+// results [slab][M][N], added in slab order by the caller (spacap_sum_slabs_f32 / spacap_sa_dw1_assemble_f32).
+namespace {
+template <int NT>
+__global__ __launch_bounds__(256) void dense_wgrad_tall_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X, long ldx,
+                                                               long R, int M, int N, float *__restrict__ part) {
+  constexpr int TR = 32, MB = 64, NB = 16 * NT, LG = MB + 4, LX = NB + 4;
+  constexpr int NG = TR * MB / 256, NX = (TR * NB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float s_g[TR * LG];
+  __shared__ __attribute__((aligned(16))) float s_x[TR * LX];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int nslab = gridDim.x, m0 = blockIdx.y * MB, n0 = blockIdx.z * NB;
+  const long ntiles = (R + TR - 1) / TR;
+  const long per = (ntiles + nslab - 1) / nslab, tbeg = (long)blockIdx.x * per, tend = tbeg + per < ntiles ? tbeg + per : ntiles;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float tg[NG], tx[NX];
+  auto fetch = [&](long t) {
+    const long r0 = t * TR;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + 256 * i, j = e / MB, m = e % MB;
+      tg[i] = (t < tend && r0 + j < R && m0 + m < M) ? G[(size_t)(r0 + j) * ldg + m0 + m] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, j = e / NB, n = e % NB;
+      tx[i] = (e < TR * NB && t < tend && r0 + j < R && n0 + n < N) ? X[(size_t)(r0 + j) * ldx + n0 + n] : 0.f;
+    }
+  };
+  fetch(tbeg);
+  for (long t = tbeg; t < tend; ++t) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int e = tid + 256 * i;
+      s_g[(e / MB) * LG + e % MB] = tg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i;
+      if (e < TR * NB) s_x[(e / NB) * LX + e % NB] = tx[i];
+    }
+    __syncthreads();
+    fetch(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < TR / 4; ++ks) {
+      const float a = s_g[(ks * 4 + lg) * LG + w * 16 + l15];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[n] = MFMA16(a, s_x[(ks * 4 + lg) * LX + n * 16 + l15], acc[n]);
+    }
+    __syncthreads();
+  }
+  float *o = part + (size_t)blockIdx.x * M * N;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m0 + w * 16 + 4 * lg + u, c = n0 + n * 16 + l15;
+      if (m < M && c < N) o[(size_t)m * N + c] = acc[n][u];
+    }
+}
+}  // namespace
+
+/* row slabs (= partial results) spacap_dense_wgrad_tall_f32 should be called with for (R, M, N) */
+extern "C" int spacap_dense_wgrad_tall_slabs(long R, int M, int N) {
+  if (R < 1 || M < 1 || N < 1) return 0;
+  const long tiles = (R + 31) / 32, yz = (long)((M + 63) / 64) * ((N + (N <= 16 ? 15 : 143)) / (N <= 16 ? 16 : 144));
+  long n = 512 / yz, cap = (8L << 20) / ((long)M * N);   // <= 32 MB of partial results
+  if (n > cap) n = cap;
+  if (n > tiles / 4) n = tiles / 4;                      // at least four tiles per slab
+  return (int)(n < 1 ? 1 : n);
+}
+
+/* part f32 [nslab][M][N]: per row slab, dW[m][n] = sum_r G[r][m] X[r][n] over the slab's rows (ascending); G rows of M floats at
+   stride ldg, X rows of N floats at stride ldx; any R >= 1, M, N >= 1, nslab >= 1.  The caller adds the slabs in order. */
+extern "C" int spacap_dense_wgrad_tall_f32(const float *G, long ldg, const float *X, long ldx, long R, int M, int N, int nslab, float *part,
+                                           spacap_stream_t stream) {
+  const char *what = "spacap_dense_wgrad_tall_f32";
+  SPACAP_REQUIRE(R >= 1 && M >= 1 && N >= 1 && nslab >= 1 && nslab <= 65535 && ldg >= M && ldx >= N, "%s: bad sizes", what);
+  SPACAP_REQUIRE(G && X && part, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const unsigned gy = (unsigned)((M + 63) / 64);
+  if (N <= 16)
+    hipLaunchKernelGGL(dense_wgrad_tall_kernel<1>, dim3(nslab, gy, 1), dim3(256), 0, s, G, ldg, X, ldx, R, M, N, part);
+  else
+    hipLaunchKernelGGL(dense_wgrad_tall_kernel<9>, dim3(nslab, gy, (unsigned)((N + 143) / 144)), dim3(256), 0, s, G, ldg, X, ldx, R, M, N, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

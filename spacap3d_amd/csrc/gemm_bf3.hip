@@ -1,0 +1,297 @@
+// Tiled split-bf16 ("bf16 x 3") row products for WIDE layers, for gfx950 (MI355X):
+//
+//     out[r, n] = epi( sum_k A[r, k] W[n, k] )          A f32 [R, K], W f32 [N, K] (y = x W^T), out f32 [R, N]
+//
+// Callers: the relation head of the 512-wide / 32-head stress configuration (BASELINE.json config 5; reference
+// models/transformer_captioner.py:319-326, 392-398: Linear(d_model, d_model) - ReLU - Linear(d_model, d_model) - ReLU -
+// Linear(d_model, 9) on all B K K proposal pairs) -- 16 x 512 x 512 = 4.19 M pair rows x 512 x 512 = 2.2 TFLOP per product,
+// which round 4 sent to rocBLAS as fp32 GEMMs (0.85 - 0.98 of the fp32-MFMA peak: matrix bound).  The fused relation kernels
+// (csrc/relation_fused.hip) keep a 128 x 128 weight matrix in registers; a 512 x 512 one (1.5 MB as three bf16 images) has to
+// stream, so this is a classic tiled GEMM instead.
+//
+// Arithmetic: every fp32 operand is x0 + x1 + x2 with three bf16 pieces (24 mantissa bits); a product is the six piece products
+// whose weight is above 2^-24, each exact in the fp32 accumulator of v_mfma_f32_16x16x32_bf16: fp32-equivalent results at 6/16
+// of the fp32-MFMA time (the arithmetic of csrc/relation_fused.hip and csrc/sa_bf3.inc).
+// Organisation: 128 x 128 output tile per workgroup of 4 waves (2 x 2, 64 x 64 each), K in steps of 32.  The WEIGHTS are split
+// once per call into three bf16 images in HBM ([3][N][K], 1.5 MB: L2 resident) and go to LDS as they are; the ACTIVATIONS are
+// read as fp32, split in registers and written to LDS as three images [128][32 + 8] (80-byte rows: conflict-free 16-byte
+// operand reads).  The next step's global loads are in flight while the current step is multiplied (register staging, one LDS
+// buffer, two barriers per step); two workgroups per CU (61 KB of LDS, <= 256 registers) overlap each other's staging and matrix
+// phases.  Workgroup -> tile mapping: the column tiles of one row tile run back to back ON THE SAME XCD (workgroups are dealt
+// round robin to the 8 XCDs), so an activation tile is fetched from HBM once and re-read from that XCD's L2.
+// Epilogues: bias + ReLU (forward); none (data gradient: the consumer masks).  Split over rows for the weight gradient
+//     dW[n, k] = sum_r G[r, n] X[r, k]
+// (contraction over the rows: both operands are staged TRANSPOSED, channel-major bf16 images, so that the matrix cores read 16
+// bytes of consecutive rows per lane); per-slab partial results, added in slab order by the caller.
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = float __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define MFMA_B(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+constexpr int BM = 128, BN = 128, BK = 32, LDS_ROW = BK + 8;   // halfs per LDS row (80 bytes)
+constexpr int IMG = BM * LDS_ROW;                               // one bf16 image of a 128 x 32 tile
+
+__device__ __forceinline__ f32x4 ld4(const float *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+__device__ __forceinline__ void split4(f32x4 v, bf16x4 &p0, bf16x4 &p1, bf16x4 &p2) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const __bf16 h = (__bf16)v[u];
+    const float r = v[u] - (float)h;
+    const __bf16 m = (__bf16)r;
+    p0[u] = h, p1[u] = m, p2[u] = (__bf16)(r - (float)m);
+  }
+}
+
+// W f32 [N][K] (trans == 0) or [K][N] (trans != 0: the image is of W^T) at row stride ldw -> Wp bf16 [3][N][K]
+__global__ __launch_bounds__(256) void gemm_bf3_split_w_kernel(const float *__restrict__ W, long ldw, int N, int K, int trans,
+                                                               __bf16 *__restrict__ Wp) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)N * K) return;
+  const int n = (int)(e / K), k = (int)(e % K);
+  const float v = trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k];
+  const __bf16 h = (__bf16)v;
+  const float r = v - (float)h;
+  const __bf16 m = (__bf16)r;
+  Wp[e] = h, Wp[(size_t)N * K + e] = m, Wp[(size_t)2 * N * K + e] = (__bf16)(r - (float)m);
+}
+
+// logical tile id of a workgroup: consecutive ids on the same XCD (see the header comment)
+__device__ __forceinline__ long xcd_local_id(long bid, long total) {
+  const long per = total / 8;
+  return bid < per * 8 ? (bid % 8) * per + bid / 8 : bid;
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 2) void gemm_bf3_kernel(const float *__restrict__ A, long lda, const __bf16 *__restrict__ Wp,
+                                                          const float *__restrict__ bias, long R, int K, int N,
+                                                          float *__restrict__ out, long ldo) {
+  __shared__ __attribute__((aligned(16))) __bf16 sA[3 * IMG];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[3 * IMG];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int nbn = N / BN;
+  const long L = xcd_local_id(blockIdx.x, gridDim.x);
+  const long row0 = (L / nbn) * BM;
+  const int col0 = (int)(L % nbn) * BN;
+  // staging: two threads per tile row (A) / tile column (B), 16 k each
+  const int srow = tid >> 1, sk = 16 * (tid & 1);
+  const long garow = row0 + srow < R ? row0 + srow : R - 1;
+  const float *ag = A + (size_t)garow * lda + sk;
+  const __bf16 *bg = Wp + (size_t)(col0 + srow) * K + sk;
+  const size_t wimg = (size_t)N * K;
+  f32x4 ra[4];
+  bf16x8 rb[3][2];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = ld4(ag + kt * BK + 4 * i);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[p][i] = *reinterpret_cast<const bf16x8 *>(bg + p * wimg + kt * BK + 8 * i);
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nk = K / BK;
+  fetch(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();   // the previous step's operand reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 p0, p1, p2;
+      split4(ra[i], p0, p1, p2);
+      __bf16 *d = sA + srow * LDS_ROW + sk + 4 * i;
+      *reinterpret_cast<bf16x4 *>(d) = p0;
+      *reinterpret_cast<bf16x4 *>(d + IMG) = p1;
+      *reinterpret_cast<bf16x4 *>(d + 2 * IMG) = p2;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<bf16x8 *>(sB + p * IMG + srow * LDS_ROW + sk + 8 * i) = rb[p][i];
+    __syncthreads();
+    if (kt + 1 < nk) fetch(kt + 1);
+    bf16x8 a[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[mt][p] = *reinterpret_cast<const bf16x8 *>(sA + p * IMG + (64 * wm + 16 * mt + l15) * LDS_ROW + 8 * lg);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(sB + p * IMG + (64 * wn + 16 * nt + l15) * LDS_ROW + 8 * lg);
+      // the six piece products, smallest first; four independent accumulators between two dependent instructions
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = MFMA_B(a[mt][PA[q]], b[PB[q]], acc[mt][nt]);
+    }
+  }
+  // acc[mt][nt][u] = out[row0 + 64 wm + 16 mt + 4 lg + u][col0 + 64 wn + 16 nt + l15]: 64-byte runs per 16 lanes
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int c = col0 + 64 * wn + 16 * nt + l15;
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long r = row0 + 64 * wm + 16 * mt + 4 * lg + u;
+        float v = acc[mt][nt][u] + bv;
+        if (RELU) v = fmaxf(v, 0.f);
+        if (r < R) out[(size_t)r * ldo + c] = v;
+      }
+  }
+}
+
+// ---- weight gradient: part[slab][n][k] = sum over the slab's rows of G[r][n] X[r][k] ------------------------------------------
+// 128 (n) x 128 (k) tile of dW per workgroup, rows in steps of 32 (= the contraction depth of one MFMA).  Both operands arrive
+// row-major (a thread: 16 consecutive channels of one row) and are needed channel-major (a lane: 8 consecutive rows of one
+// channel): the split pieces are written to LDS transposed, two bytes at a time, into [128 channels][32 + 8 rows] images.
+constexpr int LDT_ROW = 32 + 8;   // halfs per channel row of a transposed image (80 bytes: conflict-free 16-byte reads)
+__global__ __launch_bounds__(256, 2) void gemm_bf3_wgrad_kernel(const float *__restrict__ G, long ldg, const float *__restrict__ X, long ldx,
+                                                                long R, int N, int K, float *__restrict__ part) {
+  __shared__ __attribute__((aligned(16))) __bf16 sG[3 * 128 * LDT_ROW];
+  __shared__ __attribute__((aligned(16))) __bf16 sX[3 * 128 * LDT_ROW];
+  constexpr int TIMG = 128 * LDT_ROW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const int wm = w >> 1, wn = w & 1;
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  const int nslab = gridDim.x;
+  const long nsteps = (R + 31) / 32, per = (nsteps + nslab - 1) / nslab;
+  const long sbeg = (long)blockIdx.x * per, send = sbeg + per < nsteps ? sbeg + per : nsteps;
+  // staging: thread = (row tid / 8 of the 32-row step, channel pairs 2 (tid % 8) + 16 i, i < 8): 8-byte loads, 64 contiguous bytes
+  // per 8 lanes; the transposed two-byte LDS writes of a wave then fall into 32 distinct words (channel pitch 20 words: the 8
+  // lanes of a row are 40 words apart, the 8 rows of a wave share 4 words)
+  const int srow = tid >> 3, sq = 2 * (tid & 7);
+  float2 rg[8], rx[8];
+  auto fetch = [&](long s) {
+    const long r = s * 32 + srow;
+    const bool ok = s < send && r < R;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rg[i] = ok ? *reinterpret_cast<const float2 *>(G + (size_t)r * ldg + n0 + sq + 16 * i) : make_float2(0.f, 0.f);
+      rx[i] = ok ? *reinterpret_cast<const float2 *>(X + (size_t)r * ldx + k0 + sq + 16 * i) : make_float2(0.f, 0.f);
+    }
+  };
+  auto put = [&](__bf16 *img, const float2 *v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float x = u ? v[i].y : v[i].x;
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        __bf16 *d = img + (sq + 16 * i + u) * LDT_ROW + srow;
+        d[0] = h, d[TIMG] = m, d[2 * TIMG] = (__bf16)(r1 - (float)m);
+      }
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fetch(sbeg);
+  for (long s = sbeg; s < send; ++s) {
+    __syncthreads();
+    put(sG, rg);
+    put(sX, rx);
+    __syncthreads();
+    fetch(s + 1);
+    bf16x8 a[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[mt][p] = *reinterpret_cast<const bf16x8 *>(sG + p * TIMG + (64 * wm + 16 * mt + l15) * LDT_ROW + 8 * lg);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(sX + p * TIMG + (64 * wn + 16 * nt + l15) * LDT_ROW + 8 * lg);
+      constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = MFMA_B(a[mt][PA[q]], b[PB[q]], acc[mt][nt]);
+    }
+  }
+  float *o = part + (size_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        o[(size_t)(n0 + 64 * wm + 16 * mt + 4 * lg + u) * K + k0 + 64 * wn + 16 * nt + l15] = acc[mt][nt][u];
+}
+
+bool bf3_shape(int K, int N) { return K >= 128 && N >= 128 && K % 128 == 0 && N % 128 == 0 && K <= 4096 && N <= 4096; }
+
+}  // namespace
+
+extern "C" int spacap_gemm_bf3_supported(int K, int N) { return bf3_shape(K, N) ? 1 : 0; }
+
+/* Wp bf16 [3][N][K] (3 N K two-byte elements) = the three split pieces of W [N][K] (trans == 0; row stride ldw) or of the
+   transpose of W [K][N] (trans != 0). */
+extern "C" int spacap_gemm_bf3_split_w_f32(const float *W, long ldw, int N, int K, int trans, void *Wp, spacap_stream_t stream) {
+  const char *what = "spacap_gemm_bf3_split_w_f32";
+  SPACAP_REQUIRE(W && Wp && N >= 1 && K >= 1 && ldw >= (trans ? N : K), "%s: bad arguments", what);
+  hipLaunchKernelGGL(gemm_bf3_split_w_kernel, dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), 0, spacap::as_stream(stream), W, ldw,
+                     N, K, trans, static_cast<__bf16 *>(Wp));
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* out f32 [R][N] (row stride ldo) = A f32 [R][K] (row stride lda, 16-byte aligned rows) W^T (+ bias f32 [N], nullable), then ReLU
+   when relu != 0; Wp from spacap_gemm_bf3_split_w_f32.  K, N multiples of 128; any R >= 0. */
+extern "C" int spacap_gemm_bf3_f32(const float *A, long lda, const void *Wp, const float *bias, long R, int K, int N, int relu, float *out,
+                                   long ldo, spacap_stream_t stream) {
+  const char *what = "spacap_gemm_bf3_f32";
+  SPACAP_REQUIRE(R >= 0 && bf3_shape(K, N) && lda >= K && ldo >= N && lda % 4 == 0, "%s: (R=%ld, K=%d, N=%d) unsupported", what, R, K, N);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(A && Wp && out && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(Wp) & 15) == 0,
+                 "%s: null / unaligned pointer", what);
+  const long tiles = ((R + BM - 1) / BM) * (N / BN);
+  SPACAP_REQUIRE(tiles < 2147483647L, "%s: too many tiles", what);
+  hipStream_t s = spacap::as_stream(stream);
+  if (relu)
+    hipLaunchKernelGGL(gemm_bf3_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, static_cast<const __bf16 *>(Wp), bias, R, K, N, out, ldo);
+  else
+    hipLaunchKernelGGL(gemm_bf3_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, A, lda, static_cast<const __bf16 *>(Wp), bias, R, K, N, out, ldo);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* row slabs (= partial results) of spacap_gemm_bf3_wgrad_f32 for (R, N, K) */
+extern "C" int spacap_gemm_bf3_wgrad_slabs(long R, int N, int K) {
+  if (R < 1 || !bf3_shape(K, N)) return 0;
+  const long steps = (R + 31) / 32, yz = (long)(N / 128) * (K / 128);
+  long n = 1024 / yz, cap = (16L << 20) / ((long)N * K);   // <= 64 MB of partial results
+  if (n > cap) n = cap;
+  if (n > steps / 8) n = steps / 8;
+  return (int)(n < 1 ? 1 : n);
+}
+
+/* part f32 [nslab][N][K]: per row slab, dW[n][k] = sum_r G[r][n] X[r][k] (G f32 [R][N] at stride ldg, X f32 [R][K] at stride
+   ldx, 16-byte aligned rows); the caller adds the slabs in order.  N, K multiples of 128. */
+extern "C" int spacap_gemm_bf3_wgrad_f32(const float *G, long ldg, const float *X, long ldx, long R, int N, int K, int nslab, float *part,
+                                         spacap_stream_t stream) {
+  const char *what = "spacap_gemm_bf3_wgrad_f32";
+  SPACAP_REQUIRE(R >= 1 && bf3_shape(K, N) && nslab >= 1 && nslab <= 65535 && ldg >= N && ldx >= K && ldg % 4 == 0 && ldx % 4 == 0,
+                 "%s: (R=%ld, N=%d, K=%d, nslab=%d) unsupported", what, R, N, K, nslab);
+  SPACAP_REQUIRE(G && X && part && ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(X)) & 15) == 0, "%s: null / unaligned pointer", what);
+  hipLaunchKernelGGL(gemm_bf3_wgrad_kernel, dim3(nslab, N / 128, K / 128), dim3(256), 0, spacap::as_stream(stream), G, ldg, X, ldx, R, N, K, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}

@@ -344,18 +344,23 @@ class _SAMLP(Function):
                 if ctx.needs_input_grad[4]:
                     from .linear import dense_product
                     dpm = dense_product(g2, W1, False, col0=3).view_as(pm)    # dY W1[:, 3:]
+                # [rel columns | feature columns] from the two sets of partial results in one launch (the values of the two
+                # slab sums + the concatenation).  Feature partials: the Linear layers' slab kernel for multiples of 128
+                # channels (SA2 - SA4), else the tall-and-narrow kernel (SA1 with 7 / 132 feature channels: cfg3, cfg4)
+                x2c = x2.contiguous()
                 nslab = int(lib.spacap_linear_wgrad_slabs(B * Np, C1, Cf))
                 if nslab:
-                    # [rel columns | feature columns] from the two sets of partial results in one launch (the values of the two
-                    # slab sums + the concatenation)
                     pf = torch.empty(nslab, C1 * Cf, **f32)
-                    check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.contiguous().data_ptr(), B * Np, C1, Cf, 0, pf.data_ptr(), st),
+                    check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2c.data_ptr(), B * Np, C1, Cf, 0, pf.data_ptr(), st),
                           "spacap_linear_wgrad_f32")
-                    dW1 = torch.empty(C1, 3 + Cf, **f32)
-                    check(lib.spacap_sa_dw1_assemble_f32(pw1.data_ptr(), nparts, pf.data_ptr(), nslab, C1, Cf, dW1.data_ptr(), st),
-                          "spacap_sa_dw1_assemble_f32")
                 else:
-                    dW1 = torch.cat([sum_slabs(pw1)[:, :3], _feature_weight_gradient(g2, x2)], 1)
+                    nslab = int(lib.spacap_dense_wgrad_tall_slabs(B * Np, C1, Cf))
+                    pf = torch.empty(nslab, C1 * Cf, **f32)
+                    check(lib.spacap_dense_wgrad_tall_f32(g2.data_ptr(), C1, x2c.data_ptr(), Cf, B * Np, C1, Cf, nslab, pf.data_ptr(), st),
+                          "spacap_dense_wgrad_tall_f32")
+                dW1 = torch.empty(C1, 3 + Cf, **f32)
+                check(lib.spacap_sa_dw1_assemble_f32(pw1.data_ptr(), nparts, pf.data_ptr(), nslab, C1, Cf, dW1.data_ptr(), st),
+                      "spacap_sa_dw1_assemble_f32")
             else:
                 dW1 = sum_slabs(pw1)[:, :W1.shape[1]].contiguous()    # (C1, 4): rel x, y, z, inline feature
             dxyz = dnew = None
@@ -389,29 +394,6 @@ def supported(mlp_module, nsample):
         return False   # cumulative-average running statistics need the batch count on the host: per-operator path
     c = [l.conv.out_channels for l in layers]
     return bool(lib.spacap_sa_mlp_supported(*c)) and 1 <= nsample <= 255
-
-
-def _feature_weight_gradient(g2, x2):
-    """dW_f = g2^T x2 for g2 (R, C1) = the gradient of Y = F W1[:, 3:]^T and x2 (R, Cf) = the point-major source features F.
-    The reduction runs over all R = B*Np source points into a small (C1, Cf) matrix: the BLAS heuristics run that without
-    a K split (96 us at SA2) -> the slab kernel of the Linear layers (csrc/sa_mlp.hip: linear_wgrad_kernel, ~15 us) for
-    multiples of 128 channels, else (cfg3: 7, cfg4: 132 input channels) 64 row slabs as one batched GEMM + an ordered sum
-    -- one long fp32 accumulation of a gradient that sums to ~0 per channel (BatchNorm) would also lose digits."""
-    R, C1 = g2.shape
-    Cf = x2.shape[1]
-    x2 = x2.contiguous()
-    nslab = int(lib.spacap_linear_wgrad_slabs(R, C1, Cf))
-    if nslab:
-        with torch.cuda.device(g2.device):
-            part = torch.empty(nslab, C1 * Cf, dtype=torch.float32, device=g2.device)
-            check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2.data_ptr(), R, C1, Cf, 0, part.data_ptr(),
-                                              torch.cuda.current_stream(g2.device).cuda_stream), "spacap_linear_wgrad_f32")
-        return sum_slabs(part).view(C1, Cf)
-    S = 64
-    if R % S == 0 and R >= 64 * S:
-        pw = torch.bmm(g2.view(S, R // S, C1).transpose(1, 2), x2.view(S, R // S, Cf))
-        return sum_slabs(pw.view(S, C1 * Cf) if (C1 * Cf) % 4 == 0 else pw).view(C1, Cf)
-    return g2.t() @ x2
 
 
 def rows_index(idx, Np):

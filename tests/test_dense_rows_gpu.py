@@ -81,3 +81,31 @@ def test_relation_value_projection_per_head(lin, B, K):
     U.backward(go)
     ref.backward(go.double())
     assert _rel(qkv.grad, q64.grad) < 1e-5 and _rel(W1.grad, w64.grad) < 1e-5
+
+
+@pytest.mark.parametrize("R,M,N", [(320000, 64, 7), (320000, 64, 132), (5000, 64, 1), (1234, 100, 145), (37, 3, 16), (40000, 64, 17)])
+def test_tall_weight_gradient_of_a_narrow_product(R, M, N):
+    """spacap_dense_wgrad_tall_f32: dW = G^T X over many rows into a small, odd-width matrix -- the feature columns of SA1's first
+    layer at 7 / 132 input channels (BASELINE configs 3 / 4; lib/pointnet2/pytorch_utils.py:11-36), which round 4 still sent to
+    torch.bmm.  Per-slab partial results summed in slab order; against float64, 1e-5 of the result's scale (one fp32
+    accumulation per slab of a few hundred rows)."""
+    from spacap3d_amd._native import check, lib, sum_slabs
+    g = torch.Generator().manual_seed(R + N)
+    G = torch.randn(R, M, generator=g).to(DEV)
+    X = (torch.randn(R, N, generator=g) + 0.3).to(DEV)
+    nslab = int(lib.spacap_dense_wgrad_tall_slabs(R, M, N))
+    assert nslab >= 1
+    for ns in {nslab, 1, 3}:
+        part = torch.full((ns, M * N), float("nan"), device=DEV)
+        check(lib.spacap_dense_wgrad_tall_f32(G.data_ptr(), M, X.data_ptr(), N, R, M, N, ns, part.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "spacap_dense_wgrad_tall_f32")
+        got = part.double().sum(0).view(M, N)
+        ref = G.double().t() @ X.double()
+        assert _rel(got, ref) < (1e-5 if ns > 1 or R < 50000 else 2e-4), (ns, _rel(got, ref))
+    # strided operands (a column window of wider rows)
+    Gw, Xw = torch.randn(R, M + 5, generator=g).to(DEV), torch.randn(R, N + 3, generator=g).to(DEV)
+    part = torch.empty(nslab, M * N, device=DEV)
+    check(lib.spacap_dense_wgrad_tall_f32(Gw.data_ptr(), M + 5, Xw.data_ptr(), N + 3, R, M, N, nslab, part.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "spacap_dense_wgrad_tall_f32")
+    ref = Gw[:, :M].double().t() @ Xw[:, :N].double()
+    assert _rel(part.double().sum(0).view(M, N), ref) < 1e-5

@@ -606,19 +606,35 @@ def test_gradient_slots_are_scoped_to_the_step_and_accumulation_outside_it_is_pl
     assert not bad, bad[:8]
 
 
-def test_no_library_gemm_or_convolution_kernel_inside_a_training_step():
-    """Round 4: every dense product of the default model's training step is one of this repository's kernels -- no rocBLAS
-    (`Cijk_*`), MIOpen (`naive_conv*`, `miopen*`) or hipBLASLt kernel is launched between the start of a step and the end of
-    its optimizer update (vote / proposal / FP / position nets: models/voting_module.py:28-61, models/proposal_module.py:46-54,
+NO_LIBRARY_CASES = {
+    # BASELINE.json configs at small batch / few points: widths (which decide the kernels) as in bench.py's CFG table
+    "cfg2": dict(feats=dict(), model=dict(), points=8192),
+    "cfg3": dict(feats=dict(use_color=True, use_normal=True), model=dict(), points=8192),
+    "cfg4": dict(feats=dict(use_multiview=True, use_normal=True), model=dict(), points=8192),
+    "cfg5": dict(feats=dict(), model=dict(d_model=512, h=32, num_proposal=512), points=8192),
+}
+# cfg5's relation head at 512 hidden channels / 32 heads still runs layers 2 - 3 as library GEMMs (csrc/relation.hip path)
+NO_LIBRARY_XFAIL = {"cfg5"}
+
+
+@pytest.mark.parametrize("cfg", sorted(NO_LIBRARY_CASES))
+def test_no_library_gemm_or_convolution_kernel_inside_a_training_step(cfg):
+    """Every dense product of the training step is one of this repository's kernels -- no rocBLAS (`Cijk_*`), MIOpen
+    (`naive_conv*`, `miopen*`) or hipBLASLt kernel is launched between the start of a step and the end of its optimizer update
+    (vote / proposal / FP / position nets: models/voting_module.py:28-61, models/proposal_module.py:46-54,
     lib/pointnet2/pointnet2_modules.py:376-421, models/transformer_captioner.py:149-164; vocabulary projection :93-100; the SA
-    modules' first-layer feature product).  Checked on the kernel names of one eager step under torch.profiler."""
+    modules' first-layer feature product and its weight gradient at 1 / 7 / 132 input channels).  Checked on the kernel names of
+    one eager step under torch.profiler, for the model of every BASELINE config."""
     from torch.profiler import ProfilerActivity, profile
     from spacap3d_amd.engine import Trainer, synthetic_batch
     from spacap3d_amd.spacapnet import build_default
+    case = NO_LIBRARY_CASES[cfg]
     torch.manual_seed(0)
-    model = build_default(vocab_size=3001, num_proposal=256).to(DEV).train()     # the benchmark's model (widths matter here)
+    kw = dict(vocab_size=3001, num_proposal=256, input_feature_dim=S.num_extra_channels(**case["feats"]))
+    kw.update(case["model"])
+    model = build_default(**kw).to(DEV).train()     # the benchmark's model (widths matter here)
     tr = Trainer(model, S.mean_size_arr().numpy())
-    data = synthetic_batch(2, 8192, DEV, seed=1)
+    data = synthetic_batch(2, case["points"], DEV, seed=1, **case["feats"])
     for _ in range(2):
         tr.step(data, next_data=data)
     torch.cuda.synchronize()
@@ -629,5 +645,9 @@ def test_no_library_gemm_or_convolution_kernel_inside_a_training_step():
     assert len(names) > 100, len(names)     # the profiler saw the step's kernels
     bad = [n for n in names if n.startswith("Cijk_") or "naive_conv" in n or "miopen" in n.lower() or "hipblaslt" in n.lower()
            or "rocblas" in n.lower()]
+    if cfg in NO_LIBRARY_XFAIL and bad:
+        pytest.xfail(f"{cfg}: {len(bad)} library kernel names left: {bad[:3]}")
     assert not bad, bad
     assert any("conv1x1_cm_kernel" in n for n in names) and any("dense_rows_kernel" in n for n in names)
+    if cfg in ("cfg3", "cfg4"):
+        assert any("dense_wgrad_tall_kernel" in n for n in names)
