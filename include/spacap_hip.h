@@ -675,6 +675,28 @@ int spacap_dense_wgrad_tall_slabs(long R, int M, int N);
 int spacap_dense_wgrad_tall_f32(const float *G, long ldg, const float *X, long ldx, long R, int M, int N, int nslab, float *part,
                                 spacap_stream_t stream);
 
+/* ---- wide layers on the matrix cores as split-bf16 ("bf16 x 3", fp32-equivalent) tiled products (csrc/gemm_bf3.hip) ----------
+ * The relation head of the 512-wide / 32-head stress configuration (models/transformer_captioner.py:319-326, 392-398 at
+ * d_model = 512) and the Transformer's Linear layers at that width.  K, N multiples of 128 (spacap_gemm_bf3_supported).
+ *   spacap_gemm_bf3_split_w_f32   Wp bf16 [3][N][K] = the three bf16 pieces of W f32 [N][K] (trans == 0, row stride ldw) or of the
+ *                                 transpose of W f32 [K][N] (trans != 0); 3 N K two-byte elements
+ *   spacap_gemm_bf3_f32           out f32 [R][N] (stride ldo) = A f32 [R][K] (stride lda) W^T + bias (nullable), ReLU when relu != 0
+ *   spacap_gemm_bf3_wgrad_f32     part f32 [nslab][N][K]: per row slab dW[n][k] = sum_r G[r][n] X[r][k]; the caller adds the slabs
+ *                                 in order; nslab = spacap_gemm_bf3_wgrad_slabs(R, N, K) or any count >= 1 */
+int spacap_gemm_bf3_supported(int K, int N);
+int spacap_gemm_bf3_split_w_f32(const float *W, long ldw, int N, int K, int trans, void *Wp, spacap_stream_t stream);
+int spacap_gemm_bf3_f32(const float *A, long lda, const void *Wp, const float *bias, long R, int K, int N, int relu, float *out, long ldo,
+                        spacap_stream_t stream);
+int spacap_gemm_bf3_wgrad_slabs(long R, int N, int K);
+int spacap_gemm_bf3_wgrad_f32(const float *G, long ldg, const float *X, long ldx, long R, int N, int K, int nslab, float *part,
+                              spacap_stream_t stream);
+/* Tail of the relation head's backward at any width C (C / 4 divides 256): dz2 f32 [R,C] = (dpred f32 [R,9] W3 f32 [9,C]) where
+ * hid2 f32 [R,C] > 0, and per-workgroup partial sums part f32 [nparts][9 C + C + 16] = dW3 [9][C] | db2 [C] | db3 [9 (+7 pad)]. */
+int spacap_rel_wide_tail_supported(int C);
+int spacap_rel_wide_tail_nparts(long R);
+int spacap_rel_wide_tail_bwd_f32(const float *dpred, const float *W3, const float *hid2, long R, int C, int nparts, float *dz2, float *part,
+                                 spacap_stream_t stream);
+
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with
  * a f32 [R,K], Wop[k,n] = trans_w ? W[n,k] (W f32 [CO,K]: y = x W^T) : W[k,n] (W f32 [K,CO]: dx = g W), bias f32 [CO]

@@ -110,6 +110,14 @@ SIGNATURES = {
     "spacap_dense_wgrad_blocks_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_dense_wgrad_tall_slabs": (_i, [_l, _i, _i]),
     "spacap_dense_wgrad_tall_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p]),
+    "spacap_gemm_bf3_supported": (_i, [_i, _i]),
+    "spacap_gemm_bf3_split_w_f32": (_i, [_p, _l, _i, _i, _i, _p, _p]),
+    "spacap_gemm_bf3_f32": (_i, [_p, _l, _p, _p, _l, _i, _i, _i, _p, _l, _p]),
+    "spacap_gemm_bf3_wgrad_slabs": (_i, [_l, _i, _i]),
+    "spacap_gemm_bf3_wgrad_f32": (_i, [_p, _l, _p, _l, _l, _i, _i, _i, _p, _p]),
+    "spacap_rel_wide_tail_supported": (_i, [_i]),
+    "spacap_rel_wide_tail_nparts": (_i, [_l]),
+    "spacap_rel_wide_tail_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p]),
     "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
     "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
     "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),

@@ -236,6 +236,90 @@ __global__ __launch_bounds__(256, 2) void gemm_bf3_wgrad_kernel(const float *__r
         o[(size_t)(n0 + 64 * wm + 16 * mt + 4 * lg + u) * K + k0 + 64 * wn + 16 * nt + l15] = acc[mt][nt][u];
 }
 
+// ---- tail of the relation head's backward at any width C (multiple of 4, C / 4 dividing 256):
+//   dz2 = (dpred W3) * [hid2 > 0],  dW3 = dpred^T hid2,  db2 = sum dz2,  db3 = sum dpred
+// (models/transformer_captioner.py:319-326: the last Linear(C, 9) and the ReLU in front of it).  One pass over hid2 -> dz2,
+// 9 multiply-adds per element each way, HBM bound; per-workgroup partial sums [9 C | C | 16], added in order by the caller.
+constexpr int WT_NO = 9, WT_TM = 64;
+__global__ __launch_bounds__(256) void rel_wide_tail_bwd_kernel(const float *__restrict__ dpred, const float *__restrict__ W3,
+                                                                const float *__restrict__ hid2, long R, int C, float *__restrict__ dz2,
+                                                                float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int C4 = C / 4, RG = 256 / C4;           // row groups of the workgroup
+  float *s_dp = smem;                            // [WT_TM][9]
+  float *s_red = smem + WT_TM * WT_NO;           // [RG][C4][41]
+  const int tid = threadIdx.x, c4 = tid % C4, r0 = tid / C4;
+  float w3[WT_NO][4], aw[WT_NO][4], ab2[4] = {0.f, 0.f, 0.f, 0.f}, ab3[WT_NO];
+#pragma unroll
+  for (int o = 0; o < WT_NO; ++o) {
+    ab3[o] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[o][u] = W3[(size_t)o * C + c4 * 4 + u], aw[o][u] = 0.f;
+  }
+  const long ntiles = (R + WT_TM - 1) / WT_TM;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long row0 = t * WT_TM;
+    __syncthreads();
+    for (int i = tid; i < WT_TM * WT_NO; i += 256) s_dp[i] = (row0 * WT_NO + i < R * WT_NO) ? dpred[row0 * WT_NO + i] : 0.f;
+    __syncthreads();
+    for (int row = r0; row < WT_TM; row += RG) {
+      if (row0 + row >= R) break;
+      const f32x4 h = ld4(hid2 + (size_t)(row0 + row) * C + c4 * 4);
+      float d[WT_NO];
+#pragma unroll
+      for (int o = 0; o < WT_NO; ++o) d[o] = s_dp[row * WT_NO + o];
+      f32x4 dz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < WT_NO; ++o)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          dz[u] = __builtin_fmaf(d[o], w3[o][u], dz[u]);
+          aw[o][u] = __builtin_fmaf(d[o], h[u], aw[o][u]);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        dz[u] = h[u] > 0.f ? dz[u] : 0.f;
+        ab2[u] += dz[u];
+      }
+      *reinterpret_cast<f32x4 *>(dz2 + (size_t)(row0 + row) * C + c4 * 4) = dz;
+      if (c4 == 0) {
+#pragma unroll
+        for (int o = 0; o < WT_NO; ++o) ab3[o] += d[o];
+      }
+    }
+  }
+  __syncthreads();
+  float *mine = &s_red[(size_t)(r0 * C4 + c4) * 41];
+#pragma unroll
+  for (int o = 0; o < WT_NO; ++o)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mine[o * 4 + u] = aw[o][u];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mine[36 + u] = ab2[u];
+  if (c4 == 0) {
+#pragma unroll
+    for (int o = 0; o < WT_NO; ++o) s_dp[r0 * 16 + o] = ab3[o];   // (s_dp is free now)
+  }
+  __syncthreads();
+  const size_t PW = (size_t)WT_NO * C + C + 16;
+  float *o_part = part + (size_t)blockIdx.x * PW;
+  for (int i = tid; i < C4 * 40; i += 256) {
+    const int q = i / 40, e = i % 40;
+    float a = 0.f;
+    for (int g = 0; g < RG; ++g) a += s_red[(size_t)(g * C4 + q) * 41 + e];
+    if (e < 36) o_part[(size_t)(e >> 2) * C + q * 4 + (e & 3)] = a;
+    else o_part[(size_t)WT_NO * C + q * 4 + (e - 36)] = a;
+  }
+  if (tid < 16) {
+    float a = 0.f;
+    if (tid < WT_NO)
+      for (int g = 0; g < RG; ++g) a += s_dp[g * 16 + tid];
+    o_part[(size_t)WT_NO * C + C + tid] = a;
+  }
+}
+
+bool wide_tail_shape(int C) { return C >= 16 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }
+
 bool bf3_shape(int K, int N) { return K >= 128 && N >= 128 && K % 128 == 0 && N % 128 == 0 && K <= 4096 && N <= 4096; }
 
 }  // namespace
@@ -292,6 +376,24 @@ extern "C" int spacap_gemm_bf3_wgrad_f32(const float *G, long ldg, const float *
                  "%s: (R=%ld, N=%d, K=%d, nslab=%d) unsupported", what, R, N, K, nslab);
   SPACAP_REQUIRE(G && X && part && ((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(X)) & 15) == 0, "%s: null / unaligned pointer", what);
   hipLaunchKernelGGL(gemm_bf3_wgrad_kernel, dim3(nslab, N / 128, K / 128), dim3(256), 0, spacap::as_stream(stream), G, ldg, X, ldx, R, N, K, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* ---- tail of the relation head's backward at any width (see rel_wide_tail_bwd_kernel) ---------------------------------------
+   dpred f32 [R,9], W3 f32 [9,C], hid2 f32 [R,C] -> dz2 f32 [R,C], part f32 [nparts][9 C + C + 16] (dW3 | db2 | db3). */
+extern "C" int spacap_rel_wide_tail_supported(int C) { return wide_tail_shape(C) ? 1 : 0; }
+extern "C" int spacap_rel_wide_tail_nparts(long R) {
+  const long tiles = (R + WT_TM - 1) / WT_TM;
+  const long g = 4L * spacap::device_cus();
+  return (int)(tiles < g ? (tiles < 1 ? 1 : tiles) : g);
+}
+extern "C" int spacap_rel_wide_tail_bwd_f32(const float *dpred, const float *W3, const float *hid2, long R, int C, int nparts, float *dz2,
+                                            float *part, spacap_stream_t stream) {
+  const char *what = "spacap_rel_wide_tail_bwd_f32";
+  SPACAP_REQUIRE(dpred && W3 && hid2 && dz2 && part && R >= 1 && nparts >= 1 && wide_tail_shape(C), "%s: bad arguments (C=%d)", what, C);
+  const size_t lds = sizeof(float) * ((size_t)WT_TM * WT_NO + (size_t)256 * 41);
+  hipLaunchKernelGGL(rel_wide_tail_bwd_kernel, dim3(nparts), dim3(256), lds, spacap::as_stream(stream), dpred, W3, hid2, R, C, dz2, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

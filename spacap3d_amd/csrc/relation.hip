@@ -201,16 +201,17 @@ __global__ __launch_bounds__(256) void relation_l1_bwd_kernel(const float *__res
   }
   *reinterpret_cast<f32x4 *>(&s_mem[jj * C + c4 * 4]) = db;
   __syncthreads();
-  if (threadIdx.x < C) {
+  for (int c = threadIdx.x; c < C; c += 256) {   // (C = 512: two channels per thread)
     float s = 0.f;
-    for (int r = 0; r < RPI; ++r) s += s_mem[r * C + threadIdx.x];
-    db_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C + threadIdx.x] = s;
+    for (int r = 0; r < RPI; ++r) s += s_mem[r * C + c];
+    db_part[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C + c] = s;
   }
 }
 
 bool l1_shape_ok(int H, int K, int C) {
-  return (H == 4 || H == 8 || H == 16 || H == 32) && K >= 1 && C % 4 == 0 && C >= 16 && C <= 256 && 256 % (C / 4) == 0 &&
-         (C / 4) <= 64 && (256 / (C / 4)) * H <= 256;
+  // (C = 512 / H = 32, the stress configuration: 128 threads per key column, two key columns per workgroup)
+  return (H == 4 || H == 8 || H == 16 || H == 32) && K >= 1 && C % 4 == 0 && C >= 16 && C <= 512 && 256 % (C / 4) == 0 &&
+         (C / 4) <= 128 && (256 / (C / 4)) * H <= 256;
 }
 
 }  // namespace
@@ -246,8 +247,15 @@ extern "C" int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, con
   dim3 grid((K + RPI - 1) / RPI, B, L1_ISPLIT);
   hipStream_t s = spacap::as_stream(stream);
   const size_t lds = sizeof(float) * (256 * (C / 4 + 1) > RPI * C ? 256 * (C / 4 + 1) : RPI * C);
-#define L1B(HV) if (H == HV) hipLaunchKernelGGL((relation_l1_bwd_kernel<HV>), grid, dim3(256), lds, s, dH1, H1, P, U, K, C, dP, dU, db_part);
-  L1B(4) L1B(8) L1B(16) L1B(32)
+  static unsigned long long lds_ok[4] = {0, 0, 0, 0};
+#define L1B(HV, SLOT)                                                                                                         \
+  if (H == HV) {                                                                                                              \
+    if (lds > 65536)                                                                                                          \
+      SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&relation_l1_bwd_kernel<HV>), 160 * 1024 - 512, \
+                                                 lds_ok[SLOT]), "spacap_relation_l1_bwd_f32");                                \
+    hipLaunchKernelGGL((relation_l1_bwd_kernel<HV>), grid, dim3(256), lds, s, dH1, H1, P, U, K, C, dP, dU, db_part);          \
+  }
+  L1B(4, 0) L1B(8, 1) L1B(16, 2) L1B(32, 3)
 #undef L1B
   SPACAP_CHECK_LAUNCH("spacap_relation_l1_bwd_f32");
   return SPACAP_OK;

@@ -38,20 +38,67 @@ def use_rows(R, K, CO):
 _ROWS_RULE = lambda R, K, CO: R <= 512
 
 
+def bf3_pieces(W, trans=False):
+    """The three bf16 pieces of W (N, K) -- or of W^T when ``trans`` (W is then (K, N)) -- as one bf16 tensor (3, N, K): the weight
+    operand of ``bf3_product`` (csrc/gemm_bf3.hip: split once per call, 1.5 MB for a 512 x 512 matrix)."""
+    W = W.contiguous()
+    N, K = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+    dev = W.device
+    with torch.cuda.device(dev):
+        Wp = torch.empty(3, N, K, dtype=torch.bfloat16, device=dev)
+        check(lib.spacap_gemm_bf3_split_w_f32(W.data_ptr(), W.shape[1], N, K, 1 if trans else 0, Wp.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream), "spacap_gemm_bf3_split_w_f32")
+    return Wp
+
+
+def bf3_product(a2, Wp, bias=None, relu=False, out=None):
+    """out (R, N) = a2 (R, K) W^T (+ bias) (ReLU) with W given as its pieces (bf3_pieces): the tiled split-bf16 kernel
+    (fp32-equivalent arithmetic on the bf16 matrix cores; K, N multiples of 128)."""
+    R, K = a2.shape
+    N = Wp.shape[1]
+    assert a2.is_contiguous() and Wp.shape[2] == K
+    dev = a2.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty(R, N, dtype=torch.float32, device=dev)
+        check(lib.spacap_gemm_bf3_f32(a2.data_ptr(), K, Wp.data_ptr(), bias.data_ptr() if bias is not None else None, R, K, N,
+                                      1 if relu else 0, out.data_ptr(), N, torch.cuda.current_stream(dev).cuda_stream),
+              "spacap_gemm_bf3_f32")
+    return out
+
+
+def _use_bf3(R, K, N):
+    return R >= 1024 and bool(lib.spacap_gemm_bf3_supported(K, N))
+
+
 def _forward_product(x, weight, bias):
-    """x W^T + b: the row-panel kernel where it is the faster one, else the BLAS GEMM."""
+    """x W^T + b on this library's kernels: the row-panel kernel up to 512 rows of a d_model-sized projection, the tiled
+    split-bf16 kernel for tall products of 128-multiples (the 512-wide model), the shape-agnostic fp32-MFMA row product
+    otherwise.  (No BLAS call: tests/test_engine_gpu.py checks every BASELINE config's step for library kernels.)"""
     CO, K = weight.shape
     R = x.numel() // K
-    if x.is_cuda and x.dtype == torch.float32 and use_rows(R, K, CO) and weight.is_contiguous():
-        return rows_product(x.reshape(R, K).contiguous(), weight, bias, True).view(*x.shape[:-1], CO)
+    if x.is_cuda and x.dtype == torch.float32 and weight.is_contiguous():
+        x2 = x.reshape(R, K).contiguous()
+        if use_rows(R, K, CO):
+            out = rows_product(x2, weight, bias, True)
+        elif _use_bf3(R, K, CO):
+            out = bf3_product(x2, bf3_pieces(weight), bias)
+        else:
+            out = dense_product(x2, weight, True, bias=bias)
+        return out.view(*x.shape[:-1], CO)
     return F.linear(x, weight, bias)
 
 
 def _data_gradient(g2, weight):
-    """g2 W for g2 (R, CK) dense and W (CK, CP)."""
+    """g2 W for g2 (R, CK) dense and W (CK, CP); kernels as in _forward_product."""
     R, CK = g2.shape
-    if g2.is_cuda and g2.dtype == torch.float32 and use_rows(R, CK, weight.shape[1]) and weight.is_contiguous():
-        return rows_product(g2.contiguous(), weight, None, False)
+    if g2.is_cuda and g2.dtype == torch.float32 and weight.is_contiguous():
+        g2 = g2.contiguous()
+        if use_rows(R, CK, weight.shape[1]):
+            return rows_product(g2, weight, None, False)
+        if _use_bf3(R, CK, weight.shape[1]):
+            return bf3_product(g2, bf3_pieces(weight, trans=True))
+        return dense_product(g2, weight, False)
     return g2 @ weight
 
 
@@ -378,6 +425,78 @@ class RelationHead(Function):
         return dP, sum_slabs(dU), s[o:o + 128], dW2, s[o + 128:o + 256], dW3, s[o + 256:o + 265]
 
 
+class RelationWide(Function):
+    """The relation head at widths the one-kernel form has no kernel for (the 512-wide / 32-head stress configuration;
+    models/transformer_captioner.py:319-326, 392-397 at d_model = 512), composed of this library's kernels:
+        hid1 = relu(b1 + sum_h P U)            csrc/relation.hip (the pair feature is never formed: U = per-head first Linear of V)
+        hid2 = relu(hid1 W2^T + b2)            csrc/gemm_bf3.hip (tiled split-bf16 product, bias + ReLU in its epilogue)
+        pred = hid2 W3^T + b3                  csrc/dense_rows.hip
+    backward: dz2 / dW3 / db2 / db3 in one pass over hid2 (rel_wide_tail_bwd_kernel), dW2 = dz2^T hid1 and dhid1 = dz2 W2 as
+    split-bf16 products, then the first layer's backward (masks by hid1 > 0 itself).  Three tensors of pair size live between
+    forward and backward (hid1, hid2; dz2 in the backward; dhid1 reuses hid2's memory)."""
+
+    @staticmethod
+    def forward(ctx, P, U, b1, W2, b2, W3, b3):
+        P, U, W2c, W3c = P.contiguous(), U.contiguous(), W2.contiguous(), W3.contiguous()
+        B, H, K, _ = P.shape
+        C = U.shape[-1]
+        dev = P.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            hid1 = torch.empty(B * K * K, C, dtype=torch.float32, device=dev)
+            check(lib.spacap_relation_l1_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), B, H, K, C, hid1.data_ptr(), st),
+                  "spacap_relation_l1_fwd_f32")
+            hid2 = bf3_product(hid1, bf3_pieces(W2c), b2, relu=True)
+            pred = dense_product(hid2, W3c, True, bias=b3)
+        ctx.save_for_backward(P, U, W2c, W3c, hid1, hid2)
+        return pred.view(B, K, K, W3c.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        P, U, W2, W3, hid1, hid2 = ctx.saved_tensors
+        B, H, K, _ = P.shape
+        C = U.shape[-1]
+        NO = W3.shape[0]
+        R = B * K * K
+        dev = P.device
+        st = torch.cuda.current_stream(dev).cuda_stream
+        g2 = g.reshape(R, NO).contiguous()
+        with torch.cuda.device(dev):
+            nparts = int(lib.spacap_rel_wide_tail_nparts(R))
+            part = torch.empty(nparts, NO * C + C + 16, dtype=torch.float32, device=dev)
+            dz2 = torch.empty_like(hid2)
+            check(lib.spacap_rel_wide_tail_bwd_f32(g2.data_ptr(), W3.data_ptr(), hid2.data_ptr(), R, C, nparts, dz2.data_ptr(),
+                                                   part.data_ptr(), st), "spacap_rel_wide_tail_bwd_f32")
+            s = sum_slabs(part, deferrable=True)
+            dW3, db2, db3 = s[:NO * C].view(NO, C), s[NO * C:NO * C + C], s[NO * C + C:NO * C + C + NO]
+            nslab = int(lib.spacap_gemm_bf3_wgrad_slabs(R, C, C))
+            pw = torch.empty(nslab, C * C, dtype=torch.float32, device=dev)
+            check(lib.spacap_gemm_bf3_wgrad_f32(dz2.data_ptr(), C, hid1.data_ptr(), C, R, C, C, nslab, pw.data_ptr(), st),
+                  "spacap_gemm_bf3_wgrad_f32")
+            dW2 = sum_slabs(pw, deferrable=True).view(C, C)
+            dh1 = bf3_product(dz2, bf3_pieces(W2, trans=True), out=hid2)      # hid2 is dead: its memory takes dhid1
+            del dz2
+            dP = torch.empty_like(P)
+            dU = torch.empty(int(lib.spacap_relation_l1_isplit()), *U.shape, dtype=torch.float32, device=dev)
+            pb = torch.empty(int(lib.spacap_relation_l1_blocks(B, K, C)), C, dtype=torch.float32, device=dev)
+            check(lib.spacap_relation_l1_bwd_f32(dh1.data_ptr(), hid1.data_ptr(), P.data_ptr(), U.data_ptr(), B, H, K, C, dP.data_ptr(),
+                                                 dU.data_ptr(), pb.data_ptr(), st), "spacap_relation_l1_bwd_f32")
+        return dP, sum_slabs(dU), sum_slabs(pb), dW2, db2, dW3, db3
+
+
+def relation_head_wide(P, V, lin1, lin2, lin3):
+    """``relation_head`` for widths without the one-kernel form; ``None`` when these kernels do not cover the shape either."""
+    B, H, K, D = V.shape
+    C = lin1.weight.shape[0]
+    if not P.is_cuda or P.dtype != torch.float32 or lin1.bias is None or lin2.bias is None or lin3.bias is None or \
+            tuple(lin1.weight.shape) != (C, H * D) or tuple(lin2.weight.shape) != (C, C) or lin3.weight.shape[1] != C or \
+            lin3.weight.shape[0] != 9 or not lib.spacap_relation_l1_supported(H, K, C) or \
+            not lib.spacap_gemm_bf3_supported(C, C) or not lib.spacap_rel_wide_tail_supported(C):
+        return None
+    U = RelationU.apply(V, lin1.weight)
+    return RelationWide.apply(P, U, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias)
+
+
 def relation_head(P, V, lin1, lin2, lin3):
     """``lin3(relu(lin2(relu(lin1(feature(P, V))))))`` -> (B,K,K,9) through ``RelationHead``; ``None`` when the shape has
     no fused kernel (the caller composes relation_layer1 / relation_tail instead).  P (B,h,K,K), V (B,h,K,d)."""
@@ -385,7 +504,7 @@ def relation_head(P, V, lin1, lin2, lin3):
     if not P.is_cuda or P.dtype != torch.float32 or lin1.bias is None or lin2.bias is None or lin3.bias is None or \
             tuple(lin1.weight.shape) != (128, H * D) or tuple(lin2.weight.shape) != (128, 128) or \
             not lib.spacap_relation_fused_supported(H, K, 128, lin3.weight.shape[0]) or lin3.weight.shape[1] != 128:
-        return None
+        return relation_head_wide(P, V, lin1, lin2, lin3) if torch.is_grad_enabled() or P.is_cuda else None
     U = RelationU.apply(V, lin1.weight)   # (B,K,H,C): the first Linear applied per head to the value vectors
     return RelationHead.apply(P, U, lin1.bias, lin2.weight, lin2.bias, lin3.weight, lin3.bias)
 

@@ -412,7 +412,13 @@ def test_relation_head_one_kernel_each_way(B, K):
                 assert float((d > 5e-5).double().mean()) < 5e-3 and float(d.max()) < 0.1, (n, float(d.max()))
             else:
                 assert float(d.max()) < 5e-3, (n, float(d.max()))
-    assert relation_head(Pg[:, :, :K - 1, :K - 1], Vg[:, :, :K - 1], *lins) is None    # K not a multiple of 8
+    # K not a multiple of 8: no one-kernel form; the composition of linear.RelationWide (first-layer kernel + tiled split-bf16
+    # layer 2 + 9-wide layer 3) takes it, same values
+    odd = relation_head(Pg[:, :, :K - 1, :K - 1], Vg[:, :, :K - 1], *lins)
+    with torch.no_grad():
+        f2 = (Pr[:, :, :K - 1, :K - 1].unsqueeze(-1) * Vr[:, :, :K - 1].unsqueeze(2)).permute(0, 2, 3, 1, 4).reshape(B, K - 1, K - 1, H * D)
+        want2 = refs[2](torch.relu(refs[1](torch.relu(refs[0](f2)))))
+    assert odd is not None and float((odd.double().cpu() - want2).abs().max()) < 3e-5
     assert relation_head(Pg, Vg, lins[0], lins[1], torch.nn.Linear(128, 5).to(DEV)) is None
 
 

@@ -11,11 +11,13 @@ from spacap3d_amd.engine import Trainer
 from spacap3d_amd.spacapnet import build_default
 
 dev = torch.device("cuda", 0)
-cfg = B.CFG["cfg2"]
+cfg = B.CFG[os.environ.get("CFG", "cfg2")]
+SMALL = os.environ.get("SMALL") == "1"     # 2 scenes x 8 192 points: call sites only
+ONLY = os.environ.get("ONLY", "")          # e.g. ONLY=mm,conv: only operators whose name contains one of these
 torch.manual_seed(0)
 model = build_default(input_feature_dim=S.num_extra_channels(**cfg["feats"]), num_proposal=cfg["proposals"], **cfg["transformer"]).to(dev).train()
 tr = Trainer(model, S.mean_size_arr().numpy())
-data = B.synthetic_batch(cfg["batch"], cfg["n_points"], dev, seed=1000, **cfg["feats"])
+data = B.synthetic_batch(2 if SMALL else cfg["batch"], 8192 if SMALL else cfg["n_points"], dev, seed=1000, **cfg["feats"])
 for _ in range(3):
     tr.step(data, next_data=data)
 torch.cuda.synchronize()
@@ -29,7 +31,7 @@ class Tracer(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = str(func)
-        if not any(k in name for k in NOKERNEL):
+        if not any(k in name for k in NOKERNEL) and (not ONLY or any(k in name for k in ONLY.split(","))):
             ts = [a for a in list(args) + [out] if isinstance(a, torch.Tensor)]
             if any(t.is_cuda for t in ts):
                 fr = [f for f in traceback.extract_stack() if "spacap3d_amd" in f.filename]
