@@ -696,6 +696,17 @@ int spacap_rel_wide_tail_supported(int C);
 int spacap_rel_wide_tail_nparts(long R);
 int spacap_rel_wide_tail_bwd_f32(const float *dpred, const float *W3, const float *hid2, long R, int C, int nparts, float *dz2, float *part,
                                  spacap_stream_t stream);
+/* First layer of the relation head at wide C on the matrix cores (csrc/gemm_bf3.hip: one workgroup per key column, fp32 MFMA):
+ * hid1 f32 [B,K,K,C] = relu(b1 + sum_h P[b,h,i,j] U[b,j,h,:]) from Pt f32 [B,K,H,K] = P transposed (spacap_rel_wide_transpose_f32
+ * with to_t = 1: out[b,j,h,i] = in[b,h,i,j]; to_t = 0: the inverse), U f32 [B,K,H,C], b1 f32 [C].  Backward: dh1, hid1 -> dPt
+ * f32 [B,K,H,K], dU f32 [B,K,H,C], db_part f32 [B K][C] (one row per key column, added in order by the caller); the ReLU mask
+ * hid1 > 0 is applied here.  H in {8,16,32}, C in {128,256,512} (spacap_rel_wide_l1_supported). */
+int spacap_rel_wide_l1_supported(int H, int K, int C);
+int spacap_rel_wide_transpose_f32(const float *in, float *out, int B, int H, int K, int to_t, spacap_stream_t stream);
+int spacap_rel_wide_l1_fwd_f32(const float *Pt, const float *U, const float *b1, int B, int H, int K, int C, float *hid1,
+                               spacap_stream_t stream);
+int spacap_rel_wide_l1_bwd_f32(const float *dh1, const float *hid1, const float *Pt, const float *U, int B, int H, int K, int C,
+                               float *dPt, float *dU, float *db_part, spacap_stream_t stream);
 
 /* Row-panel product of a d_model-sized projection (replaces nn.Linear's forward / data gradient where the BLAS
  * heuristics are poor, models/transformer_captioner.py:63-99): out[r,n] = sum_k a[r,k] Wop[k,n] (+ bias[n]) with

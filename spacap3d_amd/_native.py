@@ -118,6 +118,10 @@ SIGNATURES = {
     "spacap_rel_wide_tail_supported": (_i, [_i]),
     "spacap_rel_wide_tail_nparts": (_i, [_l]),
     "spacap_rel_wide_tail_bwd_f32": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _p]),
+    "spacap_rel_wide_l1_supported": (_i, [_i, _i, _i]),
+    "spacap_rel_wide_transpose_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "spacap_rel_wide_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "spacap_rel_wide_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
     "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
     "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),

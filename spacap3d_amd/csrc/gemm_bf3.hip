@@ -320,6 +320,201 @@ __global__ __launch_bounds__(256) void rel_wide_tail_bwd_kernel(const float *__r
 
 bool wide_tail_shape(int C) { return C >= 16 && C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0; }
 
+// ---- first layer of the relation head at wide C, forward and backward, on the matrix cores -----------------------------------
+//   hid1[b,i,j,:] = relu(b1 + sum_h P[b,h,i,j] U[b,j,h,:])        (models/transformer_captioner.py:392-397 + the first Linear of
+//   :319-326, factored through U[b,j,h,:] = W1[:, 16 h : 16 h + 16] V[b,h,j,:])
+// csrc/relation.hip does this on the vector pipe with U[b,j] in registers (4 channels per thread): at C = 512 / H = 32 that is
+// 256 registers per thread, one wave per SIMD, and its backward ran 24 ms of the stress configuration's step.  Here one
+// workgroup owns ONE key column (b, j) and walks the queries in tiles of 16, every product on v_mfma_f32_16x16x4_f32 (exact fp32
+// products):      forward   hid1 tile [16 x C]   = Pt_j^T [16 x H] U_j [H x C]
+//                 backward  dP tile [16 x H]     = dz1 [16 x C] U_j^T [C x H]      (each wave a quarter of C, summed through LDS)
+//                           dU_j [H x C]        += Pt_j [H x 16] dz1 [16 x C]      (registers, written once: no partial slabs)
+//                           db1                 += column sums of dz1              (per workgroup partial)
+// with dz1 = dhid1 * [hid1 > 0].  The attention map is read TRANSPOSED, Pt[b,j,h,i] = P[b,h,i,j] (one tiled transposition
+// per direction, 0.5 GB): a key column's [H x K] block is then contiguous instead of 16 384 four-byte reads at stride K.
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// out[((b K + j) H + h) K + i] = in[((b H + h) K + i) K + j]  (to_t != 0)   or the inverse (to_t == 0); 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void rel_wide_transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int H, int K, int to_t) {
+  __shared__ float tile[32][33];
+  const int bh = blockIdx.z, b = bh / H, h = bh % H;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;   // x: the input's fastest index
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  // to_t: input (b,h,i,j): y = i, x = j; output (b,j,h,i).   else: input (b,j,h,i): blockIdx.z = b * H + h, y = j, x = i
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int y = y0 + r, x = x0 + tx;
+    if (y < K && x < K)
+      tile[r][tx] = to_t ? in[(((size_t)b * H + h) * K + y) * K + x] : in[(((size_t)b * K + y) * H + h) * K + x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int x = x0 + r, y = y0 + tx;   // output row index x (the input's fast index), fast index y
+    if (y < K && x < K) {
+      if (to_t) out[(((size_t)b * K + x) * H + h) * K + y] = tile[tx][r];
+      else out[(((size_t)b * H + h) * K + x) * K + y] = tile[tx][r];
+    }
+  }
+}
+
+template <int HS, int NT>   // H = 4 HS heads, C = 64 NT channels (each of the 4 waves owns 16 NT of them)
+__global__ __launch_bounds__(256) void rel_wide_l1_fwd_kernel(const float *__restrict__ Pt, const float *__restrict__ U,
+                                                              const float *__restrict__ b1, int K, float *__restrict__ hid1) {
+  constexpr int H = 4 * HS, C = 64 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long bj = blockIdx.x;                 // b * K + j
+  const long b = bj / K;
+  const int j = (int)(bj - b * K);
+  const int cw = w * 16 * NT;
+  const float *uj = U + (size_t)bj * H * C;
+  float uB[NT][HS];
+  f32x4 bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int ks = 0; ks < HS; ++ks) uB[nt][ks] = uj[(size_t)(4 * ks + lg) * C + cw + 16 * nt + l15];
+    const float bv = b1[cw + 16 * nt + l15];
+    bias[nt] = f32x4{bv, bv, bv, bv};
+  }
+  const float *pj = Pt + (size_t)bj * H * K;
+  float a[HS], an[HS];
+#pragma unroll
+  for (int ks = 0; ks < HS; ++ks) an[ks] = l15 < K ? pj[(size_t)(4 * ks + lg) * K + l15] : 0.f;
+  for (int i0 = 0; i0 < K; i0 += 16) {
+#pragma unroll
+    for (int ks = 0; ks < HS; ++ks) a[ks] = an[ks];
+    if (i0 + 16 < K) {
+#pragma unroll
+      for (int ks = 0; ks < HS; ++ks) an[ks] = i0 + 16 + l15 < K ? pj[(size_t)(4 * ks + lg) * K + i0 + 16 + l15] : 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 acc = bias[nt];
+#pragma unroll
+      for (int ks = 0; ks < HS; ++ks) acc = MFMA16(a[ks], uB[nt][ks], acc);
+      // acc[u] = hid1[query i0 + 4 lg + u][channel cw + 16 nt + l15]
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 4 * lg + u;
+        if (i < K) hid1[(((size_t)b * K + i) * K + j) * C + cw + 16 * nt + l15] = fmaxf(acc[u], 0.f);
+      }
+    }
+  }
+}
+
+template <int HS, int NT>
+__global__ __launch_bounds__(256, 2) void rel_wide_l1_bwd_kernel(const float *__restrict__ dh1, const float *__restrict__ hid1,
+                                                                 const float *__restrict__ Pt, const float *__restrict__ U, int K,
+                                                                 float *__restrict__ dPt, float *__restrict__ dU, float *__restrict__ db_part) {
+  constexpr int H = 4 * HS, C = 64 * NT, LDZ = C + 4, NH = (H + 15) / 16, KSW = C / 16;   // KSW: k steps of a wave's channel quarter
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *s_z = smem;                    // [16][LDZ]: dz1 of the tile
+  float *s_dp = smem + 16 * LDZ;        // [4 waves][16 queries][16 NH + 1]
+  constexpr int LDP = 16 * NH + 1;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long bj = blockIdx.x;
+  const long b = bj / K;
+  const int j = (int)(bj - b * K);
+  const int cw = w * 16 * NT;
+  const float *uj = U + (size_t)bj * H * C;
+  // dP: B[k = channel][n = head]: lane (n = l15, k = 4 ks + lg) of the wave's quarter
+  float uP[KSW][NH];
+#pragma unroll
+  for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh) uP[ks][nh] = 16 * nh + l15 < H ? uj[(size_t)(16 * nh + l15) * C + cw + 4 * ks + lg] : 0.f;
+  f32x4 du[NH][NT];
+#pragma unroll
+  for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) du[nh][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // staging: thread = (row tid / (C / 4) + RG * pass, float4 column tid % (C / 4))
+  constexpr int C4 = C / 4, RG = 256 / C4, NP = 16 / RG;
+  const int c4 = tid % C4, r0 = tid / C4;
+  f32x4 db = {0.f, 0.f, 0.f, 0.f};
+  const float *pj = Pt + (size_t)bj * H * K;
+  float *dpj = dPt + (size_t)bj * H * K;
+  for (int i0 = 0; i0 < K; i0 += 16) {
+    __syncthreads();   // the previous tile's readers of s_z / s_dp are done
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int row = r0 + RG * p, i = i0 + row;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (i < K) {
+        const size_t off = (((size_t)b * K + i) * K + j) * C + 4 * c4;
+        g = ld4(dh1 + off);
+        const f32x4 hv = ld4(hid1 + off);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g[u] = hv[u] > 0.f ? g[u] : 0.f;
+      }
+      db += g;
+      *reinterpret_cast<f32x4 *>(s_z + row * LDZ + 4 * c4) = g;
+    }
+    // the attention operand of dU: A[m = head][k = query]: lane (m = l15, k = 4 ks + lg)
+    float pA[NH][4];
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        pA[nh][ks] = (16 * nh + l15 < H && i0 + 4 * ks + lg < K) ? pj[(size_t)(16 * nh + l15) * K + i0 + 4 * ks + lg] : 0.f;
+    __syncthreads();
+    // dP partial of this wave's channel quarter: [16 queries x H]
+    {
+      f32x4 acc[NH];
+#pragma unroll
+      for (int nh = 0; nh < NH; ++nh) acc[nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSW; ++ks) {
+        const float a = s_z[l15 * LDZ + cw + 4 * ks + lg];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) acc[nh] = MFMA16(a, uP[ks][nh], acc[nh]);
+      }
+      // acc[nh][u] = dP[query 4 lg + u][head 16 nh + l15]
+#pragma unroll
+      for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s_dp[(w * 16 + 4 * lg + u) * LDP + 16 * nh + l15] = acc[nh][u];
+    }
+    // dU += Pt_tile dz1
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float bz = s_z[(4 * ks + lg) * LDZ + cw + 16 * nt + l15];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) du[nh][nt] = MFMA16(pA[nh][ks], bz, du[nh][nt]);
+      }
+    }
+    __syncthreads();   // the four partial dP tiles are complete
+    for (int e = tid; e < 16 * H; e += 256) {
+      const int h = e / 16, q = e % 16;      // consecutive threads: consecutive queries of one head (contiguous in dPt)
+      const float v = (s_dp[(0 * 16 + q) * LDP + h] + s_dp[(1 * 16 + q) * LDP + h]) + (s_dp[(2 * 16 + q) * LDP + h] + s_dp[(3 * 16 + q) * LDP + h]);
+      if (i0 + q < K) dpj[(size_t)h * K + i0 + q] = v;
+    }
+  }
+  // du[nh][nt][u] = dU[head 16 nh + 4 lg + u][channel cw + 16 nt + l15]
+  float *duj = dU + (size_t)bj * H * C;
+#pragma unroll
+  for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (16 * nh + 4 * lg + u < H) duj[(size_t)(16 * nh + 4 * lg + u) * C + cw + 16 * nt + l15] = du[nh][nt][u];
+  __syncthreads();
+  *reinterpret_cast<f32x4 *>(s_z + r0 * LDZ + 4 * c4) = db;
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) sacc += s_z[r * LDZ + c];
+    db_part[(size_t)bj * C + c] = sacc;
+  }
+}
+
+bool wide_l1_shape(int H, int K, int C) { return (H == 8 || H == 16 || H == 32) && (C == 128 || C == 256 || C == 512) && K >= 1; }
+
 bool bf3_shape(int K, int N) { return K >= 128 && N >= 128 && K % 128 == 0 && N % 128 == 0 && K <= 4096 && N <= 4096; }
 
 }  // namespace
@@ -394,6 +589,52 @@ extern "C" int spacap_rel_wide_tail_bwd_f32(const float *dpred, const float *W3,
   SPACAP_REQUIRE(dpred && W3 && hid2 && dz2 && part && R >= 1 && nparts >= 1 && wide_tail_shape(C), "%s: bad arguments (C=%d)", what, C);
   const size_t lds = sizeof(float) * ((size_t)WT_TM * WT_NO + (size_t)256 * 41);
   hipLaunchKernelGGL(rel_wide_tail_bwd_kernel, dim3(nparts), dim3(256), lds, spacap::as_stream(stream), dpred, W3, hid2, R, C, dz2, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* ---- first layer of the relation head at wide C on the matrix cores (see rel_wide_l1_*_kernel) ---------------------------------
+   Pt f32 [B,K,H,K] = the attention map transposed (spacap_rel_wide_transpose_f32(P, ..., to_t = 1)), U f32 [B,K,H,C], b1 f32 [C]
+   -> hid1 f32 [B,K,K,C].  Backward: dh1, hid1 f32 [B,K,K,C] -> dPt f32 [B,K,H,K] (transpose back with to_t = 0), dU f32 [B,K,H,C],
+   db_part f32 [B K][C] (per key column; the caller adds the rows in order).  H in {8,16,32}, C in {128,256,512}. */
+extern "C" int spacap_rel_wide_l1_supported(int H, int K, int C) { return wide_l1_shape(H, K, C) ? 1 : 0; }
+extern "C" int spacap_rel_wide_transpose_f32(const float *in, float *out, int B, int H, int K, int to_t, spacap_stream_t stream) {
+  const char *what = "spacap_rel_wide_transpose_f32";
+  SPACAP_REQUIRE(in && out && B >= 1 && H >= 1 && K >= 1 && (long)B * H <= 65535, "%s: bad arguments", what);
+  const unsigned t = (unsigned)((K + 31) / 32);
+  hipLaunchKernelGGL(rel_wide_transpose_kernel, dim3(t, t, (unsigned)(B * H)), dim3(256), 0, spacap::as_stream(stream), in, out, H, K, to_t);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+#define WIDE_L1_DISPATCH(CALL)                                                          \
+  if (H == 8 && C == 128) { CALL(2, 2) } else if (H == 8 && C == 256) { CALL(2, 4) } else if (H == 8 && C == 512) { CALL(2, 8) }   \
+  else if (H == 16 && C == 128) { CALL(4, 2) } else if (H == 16 && C == 256) { CALL(4, 4) } else if (H == 16 && C == 512) { CALL(4, 8) } \
+  else if (H == 32 && C == 128) { CALL(8, 2) } else if (H == 32 && C == 256) { CALL(8, 4) } else { CALL(8, 8) }
+extern "C" int spacap_rel_wide_l1_fwd_f32(const float *Pt, const float *U, const float *b1, int B, int H, int K, int C, float *hid1,
+                                          spacap_stream_t stream) {
+  const char *what = "spacap_rel_wide_l1_fwd_f32";
+  SPACAP_REQUIRE(B >= 0 && wide_l1_shape(H, K, C), "%s: unsupported shape H=%d K=%d C=%d", what, H, K, C);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(Pt && U && b1 && hid1 && (long)B * K < 2147483647L, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+#define CALL(HS, NT) hipLaunchKernelGGL((rel_wide_l1_fwd_kernel<HS, NT>), dim3((unsigned)((long)B * K)), dim3(256), 0, s, Pt, U, b1, K, hid1);
+  WIDE_L1_DISPATCH(CALL)
+#undef CALL
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+extern "C" int spacap_rel_wide_l1_bwd_f32(const float *dh1, const float *hid1, const float *Pt, const float *U, int B, int H, int K, int C,
+                                          float *dPt, float *dU, float *db_part, spacap_stream_t stream) {
+  const char *what = "spacap_rel_wide_l1_bwd_f32";
+  SPACAP_REQUIRE(B >= 0 && wide_l1_shape(H, K, C), "%s: unsupported shape H=%d K=%d C=%d", what, H, K, C);
+  if (B == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(dh1 && hid1 && Pt && U && dPt && dU && db_part && (long)B * K < 2147483647L, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const int NH = (H + 15) / 16;
+  const size_t lds = sizeof(float) * ((size_t)16 * (C + 4) + (size_t)4 * 16 * (16 * NH + 1));
+#define CALL(HS, NT) hipLaunchKernelGGL((rel_wide_l1_bwd_kernel<HS, NT>), dim3((unsigned)((long)B * K)), dim3(256), lds, s, dh1, hid1, Pt, U, K, dPt, dU, db_part);
+  WIDE_L1_DISPATCH(CALL)
+#undef CALL
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -428,7 +428,8 @@ class RelationHead(Function):
 class RelationWide(Function):
     """The relation head at widths the one-kernel form has no kernel for (the 512-wide / 32-head stress configuration;
     models/transformer_captioner.py:319-326, 392-397 at d_model = 512), composed of this library's kernels:
-        hid1 = relu(b1 + sum_h P U)            csrc/relation.hip (the pair feature is never formed: U = per-head first Linear of V)
+        hid1 = relu(b1 + sum_h P U)            csrc/gemm_bf3.hip: rel_wide_l1_* (the pair feature is never formed: U = per-head first
+                                               Linear of V; one workgroup per key column on the matrix cores, P read transposed)
         hid2 = relu(hid1 W2^T + b2)            csrc/gemm_bf3.hip (tiled split-bf16 product, bias + ReLU in its epilogue)
         pred = hid2 W3^T + b3                  csrc/dense_rows.hip
     backward: dz2 / dW3 / db2 / db3 in one pass over hid2 (rel_wide_tail_bwd_kernel), dW2 = dz2^T hid1 and dhid1 = dz2 W2 as
@@ -443,22 +444,24 @@ class RelationWide(Function):
         dev = P.device
         st = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
+            Pt = torch.empty(B, K, H, K, dtype=torch.float32, device=dev)      # Pt[b,j,h,i] = P[b,h,i,j]: a key column's block contiguous
+            check(lib.spacap_rel_wide_transpose_f32(P.data_ptr(), Pt.data_ptr(), B, H, K, 1, st), "spacap_rel_wide_transpose_f32")
             hid1 = torch.empty(B * K * K, C, dtype=torch.float32, device=dev)
-            check(lib.spacap_relation_l1_fwd_f32(P.data_ptr(), U.data_ptr(), b1.data_ptr(), B, H, K, C, hid1.data_ptr(), st),
-                  "spacap_relation_l1_fwd_f32")
+            check(lib.spacap_rel_wide_l1_fwd_f32(Pt.data_ptr(), U.data_ptr(), b1.data_ptr(), B, H, K, C, hid1.data_ptr(), st),
+                  "spacap_rel_wide_l1_fwd_f32")
             hid2 = bf3_product(hid1, bf3_pieces(W2c), b2, relu=True)
             pred = dense_product(hid2, W3c, True, bias=b3)
-        ctx.save_for_backward(P, U, W2c, W3c, hid1, hid2)
+        ctx.save_for_backward(Pt, U, W2c, W3c, hid1, hid2)
         return pred.view(B, K, K, W3c.shape[0])
 
     @staticmethod
     def backward(ctx, g):
-        P, U, W2, W3, hid1, hid2 = ctx.saved_tensors
-        B, H, K, _ = P.shape
+        Pt, U, W2, W3, hid1, hid2 = ctx.saved_tensors
+        B, K, H, _ = Pt.shape
         C = U.shape[-1]
         NO = W3.shape[0]
         R = B * K * K
-        dev = P.device
+        dev = Pt.device
         st = torch.cuda.current_stream(dev).cuda_stream
         g2 = g.reshape(R, NO).contiguous()
         with torch.cuda.device(dev):
@@ -476,12 +479,13 @@ class RelationWide(Function):
             dW2 = sum_slabs(pw, deferrable=True).view(C, C)
             dh1 = bf3_product(dz2, bf3_pieces(W2, trans=True), out=hid2)      # hid2 is dead: its memory takes dhid1
             del dz2
-            dP = torch.empty_like(P)
-            dU = torch.empty(int(lib.spacap_relation_l1_isplit()), *U.shape, dtype=torch.float32, device=dev)
-            pb = torch.empty(int(lib.spacap_relation_l1_blocks(B, K, C)), C, dtype=torch.float32, device=dev)
-            check(lib.spacap_relation_l1_bwd_f32(dh1.data_ptr(), hid1.data_ptr(), P.data_ptr(), U.data_ptr(), B, H, K, C, dP.data_ptr(),
-                                                 dU.data_ptr(), pb.data_ptr(), st), "spacap_relation_l1_bwd_f32")
-        return dP, sum_slabs(dU), sum_slabs(pb), dW2, db2, dW3, db3
+            dPt, dU = torch.empty_like(Pt), torch.empty_like(U)
+            pb = torch.empty(B * K, C, dtype=torch.float32, device=dev)
+            check(lib.spacap_rel_wide_l1_bwd_f32(dh1.data_ptr(), hid1.data_ptr(), Pt.data_ptr(), U.data_ptr(), B, H, K, C, dPt.data_ptr(),
+                                                 dU.data_ptr(), pb.data_ptr(), st), "spacap_rel_wide_l1_bwd_f32")
+            dP = torch.empty(B, H, K, K, dtype=torch.float32, device=dev)
+            check(lib.spacap_rel_wide_transpose_f32(dPt.data_ptr(), dP.data_ptr(), B, H, K, 0, st), "spacap_rel_wide_transpose_f32")
+        return dP, dU, sum_slabs(pb), dW2, db2, dW3, db3
 
 
 def relation_head_wide(P, V, lin1, lin2, lin3):
@@ -490,7 +494,7 @@ def relation_head_wide(P, V, lin1, lin2, lin3):
     C = lin1.weight.shape[0]
     if not P.is_cuda or P.dtype != torch.float32 or lin1.bias is None or lin2.bias is None or lin3.bias is None or \
             tuple(lin1.weight.shape) != (C, H * D) or tuple(lin2.weight.shape) != (C, C) or lin3.weight.shape[1] != C or \
-            lin3.weight.shape[0] != 9 or not lib.spacap_relation_l1_supported(H, K, C) or \
+            lin3.weight.shape[0] != 9 or not lib.spacap_rel_wide_l1_supported(H, K, C) or \
             not lib.spacap_gemm_bf3_supported(C, C) or not lib.spacap_rel_wide_tail_supported(C):
         return None
     U = RelationU.apply(V, lin1.weight)
