@@ -192,6 +192,8 @@ SIGNATURES = {
     "spacap_tf_ffn1_f32": (_i, [_p, _p, _p, _l, _i, _f, _u64, _p, _p, _p]),
     "spacap_tf_ffn_f32": (_i, [_i, _p, _p, _p, _p, _p, _l, _i, _f, _u64, _p, _p, _p, _p]),
     "spacap_decode_attn_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p]),
+    "spacap_decode_word_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
+    "spacap_decode_word_f32": (_i, [_p, _p, _p, _l, _i, _p, _f, _p, _p, _i, _i, _p, _p, _p]),
     "spacap_tf_gemm_splits": (_i, [_l, _i, _i]),
     "spacap_tf_gemm_f32": (_i, [_p, _p, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_tf_dgrad_mask_f32": (_i, [_p, _p, _p, _f, _l, _i, _i, _p, _p]),

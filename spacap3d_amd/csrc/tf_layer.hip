@@ -856,6 +856,138 @@ extern "C" int spacap_decode_attn_f32(const float *qkv, float *kcache, float *vc
   return SPACAP_OK;
 }
 
+// ---- greedy decoding: vocabulary projection + arg-max without the logits, and the next token's embedding ---------------------
+// (models/transformer_captioner.py:93-100 Generator: log_softmax(proj(x)) and :441-447: `_, next_word = torch.max(prob, dim=1)`;
+// the arg-max of the log-softmax is the arg-max of the logits.)  Round 4 ran F.linear on 2 048 x 3 001 logits + torch.argmax for
+// each of the 31 words.  Here a workgroup owns 16 sequences and one slice of the vocabulary: the slice's weight rows go through
+// LDS 64 at a time (next chunk's loads in flight), logits come out of v_mfma_f32_16x16x4_f32 (exact fp32 products) 16 words per
+// wave, and every lane keeps the running (best logit, first index) of its rows; the slices' winners [R][NS] are merged by
+// decode_next_kernel, which also writes the word into the caption and forms the next input row lut[word] sqrt(d) + pe[t].
+constexpr int VA_CHUNK = 64, VA_LD = D + 4;
+__global__ __launch_bounds__(256) void vocab_argmax_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
+                                                           long R, int V, int per_slice, float *__restrict__ best_v, int *__restrict__ best_i) {
+  __shared__ __attribute__((aligned(16))) float s_w[VA_CHUNK * VA_LD];
+  __shared__ float s_bv[4][16][17];
+  __shared__ int s_bi[4][16][17];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long row0 = (long)blockIdx.x * 16;
+  const int ns = gridDim.y, sl = blockIdx.y;
+  const int v_beg = sl * per_slice, v_end = min(V, v_beg + per_slice);
+  // the sequences' rows as the A operand: a[ks] = x[row0 + l15][4 ks + lg]
+  float a[D / 4];
+  {
+    const float *xr = x + (size_t)min(row0 + l15, R - 1) * D + lg;
+#pragma unroll
+    for (int ks = 0; ks < D / 4; ++ks) a[ks] = xr[4 * ks];
+  }
+  float bv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {v_beg, v_beg, v_beg, v_beg};
+  const int c4 = tid & 31, r0 = tid >> 5;   // staging: 32 float4 per weight row, 8 rows per pass
+  f32x4 stg[VA_CHUNK / 8];
+  auto fetch = [&](int v0) {
+#pragma unroll
+    for (int i = 0; i < VA_CHUNK / 8; ++i) {
+      const int v = v0 + r0 + 8 * i;
+      stg[i] = v < v_end ? ld4(W + (size_t)v * D + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  fetch(v_beg);
+  for (int v0 = v_beg; v0 < v_end; v0 += VA_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VA_CHUNK / 8; ++i) st4(&s_w[(r0 + 8 * i) * VA_LD + 4 * c4], stg[i]);
+    __syncthreads();
+    if (v0 + VA_CHUNK < v_end) fetch(v0 + VA_CHUNK);
+    const int v = v0 + 16 * w + l15;                    // this lane's word of the chunk
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+    const float *wr = s_w + (16 * w + l15) * VA_LD + lg;
+#pragma unroll
+    for (int ks = 0; ks < D / 4; ks += 2) {
+      acc = MFMA16(a[ks], wr[4 * ks], acc);
+      acc2 = MFMA16(a[ks + 1], wr[4 * ks + 4], acc2);
+    }
+    if (v < v_end) {
+      const float b = bias[v];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // acc[u] = logit of sequence row0 + 4 lg + u, word v; words arrive in increasing order
+        const float val = (acc[u] + acc2[u]) + b;
+        if (val > bv[u]) bv[u] = val, bi[u] = v;
+      }
+    }
+  }
+  // merge: rows 4 lg + u across the 16 lanes and the 4 waves; ties go to the smaller word index (torch.max: first maximum)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) s_bv[w][4 * lg + u][l15] = bv[u], s_bi[w][4 * lg + u][l15] = bi[u];
+  __syncthreads();
+  if (tid < 16 && row0 + tid < R) {
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int ww = 0; ww < 4; ++ww)
+      for (int l = 0; l < 16; ++l) {
+        const float val = s_bv[ww][tid][l];
+        const int idx = s_bi[ww][tid][l];
+        if (val > m || (val == m && idx < mi)) m = val, mi = idx;
+      }
+    best_v[(size_t)(row0 + tid) * ns + sl] = m;
+    best_i[(size_t)(row0 + tid) * ns + sl] = mi;
+  }
+}
+
+// word[r] = the best of the NS slice winners (first maximum); ys[r][t_out] = word; x[r, :] = lut[word] * scale + pe_row
+__global__ __launch_bounds__(256) void decode_next_kernel(const float *__restrict__ best_v, const int *__restrict__ best_i, int ns, long R,
+                                                          const float *__restrict__ lut, float scale, const float *__restrict__ pe_row,
+                                                          long long *__restrict__ ys, int ys_ld, int t_out, float *__restrict__ x) {
+  const long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int c4 = threadIdx.x & 31;
+  if (r >= R) return;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int s = 0; s < ns; ++s) {
+    const float val = best_v[(size_t)r * ns + s];
+    const int idx = best_i[(size_t)r * ns + s];
+    if (val > m || (val == m && idx < mi)) m = val, mi = idx;
+  }
+  if (c4 == 0) ys[(size_t)r * ys_ld + t_out] = mi;
+  const f32x4 e = ld4(lut + (size_t)mi * D + 4 * c4), p = ld4(pe_row + 4 * c4);
+  st4(x + (size_t)r * D + 4 * c4, f32x4{e[0] * scale + p[0], e[1] * scale + p[1], e[2] * scale + p[2], e[3] * scale + p[3]});
+}
+
+/* One greedy-decoding step's word choice (models/transformer_captioner.py:441-447 with the Generator of :93-100): x f32 [R,128] the
+   decoder's output rows, W f32 [V,128], bias f32 [V] -> ys i64 [R][ys_ld] column t_out = arg-max word (first maximum), and the next
+   step's input rows x_next f32 [R,128] = lut[word] * scale + pe_row (lut f32 [V,128], pe_row f32 [128]).
+   workspace: spacap_decode_word_workspace_bytes(R, V) bytes (the vocabulary slices' winners). */
+namespace {
+inline int va_slices(long R, int V) {
+  const long tiles = (R + 15) / 16;
+  long ns = (4L * spacap::device_cus() + tiles - 1) / tiles;   // ~4 workgroups per CU
+  const long most = (V + VA_CHUNK - 1) / VA_CHUNK;
+  if (ns > most) ns = most;
+  if (ns > 64) ns = 64;
+  return (int)(ns < 1 ? 1 : ns);
+}
+}  // namespace
+extern "C" size_t spacap_decode_word_workspace_bytes(long R, int V) { return R > 0 && V > 0 ? (size_t)R * va_slices(R, V) * 8 : 0; }
+extern "C" int spacap_decode_word_f32(const float *x, const float *W, const float *bias, long R, int V, const float *lut, float scale,
+                                      const float *pe_row, int64_t *ys, int ys_ld, int t_out, float *x_next, void *workspace,
+                                      spacap_stream_t stream) {
+  const char *what = "spacap_decode_word_f32";
+  SPACAP_REQUIRE(R >= 0 && V >= 1 && ys_ld >= 1 && t_out >= 0 && t_out < ys_ld, "%s: bad sizes", what);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(x && W && bias && lut && pe_row && ys && x_next && workspace && al16(x) && al16(W) && al16(lut) && al16(pe_row) && al16(x_next),
+                 "%s: null or unaligned pointer", what);
+  SPACAP_REQUIRE(R <= 16L * 2147483647L, "%s: too many sequences", what);
+  const int ns = va_slices(R, V);
+  const int per = ((V + ns - 1) / ns + VA_CHUNK - 1) / VA_CHUNK * VA_CHUNK;   // whole chunks per slice
+  float *bv = static_cast<float *>(workspace);
+  int *bi = reinterpret_cast<int *>(bv + (size_t)R * ns);
+  hipStream_t s = spacap::as_stream(stream);
+  hipLaunchKernelGGL(vocab_argmax_kernel, dim3((unsigned)((R + 15) / 16), ns), dim3(256), 0, s, x, W, bias, R, V, per, bv, bi);
+  hipLaunchKernelGGL(decode_next_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, s, bv, bi, ns, R, lut, scale, pe_row,
+                     reinterpret_cast<long long *>(ys), ys_ld, t_out, x_next);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // number of K slices that fills the chip with 64 x 128 tiles (a divisor of K / 128)
 extern "C" int spacap_tf_gemm_splits(long R, int K, int N) {
   if (R < 1 || K < 128 || K % 128 || N < 128 || N % 128) return 0;

@@ -442,9 +442,10 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
     (models/transformer_captioner.py:402-453; the reference re-runs encoder and decoder prefix for every word).  Position 0
     is the object indicator token (R, 128), position 1 the start symbol, then every chosen word is fed back; one token per
     sequence per step, four launches per layer and step (the training kernels with dropout off + spacap_decode_attn_f32).
+    The word choice of a step -- vocabulary projection + arg-max + the chosen word's embedding row -- is one library call
+    (csrc/tf_layer.hip: vocab_argmax_kernel / decode_next_kernel: no logits in HBM, no BLAS call).
     Returns the (R, n_words) int64 word ids."""
     import math
-    import torch.nn.functional as F
     layers = list(dec.layers)
     R, dev = indicator.shape[0], indicator.device
     T = n_words + 1
@@ -463,10 +464,16 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
         ys = torch.empty(R, n_words, dtype=torch.long, device=dev)
         sqrt_d = math.sqrt(embed.d_model)
         x = indicator.contiguous()
-        word = torch.full((R,), int(sos), dtype=torch.long, device=dev)
+        lut, gw, gb = embed.lut.weight.contiguous(), generator.proj.weight.contiguous(), generator.proj.bias.contiguous()
+        V = gw.shape[0]
+        pe_rows = pe[0, :T].contiguous()
+        xw = _new(dev, R, D_MODEL)                      # the next step's input rows (written by the word kernel)
+        ws = torch.empty(int(lib.spacap_decode_word_workspace_bytes(R, V)), dtype=torch.uint8, device=dev)
         for t in range(T):
-            if t >= 1:
-                x = embed.lut(word) * sqrt_d + pe[0, t - 1]
+            if t == 1:
+                x = (lut[int(sos)] * sqrt_d + pe_rows[0]).expand(R, D_MODEL).contiguous()   # every sequence starts with <sos>
+            elif t > 1:
+                x = xw
             n0 = layers[0].sublayer[0].norm
             _rows(0, R, dev, res=x, ln_a=n0.a_2, ln_b=n0.b_2, eps=n0.eps, w2=packs[0][0], bias2=packs[0][1], n2=3 * D_MODEL, out2=qkv)
             xres = x
@@ -488,6 +495,8 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
                     _rows(0, R, dev, a1=parts, nparts=S, bias1=ff.w_2.bias, res=x1, ln_a=dec.norm.a_2, ln_b=dec.norm.b_2,
                           eps=dec.norm.eps, n_out=n)
             if t >= 1:
-                word = F.linear(n, generator.proj.weight, generator.proj.bias).argmax(dim=-1)
-                ys[:, t - 1] = word
+                # ys[:, t - 1] = argmax_v (n W^T + b); xw = lut[word] sqrt(d) + pe[t]: the input of step t + 1
+                check(lib.spacap_decode_word_f32(n.data_ptr(), gw.data_ptr(), gb.data_ptr(), R, V, lut.data_ptr(), sqrt_d,
+                                                 pe_rows[min(t, T - 1)].data_ptr(), ys.data_ptr(), n_words, t - 1, xw.data_ptr(),
+                                                 ws.data_ptr(), st), "spacap_decode_word_f32")
     return ys

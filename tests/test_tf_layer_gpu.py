@@ -332,3 +332,35 @@ def test_eval_with_other_head_counts_decodes_through_the_cached_operator_path(tf
         d2 = model.caption.forward_eval(dict(d), use_cache=False)
     assert d["lang_cap"].shape == d2["lang_cap"].shape == (2, 32, 31)
     assert (d["lang_cap"] == d2["lang_cap"]).float().mean() > 0.995
+
+
+@pytest.mark.parametrize("R,V", [(2048, 3001), (37, 40), (16, 64), (300, 1000)])
+def test_decode_word_choice_without_logits(R, V):
+    """spacap_decode_word_f32 (csrc/tf_layer.hip: vocab_argmax_kernel + decode_next_kernel): the greedy word of every sequence
+    = arg-max of x W^T + b (models/transformer_captioner.py:441-447 on the Generator of :93-100; first maximum on ties, as
+    torch.max), written into the caption, and the next input row lut[word] sqrt(d) + pe.  Against float64 logits: the chosen
+    word's logit is within fp32 rounding of the maximum (an exact tie in float64 picks the smaller index)."""
+    import math
+    from spacap3d_amd._native import check, lib
+    g = torch.Generator().manual_seed(R + V)
+    x = torch.randn(R, 128, generator=g).to(DEV)
+    W, b = (0.3 * torch.randn(V, 128, generator=g)).to(DEV), torch.randn(V, generator=g).to(DEV)
+    W[7] = W[3]
+    b[7] = b[3]                                      # two identical words: the first one must win wherever they lead
+    x[0] = 0.0
+    b[3] = b[7] = 50.0                               # ... which they do for row 0 (all-zero input: logits = bias)
+    lut, pe = torch.randn(V, 128, generator=g).to(DEV), torch.randn(128, generator=g).to(DEV)
+    ys = torch.full((R, 5), -1, dtype=torch.long, device=DEV)
+    xn = torch.empty(R, 128, device=DEV)
+    ws = torch.empty(int(lib.spacap_decode_word_workspace_bytes(R, V)), dtype=torch.uint8, device=DEV)
+    scale = math.sqrt(128.0)
+    check(lib.spacap_decode_word_f32(x.data_ptr(), W.data_ptr(), b.data_ptr(), R, V, lut.data_ptr(), scale, pe.data_ptr(), ys.data_ptr(), 5, 2,
+                                     xn.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "spacap_decode_word_f32")
+    word = ys[:, 2]
+    assert int(word[0]) == 3 and bool((ys[:, [0, 1, 3, 4]] == -1).all())
+    logits = x.double() @ W.double().t() + b.double()
+    best = logits.max(1).values
+    chosen = logits.gather(1, word.view(-1, 1)).squeeze(1)
+    assert float((best - chosen).max()) < 1e-4 * float(logits.abs().max())
+    assert float((word == logits.argmax(1)).double().mean()) > 0.995
+    assert torch.allclose(xn, lut[word] * scale + pe, rtol=0, atol=1e-5)
