@@ -827,11 +827,12 @@ int spacap_decode_attn_f32(const float *qkv, float *kcache, float *vcache, long 
                            float *out, spacap_stream_t stream);
 /* One greedy-decoding step's word choice without the logits in HBM (models/transformer_captioner.py:441-447 `torch.max(prob, dim=1)`
  * on the Generator of :93-100; the arg-max of the log-softmax is the arg-max of the logits): x f32 [R,128] = the decoder's output
- * rows, W f32 [V,128], bias f32 [V] -> ys i64 [R][ys_ld] column t_out = the arg-max word (first maximum) and x_next f32 [R,128] =
+ * rows, Wp bf16 [3][V][128] = the three split-bf16 pieces of the projection weight f32 [V,128] (spacap_gemm_bf3_split_w_f32; the
+ * logits are fp32-equivalent split-bf16 products), bias f32 [V] -> ys i64 [R][ys_ld] column t_out = the arg-max word (first maximum) and x_next f32 [R,128] =
  * lut[word] * scale + pe_row, the next step's input rows (lut f32 [V,128], pe_row f32 [128]).  workspace: device memory of
  * spacap_decode_word_workspace_bytes(R, V) bytes. */
 size_t spacap_decode_word_workspace_bytes(long R, int V);
-int spacap_decode_word_f32(const float *x, const float *W, const float *bias, long R, int V, const float *lut, float scale,
+int spacap_decode_word_f32(const float *x, const void *Wp, const float *bias, long R, int V, const float *lut, float scale,
                            const float *pe_row, int64_t *ys, int ys_ld, int t_out, float *x_next, void *workspace,
                            spacap_stream_t stream);
 /* Split-K product for the skinny feed-forward products (K = d_ff, N = 128: w_2 forward, the data gradient through w_1):

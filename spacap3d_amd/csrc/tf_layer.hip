@@ -863,73 +863,110 @@ extern "C" int spacap_decode_attn_f32(const float *qkv, float *kcache, float *vc
 // LDS 64 at a time (next chunk's loads in flight), logits come out of v_mfma_f32_16x16x4_f32 (exact fp32 products) 16 words per
 // wave, and every lane keeps the running (best logit, first index) of its rows; the slices' winners [R][NS] are merged by
 // decode_next_kernel, which also writes the word into the caption and forms the next input row lut[word] sqrt(d) + pe[t].
-constexpr int VA_CHUNK = 64, VA_LD = D + 4;
-__global__ __launch_bounds__(256) void vocab_argmax_kernel(const float *__restrict__ x, const float *__restrict__ W, const float *__restrict__ bias,
+// Arithmetic: split-bf16 (three bf16 pieces per operand, the six piece products above 2^-24 on v_mfma_f32_16x16x32_bf16:
+// fp32-equivalent logits at 6/16 of the fp32-MFMA time -- 1.6 GFLOP per word on the fp32 pipe alone is 10 us).  The weight's
+// pieces Wp bf16 [3][V][128] are made once per decoding call (spacap_gemm_bf3_split_w_f32).
+typedef __bf16 va_bf16x8 __attribute__((ext_vector_type(8)));
+#define VA_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+constexpr int VA_CHUNK = 64, VA_LDB = D + 8, VA_ROWS = 16;
+__global__ __launch_bounds__(256) void vocab_argmax_kernel(const float *__restrict__ x, const __bf16 *__restrict__ Wp, const float *__restrict__ bias,
                                                            long R, int V, int per_slice, float *__restrict__ best_v, int *__restrict__ best_i) {
-  __shared__ __attribute__((aligned(16))) float s_w[VA_CHUNK * VA_LD];
-  __shared__ float s_bv[4][16][17];
-  __shared__ int s_bi[4][16][17];
+  __shared__ __attribute__((aligned(16))) __bf16 s_w[3 * VA_CHUNK * VA_LDB];
+  __shared__ float s_bv[4][VA_ROWS][17];
+  __shared__ int s_bi[4][VA_ROWS][17];
+  constexpr int IMGW = VA_CHUNK * VA_LDB;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const long row0 = (long)blockIdx.x * 16;
+  const long row0 = (long)blockIdx.x * VA_ROWS;
   const int ns = gridDim.y, sl = blockIdx.y;
   const int v_beg = sl * per_slice, v_end = min(V, v_beg + per_slice);
-  // the sequences' rows as the A operand: a[ks] = x[row0 + l15][4 ks + lg]
-  float a[D / 4];
+  // the sequences' rows as the A operand, split once: a[kc][piece] = pieces of x[row0 + l15][32 kc + 8 lg .. + 7]
+  va_bf16x8 a[D / 32][3];
   {
-    const float *xr = x + (size_t)min(row0 + l15, R - 1) * D + lg;
+    const float *xr = x + (size_t)min(row0 + l15, R - 1) * D + 8 * lg;
 #pragma unroll
-    for (int ks = 0; ks < D / 4; ++ks) a[ks] = xr[4 * ks];
+    for (int kc = 0; kc < D / 32; ++kc) {
+      const f32x4 lo = ld4(xr + 32 * kc), hi = ld4(xr + 32 * kc + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = e < 4 ? lo[e] : hi[e - 4];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        a[kc][0][e] = h, a[kc][1][e] = m, a[kc][2][e] = (__bf16)(r1 - (float)m);
+      }
+    }
   }
   float bv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int bi[4] = {v_beg, v_beg, v_beg, v_beg};
-  const int c4 = tid & 31, r0 = tid >> 5;   // staging: 32 float4 per weight row, 8 rows per pass
-  f32x4 stg[VA_CHUNK / 8];
+  // staging: per piece 64 rows x 16 sixteen-byte pieces = 1 024 loads: 4 per thread and piece
+  const int c8 = tid & 15, r0 = tid >> 4;
+  const size_t wimg = (size_t)V * D;
+  va_bf16x8 stg[3][4];
   auto fetch = [&](int v0) {
 #pragma unroll
-    for (int i = 0; i < VA_CHUNK / 8; ++i) {
-      const int v = v0 + r0 + 8 * i;
-      stg[i] = v < v_end ? ld4(W + (size_t)v * D + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = v0 + r0 + 16 * i;
+        stg[p][i] = *reinterpret_cast<const va_bf16x8 *>(Wp + p * wimg + (size_t)min(v, V - 1) * D + 8 * c8);
+      }
   };
-  fetch(v_beg);
+  fetch(v_beg < V ? v_beg : 0);
   for (int v0 = v_beg; v0 < v_end; v0 += VA_CHUNK) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VA_CHUNK / 8; ++i) st4(&s_w[(r0 + 8 * i) * VA_LD + 4 * c4], stg[i]);
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<va_bf16x8 *>(s_w + p * IMGW + (r0 + 16 * i) * VA_LDB + 8 * c8) = stg[p][i];
     __syncthreads();
     if (v0 + VA_CHUNK < v_end) fetch(v0 + VA_CHUNK);
     const int v = v0 + 16 * w + l15;                    // this lane's word of the chunk
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    const float *wr = s_w + (16 * w + l15) * VA_LD + lg;
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-    for (int ks = 0; ks < D / 4; ks += 2) {
-      acc = MFMA16(a[ks], wr[4 * ks], acc);
-      acc2 = MFMA16(a[ks + 1], wr[4 * ks + 4], acc2);
+    for (int kc = 0; kc < D / 32; ++kc) {
+      va_bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const va_bf16x8 *>(s_w + p * IMGW + (16 * w + l15) * VA_LDB + 32 * kc + 8 * lg);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        if (kc & 1) acc2 = VA_MFMA(a[kc][PA[q]], b[PB[q]], acc2);
+        else acc = VA_MFMA(a[kc][PA[q]], b[PB[q]], acc);
+      }
     }
     if (v < v_end) {
-      const float b = bias[v];
+      const float bsv = bias[v];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {      // acc[u] = logit of sequence row0 + 4 lg + u, word v; words arrive in increasing order
-        const float val = (acc[u] + acc2[u]) + b;
+      for (int u = 0; u < 4; ++u) {      // logit of sequence row0 + 4 lg + u, word v; words arrive in increasing order
+        const float val = (acc[u] + acc2[u]) + bsv;
         if (val > bv[u]) bv[u] = val, bi[u] = v;
       }
     }
   }
-  // merge: rows 4 lg + u across the 16 lanes and the 4 waves; ties go to the smaller word index (torch.max: first maximum)
+  // merge across the 16 lanes and the 4 waves; ties go to the smaller word index (torch.max: first maximum)
 #pragma unroll
   for (int u = 0; u < 4; ++u) s_bv[w][4 * lg + u][l15] = bv[u], s_bi[w][4 * lg + u][l15] = bi[u];
   __syncthreads();
-  if (tid < 16 && row0 + tid < R) {
+  if (tid < 64) {
+    const int row = tid >> 2, ww = tid & 3;          // four threads per sequence, one wave's 16 candidates each
     float m = -INFINITY;
     int mi = 0x7fffffff;
-    for (int ww = 0; ww < 4; ++ww)
-      for (int l = 0; l < 16; ++l) {
-        const float val = s_bv[ww][tid][l];
-        const int idx = s_bi[ww][tid][l];
-        if (val > m || (val == m && idx < mi)) m = val, mi = idx;
-      }
-    best_v[(size_t)(row0 + tid) * ns + sl] = m;
-    best_i[(size_t)(row0 + tid) * ns + sl] = mi;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) {
+      const float val = s_bv[ww][row][l];
+      const int idx = s_bi[ww][row][l];
+      if (val > m || (val == m && idx < mi)) m = val, mi = idx;
+    }
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      const float om = __shfl_xor(m, o);
+      const int oi = __shfl_xor(mi, o);
+      if (om > m || (om == m && oi < mi)) m = om, mi = oi;
+    }
+    if (ww == 0 && row0 + row < R) {
+      best_v[(size_t)(row0 + row) * ns + sl] = m;
+      best_i[(size_t)(row0 + row) * ns + sl] = mi;
+    }
   }
 }
 
@@ -953,12 +990,13 @@ __global__ __launch_bounds__(256) void decode_next_kernel(const float *__restric
 }
 
 /* One greedy-decoding step's word choice (models/transformer_captioner.py:441-447 with the Generator of :93-100): x f32 [R,128] the
-   decoder's output rows, W f32 [V,128], bias f32 [V] -> ys i64 [R][ys_ld] column t_out = arg-max word (first maximum), and the next
+   decoder's output rows, Wp bf16 [3][V][128] = the pieces of the projection weight (spacap_gemm_bf3_split_w_f32), bias f32 [V]
+   -> ys i64 [R][ys_ld] column t_out = arg-max word (first maximum), and the next
    step's input rows x_next f32 [R,128] = lut[word] * scale + pe_row (lut f32 [V,128], pe_row f32 [128]).
    workspace: spacap_decode_word_workspace_bytes(R, V) bytes (the vocabulary slices' winners). */
 namespace {
 inline int va_slices(long R, int V) {
-  const long tiles = (R + 15) / 16;
+  const long tiles = (R + VA_ROWS - 1) / VA_ROWS;
   long ns = (4L * spacap::device_cus() + tiles - 1) / tiles;   // ~4 workgroups per CU
   const long most = (V + VA_CHUNK - 1) / VA_CHUNK;
   if (ns > most) ns = most;
@@ -967,7 +1005,7 @@ inline int va_slices(long R, int V) {
 }
 }  // namespace
 extern "C" size_t spacap_decode_word_workspace_bytes(long R, int V) { return R > 0 && V > 0 ? (size_t)R * va_slices(R, V) * 8 : 0; }
-extern "C" int spacap_decode_word_f32(const float *x, const float *W, const float *bias, long R, int V, const float *lut, float scale,
+extern "C" int spacap_decode_word_f32(const float *x, const void *W, const float *bias, long R, int V, const float *lut, float scale,
                                       const float *pe_row, int64_t *ys, int ys_ld, int t_out, float *x_next, void *workspace,
                                       spacap_stream_t stream) {
   const char *what = "spacap_decode_word_f32";
@@ -981,7 +1019,8 @@ extern "C" int spacap_decode_word_f32(const float *x, const float *W, const floa
   float *bv = static_cast<float *>(workspace);
   int *bi = reinterpret_cast<int *>(bv + (size_t)R * ns);
   hipStream_t s = spacap::as_stream(stream);
-  hipLaunchKernelGGL(vocab_argmax_kernel, dim3((unsigned)((R + 15) / 16), ns), dim3(256), 0, s, x, W, bias, R, V, per, bv, bi);
+  hipLaunchKernelGGL(vocab_argmax_kernel, dim3((unsigned)((R + VA_ROWS - 1) / VA_ROWS), ns), dim3(256), 0, s, x, static_cast<const __bf16 *>(W),
+                     bias, R, V, per, bv, bi);
   hipLaunchKernelGGL(decode_next_kernel, dim3((unsigned)((R + 7) / 8)), dim3(256), 0, s, bv, bi, ns, R, lut, scale, pe_row,
                      reinterpret_cast<long long *>(ys), ys_ld, t_out, x_next);
   SPACAP_CHECK_LAUNCH(what);

@@ -466,6 +466,8 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
         x = indicator.contiguous()
         lut, gw, gb = embed.lut.weight.contiguous(), generator.proj.weight.contiguous(), generator.proj.bias.contiguous()
         V = gw.shape[0]
+        from .linear import bf3_pieces
+        gwp = bf3_pieces(gw)                            # the projection weight's three bf16 pieces, once per call
         pe_rows = pe[0, :T].contiguous()
         xw = _new(dev, R, D_MODEL)                      # the next step's input rows (written by the word kernel)
         ws = torch.empty(int(lib.spacap_decode_word_workspace_bytes(R, V)), dtype=torch.uint8, device=dev)
@@ -496,7 +498,7 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
                           eps=dec.norm.eps, n_out=n)
             if t >= 1:
                 # ys[:, t - 1] = argmax_v (n W^T + b); xw = lut[word] sqrt(d) + pe[t]: the input of step t + 1
-                check(lib.spacap_decode_word_f32(n.data_ptr(), gw.data_ptr(), gb.data_ptr(), R, V, lut.data_ptr(), sqrt_d,
+                check(lib.spacap_decode_word_f32(n.data_ptr(), gwp.data_ptr(), gb.data_ptr(), R, V, lut.data_ptr(), sqrt_d,
                                                  pe_rows[min(t, T - 1)].data_ptr(), ys.data_ptr(), n_words, t - 1, xw.data_ptr(),
                                                  ws.data_ptr(), st), "spacap_decode_word_f32")
     return ys

@@ -354,7 +354,9 @@ def test_decode_word_choice_without_logits(R, V):
     xn = torch.empty(R, 128, device=DEV)
     ws = torch.empty(int(lib.spacap_decode_word_workspace_bytes(R, V)), dtype=torch.uint8, device=DEV)
     scale = math.sqrt(128.0)
-    check(lib.spacap_decode_word_f32(x.data_ptr(), W.data_ptr(), b.data_ptr(), R, V, lut.data_ptr(), scale, pe.data_ptr(), ys.data_ptr(), 5, 2,
+    from spacap3d_amd.linear import bf3_pieces
+    Wp = bf3_pieces(W)
+    check(lib.spacap_decode_word_f32(x.data_ptr(), Wp.data_ptr(), b.data_ptr(), R, V, lut.data_ptr(), scale, pe.data_ptr(), ys.data_ptr(), 5, 2,
                                      xn.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "spacap_decode_word_f32")
     word = ys[:, 2]
     assert int(word[0]) == 3 and bool((ys[:, [0, 1, 3, 4]] == -1).all())
