@@ -189,9 +189,10 @@ def _bn_relu(bn, x, training):
 
 
 def _conv(conv, x, training):
-    """``conv(x)``; in training mode through the backend's 1x1 convolution (slab weight gradient) when it has one."""
+    """``conv(x)`` through the backend's 1x1 convolution when it has one: in training mode (slab weight gradient) and in
+    the inference forward (no gradient recording: forward kernel only)."""
     from .backend import ops
-    f = getattr(ops(), "conv1x1", None) if training else None
+    f = getattr(ops(), "conv1x1", None) if (training or not torch.is_grad_enabled()) else None
     y = f(x, conv) if f is not None else None
     return conv(x) if y is None else y
 

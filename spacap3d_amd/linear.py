@@ -297,14 +297,15 @@ def conv1x1_cm(mode, weight, t, bias, M):
 
 
 def conv1x1(x, conv):
-    """``conv(x)`` for a 1x1 nn.Conv1d / nn.Conv2d ``conv``; ``None`` when the shape has no weight-gradient kernel or
-    no gradient is being recorded (the caller then calls the module)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled() and conv.weight.requires_grad):
+    """``conv(x)`` for a 1x1 nn.Conv1d / nn.Conv2d ``conv``; ``None`` when the shape has no kernel (the caller then calls the
+    module).  Without gradient recording (the inference forward) only the forward kernel runs."""
+    if not (x.is_cuda and x.dtype == torch.float32) or any(k != 1 for k in conv.kernel_size) or not x.is_contiguous():
         return None
+    if not (torch.is_grad_enabled() and conv.weight.requires_grad):
+        return conv1x1_cm(0, conv.weight, x, conv.bias, conv.out_channels) if USE_OWN_CONV else None
     B, CI = x.shape[0], x.shape[1]
     N = x.numel() // max(B * CI, 1)
-    if any(k != 1 for k in conv.kernel_size) or not x.is_contiguous() or \
-            int(lib.spacap_conv1x1_wgrad_slabs(B, conv.out_channels, CI, N)) == 0:
+    if int(lib.spacap_conv1x1_wgrad_slabs(B, conv.out_channels, CI, N)) == 0:
         return None
     return Conv1x1.apply(x, conv.weight, conv.bias)
 

@@ -46,7 +46,7 @@ class _ConvBNReLU2d(nn.Sequential):
         fused op of the backend.  Eval mode (running statistics) uses the stock modules."""
         from .backend import ops
         z = None
-        if self.training:
+        if self.training or not torch.is_grad_enabled():
             f = getattr(ops(), "conv1x1", None)   # 1x1 convolution with the slab weight gradient (linear.Conv1x1)
             z = f(x, self.conv) if f is not None else None
         if z is None:

@@ -261,6 +261,13 @@ class PositionalEncodingLearned(nn.Module):
                 y = conv(v, m) if conv is not None else None
                 return m(v) if y is None else y
             t = c(h[3], ops().bn_relu_train(c(h[0], t), h[1]))   # Conv1d -> [BatchNorm1d -> ReLU as one fused op] -> Conv1d
+        elif t.is_cuda and not torch.is_grad_enabled() and getattr(ops(), "conv1x1", None) is not None:
+            conv = ops().conv1x1     # inference forward: the two 1x1 convolutions on the library's kernel, BatchNorm on running statistics
+
+            def c(m, v):
+                y = conv(v, m)
+                return m(v) if y is None else y
+            t = c(h[3], h[2](h[1](c(h[0], t))))
         else:
             t = h(t)
         return x + t.transpose(1, 2).contiguous()
