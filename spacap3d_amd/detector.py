@@ -285,7 +285,7 @@ class ProposalModule(nn.Module):
         pm = point_major_of(features)   # the fused SA op's own (B,K,128) result
         data_dict["aggregated_vote_features"] = pm if pm is not None else features.permute(0, 2, 1).contiguous()
         data_dict["aggregated_vote_inds"] = fps_inds
-        net = features.contiguous() if self.training else features
+        net = features.contiguous() if (self.training or not torch.is_grad_enabled()) else features   # (the own 1x1 kernel takes dense tensors)
         layers = list(self.proposal)
         i = 0
         while i < len(layers):
