@@ -293,8 +293,10 @@ def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
         err = float((got.double().cpu() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
         assert err < 2e-5, err
     assert conv1x1(torch.zeros(2, CI, 33, device=DEV), torch.nn.Conv1d(CI, CO, 1).to(DEV)) is None   # N not a multiple of 32
-    with torch.no_grad():
-        assert conv1x1(xg, conv) is None
+    with torch.no_grad():   # the inference forward: the forward kernel alone (shapes it takes: N a multiple of 64), same values
+        y0 = conv1x1(xg, conv)
+        assert y0 is None or torch.equal(y0, y.detach())
+        assert (y0 is not None) == (N % 64 == 0)
 
 
 @pytest.mark.parametrize("B,CO,CI,N", [(8, 259, 256, 1024), (8, 97, 128, 256), (4, 128, 3, 256), (2, 256, 256, 512)])

@@ -54,12 +54,13 @@ def test_tiled_split_bf16_weight_gradient(R, N, K):
         assert _rel(part.double().sum(0).view(N, K), ref) < (1e-5 if ns > 1 or R < 10000 else 1e-4), ns
 
 
-@pytest.mark.parametrize("C,H", [(512, 32), (256, 16)])
-def test_wide_relation_head_matches_float64(lin, C, H):
+@pytest.mark.parametrize("C,H,seed", [(512, 32, 0), (512, 32, 1), (512, 32, 2), (256, 16, 0), (128, 8, 0)])
+def test_wide_relation_head_matches_float64(lin, C, H, seed):
     """RelationWide (hid1 kernel -> split-bf16 layer 2 -> 9-wide layer 3; backward: tail pass, split-bf16 weight / data gradients,
     first-layer backward) against the float64 composition of models/transformer_captioner.py:392-397 + :319-326."""
     B, K, D = 2, 64, 16
-    g = torch.Generator().manual_seed(C)
+    torch.manual_seed(seed)              # (the Linear layers draw their weights from the global generator)
+    g = torch.Generator().manual_seed(C + seed)
     P = torch.softmax(torch.randn(B, H, K, K, generator=g), -1).to(DEV).requires_grad_(True)
     V = torch.randn(B, H, K, D, generator=g).to(DEV).requires_grad_(True)
     l1, l2, l3 = torch.nn.Linear(H * D, C).to(DEV), torch.nn.Linear(C, C).to(DEV), torch.nn.Linear(C, 9).to(DEV)
@@ -78,5 +79,9 @@ def test_wide_relation_head_matches_float64(lin, C, H):
     (ref * wsum.double()).sum().backward()
     want = [ref, P64.grad, V64.grad] + [p.grad for m in ms for p in (m.weight, m.bias)]
     names = ["pred", "dP", "dV", "dW1", "db1", "dW2", "db2", "dW3", "db3"]
-    for n, a, b in zip(names, got, want):
-        assert _rel(a, b) < 2e-5, (n, _rel(a, b))
+    errs = {n: _rel(a, b) for n, a, b in zip(names, got, want)}
+    print("wide relation head vs float64:", {n: f"{e:.1e}" for n, e in errs.items()})
+    # 8 M ReLU gates: one that sits within fp32 rounding of zero and resolves the other way than in float64 moves single
+    # entries of dP / dV by its whole summand -- those two are held at the flip level, everything else at fp32 level
+    for n, e in errs.items():
+        assert e < (2e-3 if n in ("dP", "dV") else 3e-5), (n, e)
