@@ -102,8 +102,15 @@ class Pointnet2Backbone(nn.Module):
     @staticmethod
     def _break_up_pc(pc):
         xyz = pc[..., :3].contiguous()
-        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
-        return xyz, features
+        if pc.size(-1) <= 3:
+            return xyz, None
+        if pc.is_cuda and pc.size(-1) > 4 and pc.is_contiguous() and not pc.requires_grad:
+            # (B, C, N) as the reference hands it on (models/backbone_module.py:69-73) -- but as the typed transposed VIEW of the
+            # cloud's own feature columns: the fused SA op reads the rows in place (sa_mlp._uniform_rows) instead of through a
+            # transposed copy here and a second one back to point-major there (2 x 170 MB at 132 channels, 0.85 ms per step)
+            from .layout import ChannelMajorOf
+            return xyz, ChannelMajorOf.wrap(pc[..., 3:])
+        return xyz, pc[..., 3:].transpose(1, 2).contiguous()
 
     # Furthest-point sampling is a chain of ~4 000 sequentially dependent rounds on B workgroups (one per scene): 2.9 ms +
     # 0.76 + 0.31 + 0.16 at cfg2, while each level's grouping + shared MLP only needs THAT level's indices.  When the

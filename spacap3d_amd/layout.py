@@ -14,7 +14,8 @@ import torch
 class ChannelMajorOf(torch.Tensor):
     @staticmethod
     def wrap(pm: torch.Tensor) -> "ChannelMajorOf":
-        """``pm`` dense (B, N, C) -> the (B, C, N) transposed view of it, typed."""
+        """``pm`` (B, N, C), dense or a column window of wider rows (channels contiguous) -> the (B, C, N) transposed view of it,
+        typed."""
         res = pm.transpose(1, 2).as_subclass(ChannelMajorOf)
         res._pm = pm
         return res

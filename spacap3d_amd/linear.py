@@ -526,16 +526,18 @@ def _dense(dev, a_ptr, lda, W_ptr, ldw, trans_w, bias_ptr, R, K, CO, out_ptr, ld
 
 def dense_product(a2, W, trans_w, bias=None, col0=0, ncols=None):
     """out = a2 Wv^T (+ bias) when ``trans_w`` else a2 Wv, with Wv = W[:, col0 : col0 + ncols] a COLUMN SLICE of the dense 2-D
-    matrix W (no copy: the kernel takes the row stride).  a2 (R, K) dense.  Any sizes."""
+    matrix W (no copy: the kernel takes the row stride).  a2 (R, K): rows of K contiguous floats at ANY uniform row stride (a
+    column window of wider rows is read in place).  Any sizes."""
     R, K = a2.shape
     ldw = W.shape[1]
     ncols = ldw - col0 if ncols is None else ncols
     CO = W.shape[0] if trans_w else ncols
-    assert a2.is_contiguous() and W.is_contiguous() and (ncols == K if trans_w else W.shape[0] == K)
+    assert (K == 1 or a2.stride(1) == 1) and W.is_contiguous() and (ncols == K if trans_w else W.shape[0] == K)
+    lda = a2.stride(0) if R > 1 else K
     dev = a2.device
     with torch.cuda.device(dev):
         out = torch.empty(R, CO, dtype=torch.float32, device=dev)
-        _dense(dev, a2.data_ptr(), K, W.data_ptr() + 4 * col0, ldw, trans_w, bias.data_ptr() if bias is not None else None, R, K, CO,
+        _dense(dev, a2.data_ptr(), lda, W.data_ptr() + 4 * col0, ldw, trans_w, bias.data_ptr() if bias is not None else None, R, K, CO,
                out.data_ptr(), CO)
     return out
 

@@ -109,7 +109,9 @@ class _SAMLP(Function):
         feat = feat.contiguous() if feat is not None else None
         # first layer commuted with the gather: Y = F W1[:, 3:]^T over the SOURCE points (csrc/dense_rows.hip reads the column
         # slice of W1 in place)
-        pmc = pm.contiguous() if pm is not None else None
+        # (rows of Cf contiguous floats at a uniform stride are read in place: the input features of a (B, N, 3 + C) cloud are a
+        # column window of its rows -- no transposed / gathered copy of the 170 MB feature block of BASELINE config 4)
+        pmc = pm if (pm is None or _uniform_rows(pm)) else pm.contiguous()
         Y = _feature_product(pmc, W1c) if pm is not None else None
         nparts = int(lib.spacap_sa_nparts())
         with torch.cuda.device(dev):
@@ -340,24 +342,24 @@ class _SAMLP(Function):
                 # gradient of Y = pm W1[:, 3:]^T: d pm = dY W1[:, 3:]; the weight part reduces over all B*Np source points
                 pm = ctx.pm
                 Cf = W1.shape[1] - 3
-                g2, x2 = dY.view(-1, C1), pm.reshape(-1, Cf)
+                g2, x2 = dY.view(-1, C1), _rows2d(pm)
                 if ctx.needs_input_grad[4]:
                     from .linear import dense_product
                     dpm = dense_product(g2, W1, False, col0=3).view_as(pm)    # dY W1[:, 3:]
                 # [rel columns | feature columns] from the two sets of partial results in one launch (the values of the two
                 # slab sums + the concatenation).  Feature partials: the Linear layers' slab kernel for multiples of 128
                 # channels (SA2 - SA4), else the tall-and-narrow kernel (SA1 with 7 / 132 feature channels: cfg3, cfg4)
-                x2c = x2.contiguous()
                 nslab = int(lib.spacap_linear_wgrad_slabs(B * Np, C1, Cf))
                 if nslab:
+                    x2c = x2.contiguous()
                     pf = torch.empty(nslab, C1 * Cf, **f32)
                     check(lib.spacap_linear_wgrad_f32(g2.data_ptr(), x2c.data_ptr(), B * Np, C1, Cf, 0, pf.data_ptr(), st),
                           "spacap_linear_wgrad_f32")
-                else:
+                else:   # (reads the rows at their own stride)
                     nslab = int(lib.spacap_dense_wgrad_tall_slabs(B * Np, C1, Cf))
                     pf = torch.empty(nslab, C1 * Cf, **f32)
-                    check(lib.spacap_dense_wgrad_tall_f32(g2.data_ptr(), C1, x2c.data_ptr(), Cf, B * Np, C1, Cf, nslab, pf.data_ptr(), st),
-                          "spacap_dense_wgrad_tall_f32")
+                    check(lib.spacap_dense_wgrad_tall_f32(g2.data_ptr(), C1, x2.data_ptr(), x2.stride(0), B * Np, C1, Cf, nslab,
+                                                          pf.data_ptr(), st), "spacap_dense_wgrad_tall_f32")
                 dW1 = torch.empty(C1, 3 + Cf, **f32)
                 check(lib.spacap_sa_dw1_assemble_f32(pw1.data_ptr(), nparts, pf.data_ptr(), nslab, C1, Cf, dW1.data_ptr(), st),
                       "spacap_sa_dw1_assemble_f32")
@@ -379,11 +381,22 @@ class _SAMLP(Function):
         return (dxyz, dnew, None, None, dpm, dW1, dW2, dW3, dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None, None)
 
 
+def _uniform_rows(pm):
+    """(B, Np, Cf) whose B * Np rows of Cf contiguous floats lie at ONE uniform stride (dense, or a column window of wider rows)."""
+    return pm.stride(2) == 1 and pm.stride(0) == pm.shape[1] * pm.stride(1) and pm.data_ptr() % 4 == 0
+
+
+def _rows2d(pm):
+    """The (B * Np, Cf) view of a ``_uniform_rows`` tensor (row stride pm.stride(1))."""
+    B, Np, Cf = pm.shape
+    return pm.as_strided((B * Np, Cf), (pm.stride(1), 1), pm.storage_offset())
+
+
 def _feature_product(pm, W1c):
     """Y (B, Np, C1) = pm (B, Np, Cf) W1[:, 3:]^T."""
     from .linear import dense_product
     B, Np, Cf = pm.shape
-    return dense_product(pm.view(B * Np, Cf), W1c, True, col0=3).view(B, Np, W1c.shape[0])
+    return dense_product(_rows2d(pm), W1c, True, col0=3).view(B, Np, W1c.shape[0])
 
 
 def supported(mlp_module, nsample):
@@ -469,7 +482,8 @@ def sa_mlp_eval(xyz, new_xyz, features, idx, mlp_module, rdiv, use_xyz=True):
             feat, W1a = features.reshape(B, -1).contiguous(), W1.contiguous()
         else:
             pm = point_major_of(features)
-            Y = _feature_product((pm if pm is not None else features.transpose(1, 2)).contiguous(), W1.contiguous())
+            pm = pm if pm is not None else features.transpose(1, 2)
+            Y = _feature_product(pm if _uniform_rows(pm) else pm.contiguous(), W1.contiguous())
             W1a = W1[:, :3].contiguous()
     else:
         W1a = W1.contiguous()
