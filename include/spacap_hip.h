@@ -819,6 +819,15 @@ int spacap_tf_ffn1_f32(const float *x, const float *W, const float *bias, long R
  * x [R,128]; part f32 [dff/128][R][128] is consumed by spacap_tf_rows_f32 (nparts = dff/128), which adds the slices in order. */
 int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, const float *Wb, const float *bias, const float *y, long R, int dff,
                       float drop_p, uint64_t seed, const uint64_t *seed_dev, float *hid, float *part, spacap_stream_t stream);
+/* The same block on split-bf16 products (three bf16 pieces per operand, six piece products: fp32-equivalent at 6/16 of the
+ * fp32-MFMA time) for tall inputs (R > 512).  The weights are split ahead of time: spacap_tf_ffn_split_f32 writes, for each of
+ * nlayers layers, four piece images (W1, W2, W2^T, W1^T; spacap_tf_ffn_pieces_elems(dff) bf16 elements per layer) in one launch
+ * per 16 layers (host pointer arrays, read before the call returns); spacap_tf_ffn_bf3_f32 takes one layer's images. */
+long spacap_tf_ffn_pieces_elems(int dff);
+int spacap_tf_ffn_split_f32(const float *const *w1, const float *const *w2, void *const *pieces, int nlayers, int dff,
+                            spacap_stream_t stream);
+int spacap_tf_ffn_bf3_f32(int mode, const float *x, const void *pieces, const float *bias, const float *y, long R, int dff, float drop_p,
+                          uint64_t seed, const uint64_t *seed_dev, float *hid, float *part, spacap_stream_t stream);
 /* One greedy-decoding step of self-attention over a key / value cache (replaces the prefix recomputation of
  * models/transformer_captioner.py:435-438): qkv f32 [R, 3*128] = the packed projection of the NEW token of every sequence;
  * its k, v are appended at position t of kcache / vcache f32 [R, T, 128] (T <= 32) and its q attends over positions 0..t;

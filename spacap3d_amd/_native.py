@@ -191,6 +191,9 @@ SIGNATURES = {
     "spacap_tf_rows_parts": (_i, [_l]),
     "spacap_tf_ffn1_f32": (_i, [_p, _p, _p, _l, _i, _f, _u64, _p, _p, _p]),
     "spacap_tf_ffn_f32": (_i, [_i, _p, _p, _p, _p, _p, _l, _i, _f, _u64, _p, _p, _p, _p]),
+    "spacap_tf_ffn_pieces_elems": (_l, [_i]),
+    "spacap_tf_ffn_split_f32": (_i, [_p, _p, _p, _i, _i, _p]),
+    "spacap_tf_ffn_bf3_f32": (_i, [_i, _p, _p, _p, _p, _l, _i, _f, _u64, _p, _p, _p, _p]),
     "spacap_decode_attn_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _i, _f, _p, _p]),
     "spacap_decode_word_workspace_bytes": (ctypes.c_size_t, [_l, _i]),
     "spacap_decode_word_f32": (_i, [_p, _p, _p, _l, _i, _p, _f, _p, _p, _i, _i, _p, _p, _p]),

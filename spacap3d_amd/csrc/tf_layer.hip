@@ -684,6 +684,184 @@ __global__ __launch_bounds__(256) void tf_ffn_kernel(const TfFfnArgs P) {
   }
 }
 
+// ---- the chained feed-forward kernel on split-bf16 products (tall inputs: the encoder's 2 048 rows, greedy decoding) ---------
+// Same contract as tf_ffn_kernel; both products as bf16 x 3 (three bf16 pieces per operand, the six piece products above 2^-24
+// on v_mfma_f32_16x16x32_bf16: fp32-equivalent at 6/16 of the fp32-MFMA time).  The WEIGHTS arrive pre-split (four piece
+// images per layer, made by one batched launch per stack and forward: spacap_tf_ffn_split_f32) in the two layouts the products
+// need -- rows = the product's output unit, 8 consecutive contraction indices per 16-byte operand load -- and go from L2 straight
+// into matrix-core operand registers, one 32-deep contraction step ahead; the 64-row activation tile is split once into three
+// LDS images [64][128 + 8] which the hidden tile overwrites between the two products (everything of product 1 is in
+// accumulators by then).  52 KB of LDS, ~130 registers: three workgroups per CU.
+typedef __bf16 ff_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ff_bf16x4 __attribute__((ext_vector_type(4)));
+#define FF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+constexpr int FF_LD = D + 8, FF_IMG = 64 * FF_LD;
+struct TfFfnBf3Args {
+  const float *x, *bias, *y;
+  const __bf16 *Wa, *Wb;   // Wa [3][dff][128]: rows = hidden units; Wb [3][128][dff]: rows = the second product's outputs
+  float *hid, *part;
+  long R;
+  int dff;
+  unsigned thresh;
+  float scale;
+  unsigned long long seed;
+  const unsigned long long *seed_dev;
+};
+__device__ __forceinline__ void ff_split4(f32x4 v, ff_bf16x4 &p0, ff_bf16x4 &p1, ff_bf16x4 &p2) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const __bf16 h = (__bf16)v[u];
+    const float r = v[u] - (float)h;
+    const __bf16 m = (__bf16)r;
+    p0[u] = h, p1[u] = m, p2[u] = (__bf16)(r - (float)m);
+  }
+}
+template <bool BWD>
+__global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P) {
+  __shared__ __attribute__((aligned(16))) __bf16 s_t[3 * FF_IMG];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
+  const long row0 = (long)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 128, dff = P.dff;
+  const int c4 = tid & 31, r0 = tid >> 5;
+  // ---- the rows' tile: fp32 -> three bf16 images
+  {
+    f32x4 stg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stg[i] = ld4(P.x + (size_t)min(row0 + r0 + 8 * i, P.R - 1) * D + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      ff_bf16x4 p0, p1, p2;
+      ff_split4(stg[i], p0, p1, p2);
+      __bf16 *d = s_t + (r0 + 8 * i) * FF_LD + 4 * c4;
+      *reinterpret_cast<ff_bf16x4 *>(d) = p0;
+      *reinterpret_cast<ff_bf16x4 *>(d + FF_IMG) = p1;
+      *reinterpret_cast<ff_bf16x4 *>(d + 2 * FF_IMG) = p2;
+    }
+  }
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
+  // weight operand of a product: wq[t][piece] = rows (base row + 16 t + l15), contraction indices 32 kc + 8 lg .. + 7
+  auto wload = [&](const __bf16 *base, size_t img, size_t ld, int kc, ff_bf16x8 (*wq)[3]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wq[t][p] = *reinterpret_cast<const ff_bf16x8 *>(base + p * img + (size_t)(16 * t + l15) * ld + 32 * kc + 8 * lg);
+  };
+  // one product: acc[t][mt][u] = out[row 16 mt + l15][unit 32 w + 16 t + 4 lg + u] (weights as the A operand: a lane ends up with
+  // four consecutive units of one row)
+  auto product = [&](const __bf16 *wbase, size_t img, size_t ld, f32x4 (*acc)[4]) {
+    ff_bf16x8 wq[2][2][3];
+    wload(wbase, img, ld, 0, wq[0]);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      if (kc + 1 < 4) wload(wbase, img, ld, kc + 1, wq[(kc + 1) & 1]);
+      ff_bf16x8 a[4][3];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[mt][p] = *reinterpret_cast<const ff_bf16x8 *>(s_t + p * FF_IMG + (16 * mt + l15) * FF_LD + 32 * kc + 8 * lg);
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[t][mt] = FF_MFMA(wq[kc & 1][t][PA[q]], a[mt][PB[q]], acc[t][mt]);
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  product(P.Wa + (size_t)(c0 + 32 * w) * D, (size_t)dff * D, D, acc);
+  f32x4 bb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (!BWD && P.bias) bb[0] = ld4(P.bias + c0 + 32 * w + 4 * lg), bb[1] = ld4(P.bias + c0 + 32 * w + 16 + 4 * lg);
+  const DropSeed sd = make_seed(P.seed, P.seed_dev);
+  __syncthreads();   // every wave has read the rows' images for the last time: the hidden tile takes their place
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const long row = row0 + 16 * mt + l15;
+    const bool valid = row < P.R;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int e = 32 * w + 16 * t + 4 * lg;   // the lane's four hidden units inside the slice
+      f32x4 o = acc[t][mt];
+      if (BWD) {
+        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+        if (valid) yv = ld4(P.y + (size_t)row * dff + c0 + e);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = yv[u] > 0.f ? o[u] * P.scale : 0.f;
+      } else {
+        o += bb[t];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v = fmaxf(o[u], 0.f);
+          if (P.thresh != 0u) v = hash32((unsigned long long)row * dff + c0 + e + u, sd) >= P.thresh ? v * P.scale : 0.f;
+          o[u] = valid ? v : 0.f;
+        }
+      }
+      if (valid && P.hid) st4(P.hid + (size_t)row * dff + c0 + e, o);
+      ff_bf16x4 p0, p1, p2;
+      ff_split4(o, p0, p1, p2);
+      __bf16 *d = s_t + (16 * mt + l15) * FF_LD + e;
+      *reinterpret_cast<ff_bf16x4 *>(d) = p0;
+      *reinterpret_cast<ff_bf16x4 *>(d + FF_IMG) = p1;
+      *reinterpret_cast<ff_bf16x4 *>(d + 2 * FF_IMG) = p2;
+      acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  product(P.Wb + (size_t)(32 * w) * dff + c0, (size_t)D * dff, dff, acc);
+  float *out = P.part + (size_t)blockIdx.y * P.R * D;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const long row = row0 + 16 * mt + l15;
+    if (row < P.R) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) st4(out + (size_t)row * D + 32 * w + 16 * t + 4 * lg, acc[t][mt]);
+    }
+  }
+}
+
+// the four piece images of up to 16 feed-forward layers in one launch: per layer W1 f32 [dff][128], W2 f32 [128][dff] ->
+//   out + 0: W1  pieces [3][dff][128]     out + 1 img: W2 pieces [3][128][dff]
+//   out + 2: W2^T pieces [3][dff][128]    out + 3 img: W1^T pieces [3][128][dff]            (img = 3 dff 128 elements)
+constexpr int FF_SPLIT_MAX = 16;
+struct FfSplitTable {
+  int nlayers, dff;
+  const float *w1[FF_SPLIT_MAX], *w2[FF_SPLIT_MAX];
+  __bf16 *out[FF_SPLIT_MAX];
+};
+__global__ __launch_bounds__(256) void tf_ffn_split_kernel(const FfSplitTable T) {
+  __shared__ float tile[2][32][33];
+  const int layer = blockIdx.z, dff = T.dff;
+  const size_t n = (size_t)dff * D, img = 3 * n;
+  __bf16 *o = T.out[layer];
+  // a 32 x 32 tile of the [dff][128] view of W1 and of the [128][dff] view of W2: straight and transposed images of both
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int h0 = blockIdx.x * 32, m0 = blockIdx.y * 32;   // hidden-unit block, model-channel block
+  auto put = [&](__bf16 *dst, size_t idx, float v) {
+    const __bf16 h = (__bf16)v;
+    const float r = v - (float)h;
+    const __bf16 m = (__bf16)r;
+    dst[idx] = h, dst[n + idx] = m, dst[2 * n + idx] = (__bf16)(r - (float)m);
+  };
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const float a = T.w1[layer][(size_t)(h0 + r) * D + m0 + tx];      // W1[hidden h0 + r][channel m0 + tx]
+    const float b = T.w2[layer][(size_t)(m0 + r) * dff + h0 + tx];    // W2[channel m0 + r][hidden h0 + tx]
+    tile[0][r][tx] = a, tile[1][r][tx] = b;
+    put(o, (size_t)(h0 + r) * D + m0 + tx, a);                        // W1 pieces
+    put(o + img, (size_t)(m0 + r) * dff + h0 + tx, b);                // W2 pieces
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    put(o + 2 * img, (size_t)(h0 + r) * D + m0 + tx, tile[1][tx][r]); // W2^T[hidden h0 + r][channel m0 + tx] = W2[m0 + tx][h0 + r]
+    put(o + 3 * img, (size_t)(m0 + r) * dff + h0 + tx, tile[0][tx][r]); // W1^T[channel m0 + r][hidden h0 + tx] = W1[h0 + tx][m0 + r]
+  }
+}
+
 // One greedy-decoding step of self-attention over a key / value cache (models/transformer_captioner.py:402-453: the
 // reference re-runs the whole decoder prefix for every new word; with pre-norm layers and a causal mask the newest row of
 // that recomputation equals this incremental step).  One workgroup per sequence: the new token's k, v (from its packed
@@ -839,6 +1017,53 @@ extern "C" int spacap_tf_ffn_f32(int mode, const float *x, const float *Wa, cons
     if (small) hipLaunchKernelGGL((tf_ffn_kernel<true, 1>), grid, dim3(256), 0, s, P);
     else hipLaunchKernelGGL((tf_ffn_kernel<true, 4>), grid, dim3(256), 0, s, P);
   }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+/* bf16 elements of the piece images of ONE feed-forward layer (four images of 3 dff 128 elements, see tf_ffn_split_kernel) */
+extern "C" long spacap_tf_ffn_pieces_elems(int dff) { return dff >= 128 && dff % 128 == 0 ? 4L * 3 * dff * D : 0; }
+/* pieces[l] (device, spacap_tf_ffn_pieces_elems(dff) bf16 elements each) <- the split images of w1[l] f32 [dff,128], w2[l] f32 [128,dff];
+   the pointer arrays are HOST arrays, read before the call returns; one launch per 16 layers. */
+extern "C" int spacap_tf_ffn_split_f32(const float *const *w1, const float *const *w2, void *const *pieces, int nlayers, int dff,
+                                       spacap_stream_t stream) {
+  const char *what = "spacap_tf_ffn_split_f32";
+  SPACAP_REQUIRE(nlayers >= 0 && dff >= 128 && dff % 128 == 0 && (nlayers == 0 || (w1 && w2 && pieces)), "%s: bad arguments", what);
+  hipStream_t s = spacap::as_stream(stream);
+  for (int l0 = 0; l0 < nlayers; l0 += FF_SPLIT_MAX) {
+    FfSplitTable T;
+    T.nlayers = std::min(FF_SPLIT_MAX, nlayers - l0), T.dff = dff;
+    for (int l = 0; l < T.nlayers; ++l) {
+      SPACAP_REQUIRE(w1[l0 + l] && w2[l0 + l] && pieces[l0 + l], "%s: null pointer (layer %d)", what, l0 + l);
+      T.w1[l] = w1[l0 + l], T.w2[l] = w2[l0 + l], T.out[l] = static_cast<__bf16 *>(pieces[l0 + l]);
+    }
+    hipLaunchKernelGGL(tf_ffn_split_kernel, dim3(dff / 32, D / 32, T.nlayers), dim3(256), 0, s, T);
+  }
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+/* spacap_tf_ffn_f32 on split-bf16 products (fp32-equivalent), for R > 512 rows: `pieces` = the layer's images from
+   spacap_tf_ffn_split_f32 (mode 0 reads the W1 / W2 images, mode 1 the transposed ones); everything else as spacap_tf_ffn_f32. */
+extern "C" int spacap_tf_ffn_bf3_f32(int mode, const float *x, const void *pieces, const float *bias, const float *y, long R, int dff,
+                                     float drop_p, uint64_t seed, const uint64_t *seed_dev, float *hid, float *part, spacap_stream_t stream) {
+  const char *what = "spacap_tf_ffn_bf3_f32";
+  TfFfnBf3Args P = {};
+  SPACAP_REQUIRE((mode == 0 || mode == 1) && R >= 0 && dff >= 128 && dff % 128 == 0 && drop_params(drop_p, P.thresh, P.scale),
+                 "%s: (mode=%d, R=%ld, dff=%d, p=%f) unsupported", what, mode, R, dff, (double)drop_p);
+  if (R == 0) return SPACAP_OK;
+  SPACAP_REQUIRE(x && pieces && (hid || mode == 0) && part && (mode == 0 || y) && al16(x) && al16(pieces) && al16(bias) && al16(y) && al16(hid) &&
+                     al16(part), "%s: null or unaligned pointer", what);
+  const size_t img = (size_t)3 * dff * D;
+  const __bf16 *pc = static_cast<const __bf16 *>(pieces);
+  P.x = x, P.bias = bias, P.y = y, P.hid = hid, P.part = part, P.R = R, P.dff = dff;
+  P.Wa = pc + (mode == 0 ? 0 : 2) * img, P.Wb = pc + (mode == 0 ? 1 : 3) * img;
+  P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
+  const long tiles = (R + 63) / 64;
+  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)tiles, dff / 128);
+  hipStream_t s = spacap::as_stream(stream);
+  if (mode == 0) hipLaunchKernelGGL((tf_ffn_bf3_kernel<false>), grid, dim3(256), 0, s, P);
+  else hipLaunchKernelGGL((tf_ffn_bf3_kernel<true>), grid, dim3(256), 0, s, P);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -140,14 +140,61 @@ class LnQkv(Function):
         return dx, da, db, None, dw, dbias
 
 
+# ---- split-bf16 feed-forward block for tall inputs (csrc/tf_layer.hip: tf_ffn_bf3_kernel) ---------------------------------------
+# The kernel takes the layer's weights as pre-split bf16 piece images.  ``refresh_ffn_pieces(layers)`` (re)builds the images of a
+# whole stack with ONE launch -- run_stack / greedy_decode call it at the start of every forward, i.e. after any optimizer update
+# and before the backward of the same step -- and registers them under the address of w_1's weight; ``_ffn`` uses them when the
+# input has more than FFN_BF3_MIN_ROWS rows and falls back to the fp32-MFMA kernel otherwise (few rows: latency bound either way).
+FFN_BF3 = True
+FFN_BF3_MIN_ROWS = 512
+_FFN_PIECES = {}      # w_1.weight.data_ptr() -> (weakref to that parameter, bf16 piece images of the layer)
+
+
+def refresh_ffn_pieces(layers):
+    """One launch: the four split-bf16 images (W1, W2, W2^T, W1^T) of every layer's feed-forward weights, into a buffer that
+    lives with the stack (so a captured hipGraph replays the launch on the same memory)."""
+    import ctypes
+    import weakref
+    ffs = [l.feed_forward for l in layers]
+    if not ffs or not FFN_BF3:
+        return
+    w1s, w2s = [f.w_1.weight for f in ffs], [f.w_2.weight for f in ffs]
+    dff, dev = w1s[0].shape[0], w1s[0].device
+    if not w1s[0].is_cuda or any(w.shape != (dff, D_MODEL) or not w.is_contiguous() for w in w1s) or \
+            any(w.shape != (D_MODEL, dff) or not w.is_contiguous() for w in w2s):
+        return
+    per = int(lib.spacap_tf_ffn_pieces_elems(dff))
+    buf = getattr(ffs[0], "_spacap_ffn_pieces", None)
+    if buf is None or buf.shape != (len(ffs), per) or buf.device != dev:
+        with torch.cuda.device(dev):
+            buf = torch.empty(len(ffs), per, dtype=torch.bfloat16, device=dev)
+        ffs[0]._spacap_ffn_pieces = buf
+    n = len(ffs)
+    arr = ctypes.c_void_p * n
+    check(lib.spacap_tf_ffn_split_f32(arr(*[w.data_ptr() for w in w1s]), arr(*[w.data_ptr() for w in w2s]),
+                                      arr(*[buf[i].data_ptr() for i in range(n)]), n, dff, torch.cuda.current_stream(dev).cuda_stream),
+          "spacap_tf_ffn_split_f32")
+    for dead in [k for k, (ref, _) in _FFN_PIECES.items() if ref() is None]:
+        del _FFN_PIECES[dead]
+    for i, w in enumerate(w1s):
+        _FFN_PIECES[w.data_ptr()] = (weakref.ref(w), buf[i])
+
+
 def _ffn(mode, x2, Wa, Wb, bias, y, dff, p, seed, dev):
     """One launch of the chained feed-forward kernel: (hid (R, dff), parts (dff / 128, R, 128))."""
     from .attention import rng_state
     R = x2.shape[0]
     hid, parts = _new(dev, R, dff), _new(dev, dff // 128, R, D_MODEL)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rs = rng_state(dev).data_ptr() if (p > 0.0 and mode == 0) else None
+    w1 = Wa if mode == 0 else Wb
+    ent = _FFN_PIECES.get(w1.data_ptr()) if (FFN_BF3 and R > FFN_BF3_MIN_ROWS) else None
+    if ent is not None and ent[0]() is not None:
+        check(lib.spacap_tf_ffn_bf3_f32(mode, x2.data_ptr(), ent[1].data_ptr(), _p(bias), _p(y), R, dff, float(p), int(seed), rs,
+                                        hid.data_ptr(), parts.data_ptr(), st), "spacap_tf_ffn_bf3_f32")
+        return hid, parts
     check(lib.spacap_tf_ffn_f32(mode, x2.data_ptr(), Wa.data_ptr(), Wb.data_ptr(), _p(bias), _p(y), R, dff, float(p), int(seed),
-                                rng_state(dev).data_ptr() if (p > 0.0 and mode == 0) else None, hid.data_ptr(), parts.data_ptr(),
-                                torch.cuda.current_stream(dev).cuda_stream), "spacap_tf_ffn_f32")
+                                rs, hid.data_ptr(), parts.data_ptr(), st), "spacap_tf_ffn_f32")
     return hid, parts
 
 
@@ -400,6 +447,8 @@ def run_stack(layers, final_norm, x, mask):
 
     sub = lambda l: (l.sublayer[0], l.sublayer[-1])
     l0 = layers[0]
+    if x.numel() // x.shape[-1] > FFN_BF3_MIN_ROWS:
+        refresh_ffn_pieces(layers)       # this forward's (and its backward's) split-bf16 weight images: one launch
     pw, pb, routing = _packed(l0.self_attn)
     qkv, xres = LnQkv.apply(x, l0.sublayer[0].norm.a_2, l0.sublayer[0].norm.b_2, l0.sublayer[0].norm.eps, pw, pb, *routing)
     out = None
@@ -455,6 +504,11 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
     dff = layers[0].feed_forward.w_1.out_features
     S = dff // 128
     scale = 1.0 / math.sqrt(dk)
+    pieces = None
+    if FFN_BF3 and R > FFN_BF3_MIN_ROWS:
+        refresh_ffn_pieces(layers)
+        pieces = [_FFN_PIECES.get(l.feed_forward.w_1.weight.data_ptr()) for l in layers]
+        pieces = [e[1] for e in pieces] if all(e is not None for e in pieces) else None
     with torch.cuda.device(dev):
         kc = [_new(dev, R, T, D_MODEL) for _ in layers]
         vc = [_new(dev, R, T, D_MODEL) for _ in layers]
@@ -485,9 +539,13 @@ def greedy_decode(dec, generator, embed, pe, indicator, sos, n_words):
                                                  st), "spacap_decode_attn_f32")
                 _rows(0, R, dev, a1=a, w1=sa.linears[-1].weight, bias1=sa.linears[-1].bias, k1=D_MODEL, res=xres, x_out=x1,
                       ln_a=nf.a_2, ln_b=nf.b_2, eps=nf.eps, n_out=n2)
-                check(lib.spacap_tf_ffn_f32(0, n2.data_ptr(), ff.w_1.weight.data_ptr(), ff.w_2.weight.data_ptr(),
-                                            ff.w_1.bias.data_ptr(), None, R, dff, 0.0, 0, None, None, parts.data_ptr(), st),
-                      "spacap_tf_ffn_f32")
+                if pieces is not None:
+                    check(lib.spacap_tf_ffn_bf3_f32(0, n2.data_ptr(), pieces[i].data_ptr(), ff.w_1.bias.data_ptr(), None, R, dff, 0.0, 0,
+                                                    None, None, parts.data_ptr(), st), "spacap_tf_ffn_bf3_f32")
+                else:
+                    check(lib.spacap_tf_ffn_f32(0, n2.data_ptr(), ff.w_1.weight.data_ptr(), ff.w_2.weight.data_ptr(),
+                                                ff.w_1.bias.data_ptr(), None, R, dff, 0.0, 0, None, None, parts.data_ptr(), st),
+                          "spacap_tf_ffn_f32")
                 if i + 1 < len(layers):
                     nn_ = layers[i + 1].sublayer[0].norm
                     _rows(0, R, dev, a1=parts, nparts=S, bias1=ff.w_2.bias, res=x1, x_out=x2, ln_a=nn_.a_2, ln_b=nn_.b_2, eps=nn_.eps,

@@ -118,7 +118,7 @@ def _run(m, kind, x, mask):
     return m(x, mask) if kind == "enc" else m(x, None, None, mask)
 
 
-@pytest.mark.parametrize("kind,B,L", [("enc", 2, 256), ("dec", 3, 32), ("enc", 1, 64)])
+@pytest.mark.parametrize("kind,B,L", [("enc", 2, 256), ("dec", 3, 32), ("enc", 1, 64), ("enc", 8, 256)])   # (8 x 256 rows: split-bf16 feed-forward)
 def test_stack_matches_the_per_operator_path(tf, kind, B, L):
     m = _stack(kind).train()
     x = _rand(B, L, 128, seed=5)
@@ -366,3 +366,47 @@ def test_decode_word_choice_without_logits(R, V):
     assert float((best - chosen).max()) < 1e-4 * float(logits.abs().max())
     assert float((word == logits.argmax(1)).double().mean()) > 0.995
     assert torch.allclose(xn, lut[word] * scale + pe, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,dff,p", [(2048, 2048, 0.0), (1000, 256, 0.0), (2048, 2048, 0.1)])
+def test_feed_forward_block_on_split_bf16_products(tf, R, dff, p):
+    """csrc/tf_layer.hip: tf_ffn_bf3_kernel (both chained products of models/transformer_captioner.py:72-81 as bf16 x 3, weights from
+    the pre-split piece images of spacap_tf_ffn_split_f32) against the fp32-MFMA kernel it replaces for tall inputs: hidden
+    layer, the partial sums of the second product, and the same for the backward direction -- fp32-equivalent (1e-5 of scale,
+    identical ReLU / dropout masks up to units within rounding of zero), and against float64 for the forward."""
+    import types
+    W1, b1 = _rand(dff, 128, seed=7, scale=0.1), _rand(dff, seed=8, scale=0.1)
+    W2 = _rand(128, dff, seed=9, scale=0.05)
+    x, dy = _rand(R, 128, seed=1), _rand(R, 128, seed=2)
+    layer = types.SimpleNamespace(feed_forward=types.SimpleNamespace(w_1=types.SimpleNamespace(weight=W1), w_2=types.SimpleNamespace(weight=W2)))
+    outs = {}
+    for bf3 in (False, True):
+        tf._FFN_PIECES.clear()
+        tf.FFN_BF3 = bf3
+        try:
+            if bf3:
+                tf.refresh_ffn_pieces([layer])
+                assert W1.data_ptr() in tf._FFN_PIECES
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                h, parts = tf._ffn(0, x, W1, W2, b1, None, dff, p, 12345, DEV)
+                dh, gparts = tf._ffn(1, dy, W2, W1, None, h, dff, p, 0, DEV)
+                torch.cuda.synchronize()
+            names = [e.key for e in prof.key_averages()]
+            if names:
+                assert any("tf_ffn_bf3_kernel" in n for n in names) == bf3, names
+        finally:
+            tf.FFN_BF3 = True
+            tf._FFN_PIECES.clear()
+        outs[bf3] = (h, parts.sum(0), dh, gparts.sum(0))
+    for name, a, b in zip(("hid", "w2 product", "dhid", "w1 product"), outs[True], outs[False]):
+        # a hidden unit within fp32 rounding of zero may be gated differently by the two arithmetics: compare where both agree
+        if name in ("hid", "dhid"):
+            same = (outs[True][0] > 0) == (outs[False][0] > 0)
+            assert float(same.float().mean()) > 0.9999
+            a, b = a * same, b * same
+            assert rel(a, b) < 1e-5, (name, rel(a, b))
+        else:
+            assert rel(a, b) < 2e-4, (name, rel(a, b))    # (sums over d_ff that include the few differently gated units)
+    if p == 0.0:
+        h64 = torch.relu(x.double() @ W1.double().t() + b1.double())
+        assert rel(outs[True][0], h64) < 3e-6 and rel(outs[True][1], h64 @ W2.double().t()) < 3e-6
