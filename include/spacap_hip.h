@@ -366,8 +366,7 @@ int spacap_sa_reserve_cus(int n);
 int spacap_sa_mid_fwd_pool_f32(const float *zin, const float *st_in, const float *W, const float *gamma_out, long R,
                                int Cin, int Cout, int S, float *zout, double *part, float *cand_v, uint8_t *cand_i,
                                spacap_stream_t stream);
-/* (zout of spacap_sa_mid_fwd_pool_f32 may be NULL: the layer's output is then not stored at all -- the backward of a pooled last
-   layer needs none of it, see spacap_sa_l3bwd_f32.)  zmax (nullable) f32 [G,C]: the pre-activation of the arg-max row, what
+/* (zout of spacap_sa_mid_fwd_pool_f32 may be NULL: the layer's output is then not stored at all.)  zmax (nullable) f32 [G,C]: the pre-activation of the arg-max row, what
    the pooled layer's BatchNorm backward needs of z when z is not stored. */
 int spacap_sa_pool_finalize_f32(const float *cand_v, const uint8_t *cand_i, const float *stats, const float *gamma, long G,
                                 int S, int C, float *out, uint8_t *arg, float *zmax, spacap_stream_t stream);
@@ -380,29 +379,17 @@ int spacap_sa_pool_fwd_f32(const float *z, const float *stats, long G, int S, in
 int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const uint8_t *arg, const float *z, const float *zmax,
                            const float *stats, long G, int S, int C, float *dym, double *part,
                            spacap_stream_t stream);
-/* Backward of the POOLED last layer of a shared MLP without its pre-activation (lib/pointnet2/pytorch_utils.py:11-36 Conv2d ->
-   BatchNorm2d -> ReLU, lib/pointnet2/pointnet2_modules.py:256-259 max_pool2d; autograd backward).  z3 = a2 W3^T is linear in
-   the layer's input a2 = relu(bn(z2)), so with dz3 = g d + k0 - k1 z3 (coef3 = (g, k0, k1) rows, spacap_sa_bwd_finalize_f32)
-     dy2 = (g d) W3 + k0 W3 - a2 (W3^T diag(k1) W3)        dW3 = (g d)^T a2 + k0 (x) colsum(a2) - diag(k1) W3 (a2^T a2)
-   and one pass over z2 replaces spacap_sa_dgrad_f32 + spacap_sa_wgrad_f32 of that layer (both read z3).
-     _supported: 1 for (C2, C3) in {(64,128), (128,128), (128,256)} and S in {16,32,64} not above the row tile (64 / 32).
-     _prep:  Mneg f32 [C2,C2] = -(W3^T diag(k1) W3), vrow f32 [C2] = k0 W3.
-     _f32:   dym f32 [R/S,C3] + arg u8 [R/S,C3] (spacap_sa_pool_bwd_f32 / _pool_finalize_f32), z2 f32 [R,C2], st2 [C2,4]
-             -> dy2 f32 [R,C2] (masked by relu'), part = layer 2's BatchNorm sums, partW f32 [_parts][_part_floats].
-     _dw:    partW -> dW3 f32 [C3,C2]; sums = double scratch of _part_floats entries. */
-int spacap_sa_l3bwd_supported(int C2, int C3, int S);
-int spacap_sa_l3bwd_parts(long R, int C2, int C3);
+/* Weight gradient of a POOLED last layer of a shared MLP from its INPUT pre-activation z2 alone (lib/pointnet2/pytorch_utils.py:11-36
+   Conv2d -> BatchNorm2d -> ReLU, lib/pointnet2/pointnet2_modules.py:256-259 max_pool2d; autograd backward).  z3 = a2 W3^T is linear
+   in the layer's input a2 = relu(bn(z2)), so with dz3 = g d + k0 - k1 z3 (coef3 = (g, k0, k1) rows, spacap_sa_bwd_finalize_f32)
+     dW3 = (g d)^T a2 + k0 (x) colsum(a2) - diag(k1) W3 (a2^T a2)
+   -- z3 is not read (replaces spacap_sa_wgrad_f32 with arg != NULL, which streams z3 and z2).  spacap_sa_wgrad_pool_f32 leaves partial
+   sums of (g d)^T a2, a2^T a2 and colsum(a2) per workgroup, partW f32 [_parts][spacap_sa_l3bwd_part_floats(C2, C3)];
+   spacap_sa_l3bwd_dw_f32 combines them into dW3 f32 [C3,C2] (sums = double scratch of _part_floats entries).
+   _supported: (C2, C3, S) in {(64,128,64), (128,128,32), (128,256,32)}.  arg 4-byte, z2 and dym 16-byte aligned. */
 long spacap_sa_l3bwd_part_floats(int C2, int C3);
-int spacap_sa_l3bwd_prep_f32(const float *coef3, const float *W3, int C3, int C2, float *Mneg, float *vrow, spacap_stream_t stream);
-int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, const float *coef3, const float *W3, const float *Mneg,
-                        const float *vrow, const float *z2, const float *st2, long R, int C3, int C2, float *dy2, double *part,
-                        float *partW, spacap_stream_t stream);
 int spacap_sa_l3bwd_dw_f32(const float *partW, int nparts, const float *coef3, const float *W3, int C3, int C2, double *sums,
                            float *dW3, spacap_stream_t stream);
-/* Weight gradient of a POOLED last layer from z2 alone (same reference lines as above; replaces spacap_sa_wgrad_f32 with
-   arg != NULL, which streams z3 and z2): partial sums of (g d)^T a2, a2^T a2 and colsum(a2) per workgroup; spacap_sa_l3bwd_dw_f32
-   combines them into dW3.  _supported: (C2, C3, S) in {(64,128,64), (128,128,32), (128,256,32)}.  arg 4-byte, z2 and dym 16-byte aligned.
-   partW f32 [_parts][spacap_sa_l3bwd_part_floats(C2, C3)]. */
 int spacap_sa_wgrad_pool_supported(int C2, int C3, int S);
 int spacap_sa_wgrad_pool_parts(long R, int C2, int C3, int S);
 int spacap_sa_wgrad_pool_f32(const float *dym, const uint8_t *arg, int S, const float *coef3, const float *z2, const float *st2,

@@ -122,11 +122,7 @@ SIGNATURES = {
     "spacap_rel_wide_transpose_f32": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "spacap_rel_wide_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_rel_wide_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
-    "spacap_sa_l3bwd_supported": (_i, [_i, _i, _i]),
-    "spacap_sa_l3bwd_parts": (_i, [_l, _i, _i]),
     "spacap_sa_l3bwd_part_floats": (_l, [_i, _i]),
-    "spacap_sa_l3bwd_prep_f32": (_i, [_p, _p, _i, _i, _p, _p, _p]),
-    "spacap_sa_l3bwd_f32": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_l3bwd_dw_f32": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "spacap_sa_wgrad_pool_supported": (_i, [_i, _i, _i]),
     "spacap_sa_wgrad_pool_parts": (_i, [_l, _i, _i, _i]),

@@ -1662,67 +1662,9 @@ extern "C" int spacap_sa_pool_bwd_f32(const float *dout, const float *out, const
   return SPACAP_OK;
 }
 
-// ---- pooled last layer without z3 (sa_l3bwd.inc) ------------------------------------------------------------------------
-extern "C" int spacap_sa_l3bwd_supported(int C2, int C3, int S) { return l3bwd_shape(C2, C3, S) ? 1 : 0; }
-namespace {
-int l3bwd_grid(long R, int C2, int C3) {
-  const int tm = l3bwd_tile(C2);
-  long g = device_cus(), tiles = (R + tm - 1) / tm;
-  if (g > NPART) g = NPART;
-  if (g > tiles) g = tiles;
-  return (int)(g < 1 ? 1 : g);
-}
-}  // namespace
-/* workgroups (= partial results) of spacap_sa_l3bwd_f32, and floats per partial: [C3][C2] | [C2][C2] | [C2] */
-extern "C" int spacap_sa_l3bwd_parts(long R, int C2, int C3) { return l3bwd_shape(C2, C3, 16) && R >= 1 ? l3bwd_grid(R, C2, C3) : 0; }
+// ---- pooled layer's weight gradient from z2 alone: partial layout + reduction (sa_l3bwd.inc) ------------------------------------
+/* floats per workgroup partial of spacap_sa_wgrad_pool_f32: [C3][C2] | [C2][C2] | [C2] */
 extern "C" long spacap_sa_l3bwd_part_floats(int C2, int C3) { return (long)C3 * C2 + (long)C2 * C2 + C2; }
-
-/* Mneg [C2][C2] = -(W3^T diag(k1) W3), vrow [C2] = k0 W3 from the pooled layer's backward constants coef3 [C3][4]. */
-extern "C" int spacap_sa_l3bwd_prep_f32(const float *coef3, const float *W3, int C3, int C2, float *Mneg, float *vrow,
-                                        spacap_stream_t stream) {
-  const char *what = "spacap_sa_l3bwd_prep_f32";
-  SPACAP_REQUIRE(coef3 && W3 && Mneg && vrow && C3 >= 1 && C2 >= 1, "%s: bad arguments", what);
-  SPACAP_REQUIRE(C2 <= 1024 && 1024 % C2 == 0, "%s: C2=%d unsupported", what, C2);
-  hipLaunchKernelGGL(sa_l3_prep_kernel, dim3(C2 + 1), dim3(1024), 0, spacap::as_stream(stream), coef3, W3, C3, C2, Mneg, vrow);
-  SPACAP_CHECK_LAUNCH(what);
-  return SPACAP_OK;
-}
-
-/* dy2 [R][C2] and the partial sums of dW3 from (dym, arg) of the pooled layer, z2 and the constants of spacap_sa_l3bwd_prep_f32;
-   part receives layer 2's BatchNorm sums (sum dy2, sum dy2 xhat2).  partW [spacap_sa_l3bwd_parts][spacap_sa_l3bwd_part_floats]. */
-extern "C" int spacap_sa_l3bwd_f32(const float *dym, const uint8_t *arg, int S, const float *coef3, const float *W3, const float *Mneg,
-                                   const float *vrow, const float *z2, const float *st2, long R, int C3, int C2, float *dy2,
-                                   double *part, float *partW, spacap_stream_t stream) {
-  const char *what = "spacap_sa_l3bwd_f32";
-  SPACAP_REQUIRE(dym && arg && coef3 && W3 && Mneg && vrow && z2 && st2 && dy2 && part && partW && R >= 1, "%s: bad arguments", what);
-  SPACAP_REQUIRE(l3bwd_shape(C2, C3, S) && R % S == 0, "%s: (C2=%d, C3=%d, S=%d) unsupported", what, C2, C3, S);
-  const L3Args a{dym, arg, coef3, W3, Mneg, vrow, z2, st2, R, S, dy2, part, partW, getenv("SPACAP_L3_DBG") ? atoi(getenv("SPACAP_L3_DBG")) : 0};
-  const int grid = l3bwd_grid(R, C2, C3);
-  hipStream_t s = spacap::as_stream(stream);
-#define L3(C2V, C3V, TV, PV)                                                                                                      \
-  {                                                                                                                               \
-    static unsigned long long lds_ok = 0;                                                                                         \
-    SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&sa_l3bwd_kernel<C2V, C3V, TV, PV>),                \
-                                               (int)l3bwd_lds_bytes(C2V, TV, PV), lds_ok), what);                                 \
-    hipLaunchKernelGGL((sa_l3bwd_kernel<C2V, C3V, TV, PV>), dim3(grid), dim3(C2V * 4), l3bwd_lds_bytes(C2V, TV, PV), s, a);       \
-  }
-  // C2 = 64: one launch; C2 = 128: the data half, then the weight half (each streams z2; one register file holds either)
-  const bool only_w = (a.dbg & 16) != 0, only_d = (a.dbg & 32) != 0;   // lab: the weight half / the data half alone
-  if (C2 == 64) {
-    if (only_w) L3(64, 128, 64, 2)
-    else if (only_d) L3(64, 128, 64, 1)
-    else L3(64, 128, 64, 0)
-  } else if (C3 == 128) {
-    if (!only_w) L3(128, 128, 32, 1)
-    if (!only_d) L3(128, 128, 32, 2)
-  } else {
-    if (!only_w) L3(128, 256, 32, 1)
-    if (!only_d) L3(128, 256, 32, 2)
-  }
-#undef L3
-  SPACAP_CHECK_LAUNCH(what);
-  return SPACAP_OK;
-}
 
 /* dW3 [C3][C2] from the workgroups' partials: sums (double scratch, spacap_sa_l3bwd_part_floats entries) then
    dW3 = S + k0 (x) colsum(a2) - diag(k1) W3 Gram. */

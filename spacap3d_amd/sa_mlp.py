@@ -21,13 +21,7 @@ RECOMPUTE_Z1 = True
 # them): 14 sums per row, one thread per row, instead of 2 x 64 sums with 16 threads per row (csrc/sa_mlp.hip:
 # sa_l1_moments_kernel; 87 -> ~20 us at SA1).  The statistics differ from the summed-z1 form by rounding only (~1e-7 relative).
 L1_MOMENTS = os.environ.get("SPACAP_SA_L1_MOMENTS", "1") not in ("", "0")
-# pooled last layer: do not store its pre-activation z3; its backward is then one pass over z2 (see _SAMLP.backward,
-# csrc/sa_l3bwd.inc).  Correct (float64 gate, A/B leg of tests/test_sa_mlp_gpu.py) and 0.8 - 1.1 GB of HBM traffic lighter per
-# module, but SLOWER than the stored-z3 kernels as measured in round 4 (SA1: 1 010 vs 499 us, tools/lab/l3bwd_bench.py): the
-# scatter of the sparse term through LDS float atomics costs 540 us there (ds_add_f32 runs at ~1 500 cycles per wave
-# instruction on gfx950), the streaming skeleton with one tile in flight another 240.  Off until that is fixed.
-Z3_FREE = os.environ.get("SPACAP_SA_Z3_FREE", "0") not in ("", "0")
-# pooled last layer with z3 stored: its WEIGHT gradient alone from z2 (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel -- the sparse
+# pooled last layer: its WEIGHT gradient from z2 alone (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel -- the sparse
 # term (g d)^T a2 plus the Gram matrix a2^T a2) instead of the dense kernel that streams z3 and z2 and multiplies a [C3 x rows]
 # operand with one non-zero per group and channel.  SA1: 92 + 12 us against 249 + 12 us (tools/lab/wgrad_pool_bench.py).  Used
 # from POOL_WGRAD_MIN_ROWS rows on (below, the two extra launches of the reduction cost more than the pass saves).
@@ -123,11 +117,8 @@ class _SAMLP(Function):
             has_feat = int(feat is not None)
             z1 = torch.empty(R, 4 if recompute else C1, **f32)
             z2 = torch.empty(R, C2, **f32)
-            # pooled last layer: when the z3-free backward has a kernel for this shape (csrc/sa_l3bwd.inc) the layer's
-            # pre-activation is never stored -- the forward keeps the pooling candidates, the backward the arg-max rows' values
             pool_fused = bool(lib.spacap_sa_mid_fwd_pool_supported(C2, C3, S))
-            z3_free = Z3_FREE and pool_fused and bool(lib.spacap_sa_l3bwd_supported(C2, C3, S))
-            z3 = None if z3_free else torch.empty(R, C3, **f32)
+            z3 = torch.empty(R, C3, **f32)
             # (the arg-max rows' pre-activations: the pooled layer's BatchNorm sums in the backward read them instead of
             # gathering 4 bytes per element out of z3)
             zmax = torch.empty(B, N, C3, **f32) if pool_fused else None
@@ -201,9 +192,7 @@ class _SAMLP(Function):
         if selections.HOOK is not None:    # tests only: see selections.py
             selections.visit("sa", gammas=[g1, g2, g3], zs=[None if recompute else z1, z2, z3], stats=stats, arg=arg, out=out,
                              zmax=zmax, dims=(B, N, S))
-        ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3 if z3 is not None else zmax, stats[0], stats[1],
-                              stats[2], out, arg, zmax if z3 is not None else None)
-        ctx.z3_free = z3_free         # the saved "z3" is then zmax (B, N, C3): the arg-max rows' pre-activations
+        ctx.save_for_backward(xyz, new_xyz, idx, feat, W1c, W2c, W3c, z1, z2, z3, stats[0], stats[1], stats[2], out, arg, zmax)
         ctx.pm = pmc                  # (a tensor input: kept outside save_for_backward only to keep the saved tuple's layout)
         ctx.rdiv = float(rdiv)
         ctx.rows_index = rows_index   # prebuilt inverted index of idx (rows_index(idx, Np)), or None
@@ -236,47 +225,29 @@ class _SAMLP(Function):
 
             # pooled layer: masked gradient + BN sums over the arg-max rows
             dym = torch.empty(G, C3, **f32)
-            z3_free = ctx.z3_free
-            check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), None if z3_free else z3.data_ptr(),
-                                             z3.data_ptr() if z3_free else _ptr(zmax), st3.data_ptr(), G, S, C3, dym.data_ptr(),
-                                             part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
+            check(lib.spacap_sa_pool_bwd_f32(dout.data_ptr(), out.data_ptr(), arg.data_ptr(), z3.data_ptr(), _ptr(zmax), st3.data_ptr(), G, S, C3,
+                                             dym.data_ptr(), part.data_ptr(), st), "spacap_sa_pool_bwd_f32")
             finalize(2, C3, st3)
             dy2 = torch.empty(R, C2, **f32)
-            if z3_free:
-                # layer 3 without z3: ONE pass over z2 gives dy2, layer 2's BN sums and the partial sums of dW3
-                # (csrc/sa_l3bwd.inc: dy2 = (g d) W3 + k0 W3 - a2 M;  dW3 = (g d)^T a2 + k0 (x) colsum a2 - diag(k1) W3 a2^T a2)
-                mneg, vrow = torch.empty(C2, C2, **f32), torch.empty(C2, **f32)
-                check(lib.spacap_sa_l3bwd_prep_f32(coef[2].data_ptr(), W3.data_ptr(), C3, C2, mneg.data_ptr(), vrow.data_ptr(), st),
-                      "spacap_sa_l3bwd_prep_f32")
-                npw, nfl = int(lib.spacap_sa_l3bwd_parts(R, C2, C3)), int(lib.spacap_sa_l3bwd_part_floats(C2, C3))
+            # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
+            if POOL_WGRAD and R >= POOL_WGRAD_MIN_ROWS and lib.spacap_sa_wgrad_pool_supported(C2, C3, S):
+                # from z2 alone: dW3 = (g d)^T a2 + k0 (x) colsum a2 - diag(k1) W3 a2^T a2
+                npw, nfl = int(lib.spacap_sa_wgrad_pool_parts(R, C2, C3, S)), int(lib.spacap_sa_l3bwd_part_floats(C2, C3))
                 pw = torch.empty(npw, nfl, **f32)
-                check(lib.spacap_sa_l3bwd_f32(dym.data_ptr(), arg.data_ptr(), S, coef[2].data_ptr(), W3.data_ptr(), mneg.data_ptr(),
-                                              vrow.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
-                                              part.data_ptr(), pw.data_ptr(), st), "spacap_sa_l3bwd_f32")
+                check(lib.spacap_sa_wgrad_pool_f32(dym.data_ptr(), arg.data_ptr(), S, coef[2].data_ptr(), z2.data_ptr(),
+                                                   st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_pool_f32")
                 sums = torch.empty(nfl, dtype=torch.float64, device=dev)
                 dW3 = torch.empty(C3, C2, **f32)
                 check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef[2].data_ptr(), W3.data_ptr(), C3, C2, sums.data_ptr(),
                                                  dW3.data_ptr(), st), "spacap_sa_l3bwd_dw_f32")
             else:
-                # layer 3: weight gradient, then data gradient (its epilogue produces layer 2's BN sums)
-                if POOL_WGRAD and R >= POOL_WGRAD_MIN_ROWS and lib.spacap_sa_wgrad_pool_supported(C2, C3, S):
-                    # from z2 alone: dW3 = (g d)^T a2 + k0 (x) colsum a2 - diag(k1) W3 a2^T a2
-                    npw, nfl = int(lib.spacap_sa_wgrad_pool_parts(R, C2, C3, S)), int(lib.spacap_sa_l3bwd_part_floats(C2, C3))
-                    pw = torch.empty(npw, nfl, **f32)
-                    check(lib.spacap_sa_wgrad_pool_f32(dym.data_ptr(), arg.data_ptr(), S, coef[2].data_ptr(), z2.data_ptr(),
-                                                       st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_pool_f32")
-                    sums = torch.empty(nfl, dtype=torch.float64, device=dev)
-                    dW3 = torch.empty(C3, C2, **f32)
-                    check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef[2].data_ptr(), W3.data_ptr(), C3, C2, sums.data_ptr(),
-                                                     dW3.data_ptr(), st), "spacap_sa_l3bwd_dw_f32")
-                else:
-                    pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
-                    check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
-                                                  z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-                    dW3 = sum_slabs(pw, deferrable=True)
-                check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
-                                              W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
-                                              part.data_ptr(), st), "spacap_sa_dgrad_f32")
+                pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C3, C2, 1)), C3, C2, **f32)
+                check(lib.spacap_sa_wgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                              z2.data_ptr(), st2.data_ptr(), R, C3, C2, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+                dW3 = sum_slabs(pw, deferrable=True)
+            check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3.data_ptr(), coef[2].data_ptr(),
+                                          W3.data_ptr(), z2.data_ptr(), st2.data_ptr(), R, C3, C2, dy2.data_ptr(),
+                                          part.data_ptr(), st), "spacap_sa_dgrad_f32")
             finalize(1, C2, st2)
             # layer 2
             pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)

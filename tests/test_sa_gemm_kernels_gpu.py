@@ -258,83 +258,6 @@ def test_plain_row_product_matches_float64(R, ci, co):
     assert ((out[sel].double() - ref).abs().max() / ref.abs().max()).item() < TOL
 
 
-L3_SHAPES = [(64 * 300, 64, 128, 64), (32 * 513, 128, 256, 32), (16 * 1001, 128, 256, 16), (16 * 7, 128, 128, 16), (32 * 40, 64, 128, 32),
-             (64 * 4096, 64, 128, 64), (32 * 8192, 128, 256, 32)]
-
-
-@pytest.mark.parametrize("R,c2,c3,S", L3_SHAPES)
-def test_pooled_last_layer_backward_without_its_preactivation(R, c2, c3, S):
-    """csrc/sa_l3bwd.inc (spacap_sa_l3bwd_prep / _f32 / _dw) against a float64 restatement of the backward of Conv2d 1x1 ->
-    BatchNorm2d -> ReLU -> max_pool2d (lib/pointnet2/pytorch_utils.py:11-36, lib/pointnet2/pointnet2_modules.py:256-259) through
-    the formula the stored-z3 kernels implement: dz3 = g d + k0 - k1 z3 with z3 = a2 W3^T, dy2 = (dz3 W3) [a2 > 0],
-    dW3 = dz3^T a2, and layer 2's BatchNorm sums.  Also against the stored-z3 kernels themselves (fp32 level)."""
-    from spacap3d_amd._native import check, lib
-    if not lib.spacap_sa_l3bwd_supported(c2, c3, S):
-        pytest.skip("no kernel for this shape")
-    dev = "cuda:0"
-    torch.manual_seed(R + c3)
-    G = R // S
-    dym = torch.randn(G, c3, device=dev)
-    dym[torch.rand(G, c3, device=dev) < 0.3] = 0.0            # pooled activations that were zero pass no gradient
-    arg = torch.randint(0, S, (G, c3), dtype=torch.uint8, device=dev)
-    arg[::5] = 3                                               # many channels of a group choosing the same row
-    z2 = torch.randn(R, c2, device=dev)
-    W3 = 0.2 * torch.randn(c3, c2, device=dev)
-    coef = torch.stack([1 + 0.1 * torch.rand(c3, device=dev), 0.02 * torch.randn(c3, device=dev), 0.02 * torch.randn(c3, device=dev),
-                        torch.zeros(c3, device=dev)], dim=1).contiguous()
-    st2 = torch.stack([0.05 * torch.randn(c2, device=dev), 1 + 0.1 * torch.rand(c2, device=dev), 1 + 0.2 * torch.rand(c2, device=dev),
-                       0.1 * torch.randn(c2, device=dev)], dim=1).contiguous()
-    s = torch.cuda.current_stream().cuda_stream
-    nparts = int(lib.spacap_sa_nparts())
-    mneg, vrow = torch.empty(c2, c2, device=dev), torch.empty(c2, device=dev)
-    check(lib.spacap_sa_l3bwd_prep_f32(coef.data_ptr(), W3.data_ptr(), c3, c2, mneg.data_ptr(), vrow.data_ptr(), s), "prep")
-    npw, nfl = int(lib.spacap_sa_l3bwd_parts(R, c2, c3)), int(lib.spacap_sa_l3bwd_part_floats(c2, c3))
-    pw = torch.empty(npw, nfl, device=dev)
-    dy2 = torch.full((R, c2), float("nan"), device=dev)
-    part = torch.empty(nparts * 2 * c2, dtype=torch.float64, device=dev)
-    check(lib.spacap_sa_l3bwd_f32(dym.data_ptr(), arg.data_ptr(), S, coef.data_ptr(), W3.data_ptr(), mneg.data_ptr(), vrow.data_ptr(),
-                                  z2.data_ptr(), st2.data_ptr(), R, c3, c2, dy2.data_ptr(), part.data_ptr(), pw.data_ptr(), s), "l3bwd")
-    sums = torch.empty(nfl, dtype=torch.float64, device=dev)
-    dW3 = torch.empty(c3, c2, device=dev)
-    check(lib.spacap_sa_l3bwd_dw_f32(pw.data_ptr(), npw, coef.data_ptr(), W3.data_ptr(), c3, c2, sums.data_ptr(), dW3.data_ptr(), s), "dw")
-    torch.cuda.synchronize()
-    # ---- float64 restatement ----
-    z2d, W3d, cd, sd = z2.double(), W3.double(), coef.double(), st2.double()
-    pre = (z2d - sd[:, 0]) * sd[:, 2] + sd[:, 3]
-    a2 = pre.clamp_min(0)
-    z3 = a2 @ W3d.t()
-    d = torch.zeros(G, S, c3, dtype=torch.float64, device=dev)
-    d.scatter_(1, arg.long().unsqueeze(1), dym.double().unsqueeze(1))
-    dz3 = cd[:, 0] * d.view(R, c3) + cd[:, 1] - cd[:, 2] * z3
-    dy2_ref = (dz3 @ W3d) * (pre > 0)
-    dW3_ref = dz3.t() @ a2
-    xhat = (z2d - sd[:, 0]) * sd[:, 1]
-    s1_ref, s2_ref = dy2_ref.sum(0), (dy2_ref * xhat).sum(0)
-    assert torch.isfinite(dy2).all()
-    # rows whose pre-activation sits within float rounding of the ReLU threshold may gate differently in float64
-    near = (pre.abs() < 1e-6)
-    err = ((dy2.double() - dy2_ref).abs() * (~near)).max() / dy2_ref.abs().max()
-    assert err.item() < 3e-6, err.item()
-    errw = (dW3.double() - dW3_ref).abs().max() / dW3_ref.abs().max()
-    assert errw.item() < 3e-6, errw.item()
-    p = part.view(nparts, 2, c2).sum(0)
-    assert ((p[0] - s1_ref).abs().max() / s1_ref.abs().max()).item() < 1e-5
-    assert ((p[1] - s2_ref).abs().max() / s2_ref.abs().max()).item() < 1e-5
-    # ---- the stored-z3 kernels on the same inputs (z3 as the forward stores it: an fp32 tensor) ----
-    z3f = z3.float().contiguous()
-    dy2_old = torch.empty(R, c2, device=dev)
-    check(lib.spacap_sa_dgrad_f32(dym.data_ptr(), arg.data_ptr(), S, z3f.data_ptr(), coef.data_ptr(), W3.data_ptr(), z2.data_ptr(),
-                                  st2.data_ptr(), R, c3, c2, dy2_old.data_ptr(), part.data_ptr(), s), "dgrad")
-    torch.cuda.synchronize()
-    assert ((dy2 - dy2_old).abs().max() / dy2_old.abs().max()).item() < 1e-5
-    # ---- twice the same launch: bit-identical (the sparse sums use LDS atomics whose order is fixed by construction) ----
-    dy2b, pwb = torch.empty_like(dy2), torch.empty_like(pw)
-    check(lib.spacap_sa_l3bwd_f32(dym.data_ptr(), arg.data_ptr(), S, coef.data_ptr(), W3.data_ptr(), mneg.data_ptr(), vrow.data_ptr(),
-                                  z2.data_ptr(), st2.data_ptr(), R, c3, c2, dy2b.data_ptr(), part.data_ptr(), pwb.data_ptr(), s), "l3bwd")
-    torch.cuda.synchronize()
-    assert torch.equal(dy2, dy2b) and torch.equal(pw, pwb)
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("R,c2,c3,S", [(64 * 700, 64, 128, 64), (64 * 3, 64, 128, 64), (32 * 2100, 128, 256, 32), (32 * 517, 128, 128, 32),
                                        (32, 128, 256, 32)])

@@ -107,30 +107,6 @@ def sa_wgrad(R, ck, cp, pooled, S, dev, label):
                 what=f"{label}: dW = dz^T relu(bn(z_prev)) per row slab, {R} rows")
 
 
-def sa_l3bwd(R, c2, c3, S, dev, label):
-    """The pooled last layer's backward WITHOUT its stored pre-activation (csrc/sa_l3bwd.inc; off by default in round 4, see
-    sa_mlp.Z3_FREE): one pass over z2 (two for C2 = 128) instead of sa_wgrad + sa_dgrad, which both read z3."""
-    G = R // S
-    dym, arg = _rand(G, c3, dev=dev), torch.randint(0, S, (G, c3), dtype=torch.uint8, device=dev)
-    z2, W3, coef, st2 = _rand(R, c2, dev=dev), _rand(c3, c2, dev=dev) * 0.1, _stats(c3, dev), _stats(c2, dev)
-    coef[:, 1:3] *= 0.02
-    mneg, vrow = torch.empty(c2, c2, dtype=torch.float32, device=dev), torch.empty(c2, dtype=torch.float32, device=dev)
-    check(lib.spacap_sa_l3bwd_prep_f32(coef.data_ptr(), W3.data_ptr(), c3, c2, mneg.data_ptr(), vrow.data_ptr(), _st(dev)), "prep")
-    npw, nfl = int(lib.spacap_sa_l3bwd_parts(R, c2, c3)), int(lib.spacap_sa_l3bwd_part_floats(c2, c3))
-    pw, dy2, part = torch.empty(npw, nfl, dtype=torch.float32, device=dev), torch.empty(R, c2, dtype=torch.float32, device=dev), _part(max(c2, c3), dev)
-
-    def run():
-        check(lib.spacap_sa_l3bwd_f32(dym.data_ptr(), arg.data_ptr(), S, coef.data_ptr(), W3.data_ptr(), mneg.data_ptr(), vrow.data_ptr(),
-                                      z2.data_ptr(), st2.data_ptr(), R, c3, c2, dy2.data_ptr(), part.data_ptr(), pw.data_ptr(), _st(dev)),
-              "sa_l3bwd")
-    passes = 1 if c2 == 64 else 2
-    return dict(name=f"sa_l3bwd {c2}->{c3} R={R} ({label}, no z3)", kernel="sa_l3bwd_kernel", run=run, bf16_products=0,
-                flops=2.0 * R * 2 * c2 * c2, bytes=4.0 * R * c2 * (passes + 1) + 5.0 * G * c3 + 4.0 * pw.numel(),
-                keep=(dym, arg, z2, W3, coef, st2, mneg, vrow, pw, dy2, part),
-                what=f"{label}: dy2 and the partial sums of dW3 from z2, the pooled gradient and the arg-max map: {passes} pass(es) over "
-                     f"z2, no z3 (the stored-z3 kernels read 4 R (2 c3 + 2 c2) + write 4 R c2 bytes)")
-
-
 def sa_wgrad_pool(R, c2, c3, S, dev, label):
     """The pooled layer's weight gradient from z2 alone (csrc/sa_l3bwd.inc: sa_wgrad_pool_kernel): sparse term + Gram matrix."""
     G = R // S
@@ -309,8 +285,6 @@ def cases(dev, B=8):
         lambda: sa_wgrad(R1, 64, 64, False, 64, dev, "SA1 layer 2"),
         lambda: sa_wgrad_pool(R1, 64, 128, 64, dev, "SA1 layer 3"),
         lambda: sa_wgrad_pool(R2, 128, 256, 32, dev, "SA2 layer 3"),
-        lambda: sa_l3bwd(R1, 64, 128, 64, dev, "SA1 layer 3"),
-        lambda: sa_l3bwd(R2, 128, 256, 32, dev, "SA2 layer 3"),
         lambda: sa_mid_fwd_pool(R1, 64, 128, 64, dev, "SA1 layer 3", True),
         lambda: sa_mid_fwd_pool(R1, 64, 128, 64, dev, "SA1 layer 3", False),
         lambda: rel_fused(B, 256, 0, dev),
