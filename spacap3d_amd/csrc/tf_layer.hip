@@ -698,7 +698,7 @@ typedef __bf16 ff_bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int FF_LD = D + 8, FF_IMG = 64 * FF_LD;
 struct TfFfnBf3Args {
   const float *x, *bias, *y;
-  const __bf16 *Wa, *Wb;   // Wa [3][dff][128]: rows = hidden units; Wb [3][128][dff]: rows = the second product's outputs
+  const __bf16 *Wa, *Wb;   // the two products' weight piece images [3][dff 128], in operand order (tf_ffn_split_kernel)
   float *hid, *part;
   long R;
   int dff;
@@ -739,21 +739,23 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
     }
   }
   constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};   // smallest piece products first
-  // weight operand of a product: wq[t][piece] = rows (base row + 16 t + l15), contraction indices 32 kc + 8 lg .. + 7
-  auto wload = [&](const __bf16 *base, size_t img, size_t ld, int kc, ff_bf16x8 (*wq)[3]) {
+  // weight operand of a product, step kc: wq[t][piece] = 8 consecutive contraction indices of output unit 32 w + 16 t + l15.  The
+  // piece images are stored in OPERAND ORDER (tf_ffn_split_kernel): the 64 lanes of one load read 1 KB of consecutive bytes
+  // (per-lane 16-byte reads at a row pitch of 256 B / 4 KB ran the kernel at the L1's line rate, not the matrix rate)
+  auto wload = [&](const __bf16 *base, size_t img, int kc, ff_bf16x8 (*wq)[3]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) wq[t][p] = *reinterpret_cast<const ff_bf16x8 *>(base + p * img + (size_t)(16 * t + l15) * ld + 32 * kc + 8 * lg);
+      for (int p = 0; p < 3; ++p) wq[t][p] = *reinterpret_cast<const ff_bf16x8 *>(base + p * img + (size_t)(((t * 4 + kc) * 64 + lane) * 8));
   };
   // one product: acc[t][mt][u] = out[row 16 mt + l15][unit 32 w + 16 t + 4 lg + u] (weights as the A operand: a lane ends up with
   // four consecutive units of one row)
-  auto product = [&](const __bf16 *wbase, size_t img, size_t ld, f32x4 (*acc)[4]) {
+  auto product = [&](const __bf16 *wbase, size_t img, f32x4 (*acc)[4]) {
     ff_bf16x8 wq[2][2][3];
-    wload(wbase, img, ld, 0, wq[0]);
+    wload(wbase, img, 0, wq[0]);
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-      if (kc + 1 < 4) wload(wbase, img, ld, kc + 1, wq[(kc + 1) & 1]);
+      if (kc + 1 < 4) wload(wbase, img, kc + 1, wq[(kc + 1) & 1]);
       ff_bf16x8 a[4][3];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
@@ -773,7 +775,8 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  product(P.Wa + (size_t)(c0 + 32 * w) * D, (size_t)dff * D, D, acc);
+  const size_t wimg = (size_t)dff * D, wofs = (size_t)(blockIdx.y * 4 + w) * 4096;   // (slice, wave) block of 2 x 4 x 64 x 8 elements
+  product(P.Wa + wofs, wimg, acc);
   f32x4 bb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (!BWD && P.bias) bb[0] = ld4(P.bias + c0 + 32 * w + 4 * lg), bb[1] = ld4(P.bias + c0 + 32 * w + 16 + 4 * lg);
   const DropSeed sd = make_seed(P.seed, P.seed_dev);
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
     }
   }
   __syncthreads();
-  product(P.Wb + (size_t)(32 * w) * dff + c0, (size_t)D * dff, dff, acc);
+  product(P.Wb + wofs, wimg, acc);
   float *out = P.part + (size_t)blockIdx.y * P.R * D;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -824,8 +827,13 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
 }
 
 // the four piece images of up to 16 feed-forward layers in one launch: per layer W1 f32 [dff][128], W2 f32 [128][dff] ->
-//   out + 0: W1  pieces [3][dff][128]     out + 1 img: W2 pieces [3][128][dff]
-//   out + 2: W2^T pieces [3][dff][128]    out + 3 img: W1^T pieces [3][128][dff]            (img = 3 dff 128 elements)
+//   out + 0 img: first-product operands of the forward  (unit = hidden h, contraction k = model channel:  W1[h][k])
+//   out + 1 img: second-product operands of the forward (unit = model channel m, contraction k = hidden:  W2[m][k])
+//   out + 2 img: first-product operands of the backward (unit = hidden h, contraction k = model channel:  W2[k][h])
+//   out + 3 img: second-product operands of the backward (unit = model channel m, contraction k = hidden: W1[k][m])
+// img = 3 dff 128 elements (three pieces of dff 128).  Inside a piece the elements are in OPERAND ORDER of tf_ffn_bf3_kernel:
+//   index = ((((slice c, wave w), t, kc), lane), e)  <->  unit 32 w + 16 t + (lane % 16) [+ 128 c for hidden units],
+//   contraction index 32 kc + 8 (lane / 16) + e [+ 128 c when it runs over hidden units]
 constexpr int FF_SPLIT_MAX = 16;
 struct FfSplitTable {
   int nlayers, dff;
@@ -833,32 +841,24 @@ struct FfSplitTable {
   __bf16 *out[FF_SPLIT_MAX];
 };
 __global__ __launch_bounds__(256) void tf_ffn_split_kernel(const FfSplitTable T) {
-  __shared__ float tile[2][32][33];
-  const int layer = blockIdx.z, dff = T.dff;
+  const int layer = blockIdx.y, dff = T.dff;
   const size_t n = (size_t)dff * D, img = 3 * n;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63), kc = (int)((idx >> 9) & 3), t = (int)((idx >> 11) & 1),
+            w = (int)((idx >> 12) & 3), c = (int)(idx >> 14);
+  const int unit = 32 * w + 16 * t + (lane & 15), kk = 32 * kc + 8 * (lane >> 4) + e;   // inside the 128 x 128 block of slice c
+  const float *W1 = T.w1[layer], *W2 = T.w2[layer];
+  const int h_u = 128 * c + unit, h_k = 128 * c + kk;
+  const float v[4] = {W1[(size_t)h_u * D + kk], W2[(size_t)unit * dff + h_k], W2[(size_t)kk * dff + h_u], W1[(size_t)h_k * D + unit]};
   __bf16 *o = T.out[layer];
-  // a 32 x 32 tile of the [dff][128] view of W1 and of the [128][dff] view of W2: straight and transposed images of both
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int h0 = blockIdx.x * 32, m0 = blockIdx.y * 32;   // hidden-unit block, model-channel block
-  auto put = [&](__bf16 *dst, size_t idx, float v) {
-    const __bf16 h = (__bf16)v;
-    const float r = v - (float)h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hh = (__bf16)v[i];
+    const float r = v[i] - (float)hh;
     const __bf16 m = (__bf16)r;
-    dst[idx] = h, dst[n + idx] = m, dst[2 * n + idx] = (__bf16)(r - (float)m);
-  };
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    const float a = T.w1[layer][(size_t)(h0 + r) * D + m0 + tx];      // W1[hidden h0 + r][channel m0 + tx]
-    const float b = T.w2[layer][(size_t)(m0 + r) * dff + h0 + tx];    // W2[channel m0 + r][hidden h0 + tx]
-    tile[0][r][tx] = a, tile[1][r][tx] = b;
-    put(o, (size_t)(h0 + r) * D + m0 + tx, a);                        // W1 pieces
-    put(o + img, (size_t)(m0 + r) * dff + h0 + tx, b);                // W2 pieces
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = ty; r < 32; r += 8) {
-    put(o + 2 * img, (size_t)(h0 + r) * D + m0 + tx, tile[1][tx][r]); // W2^T[hidden h0 + r][channel m0 + tx] = W2[m0 + tx][h0 + r]
-    put(o + 3 * img, (size_t)(m0 + r) * dff + h0 + tx, tile[0][tx][r]); // W1^T[channel m0 + r][hidden h0 + tx] = W1[h0 + tx][m0 + r]
+    __bf16 *d = o + i * img + idx;
+    d[0] = hh, d[n] = m, d[2 * n] = (__bf16)(r - (float)m);
   }
 }
 
@@ -1037,7 +1037,7 @@ extern "C" int spacap_tf_ffn_split_f32(const float *const *w1, const float *cons
       SPACAP_REQUIRE(w1[l0 + l] && w2[l0 + l] && pieces[l0 + l], "%s: null pointer (layer %d)", what, l0 + l);
       T.w1[l] = w1[l0 + l], T.w2[l] = w2[l0 + l], T.out[l] = static_cast<__bf16 *>(pieces[l0 + l]);
     }
-    hipLaunchKernelGGL(tf_ffn_split_kernel, dim3(dff / 32, D / 32, T.nlayers), dim3(256), 0, s, T);
+    hipLaunchKernelGGL(tf_ffn_split_kernel, dim3((unsigned)((size_t)dff * D / 256), T.nlayers), dim3(256), 0, s, T);
   }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
