@@ -483,7 +483,8 @@ def main():
         "rel_fused_bwd_kernel": (lin, "spacap_relation_fused_bwd_f32", lambda a: True),
         "sa_mid_fwd_bf3s_kernel": (sam, "spacap_sa_mid_fwd_pool_f32", lambda a: (a[4], a[5], a[6]) == (R2_, 128, 256)),
         "sa_dgrad_bf3s_kernel": (sam, "spacap_sa_dgrad_f32", lambda a: (a[8], a[9], a[10]) == (R2_, 256, 128)),
-        "tf_ffn_kernel": (tfl, "spacap_tf_ffn_f32", lambda a: a[0] == 0 and a[6] == per_gpu * 256),
+        "tf_ffn_kernel": (tfl, "spacap_tf_ffn_f32", lambda a: a[0] == 0),
+        "tf_ffn_bf3_kernel": (tfl, "spacap_tf_ffn_bf3_f32", lambda a: a[0] == 0 and a[5] == per_gpu * 256),
         "tf_rows_kernel": (tfl, "spacap_tf_rows_f32", lambda a: (a[0]._obj.mode, a[0]._obj.R, a[0]._obj.n2) == (0, per_gpu * 256, 384)
                            and a[0]._obj.nparts > 0),
     }
@@ -563,7 +564,8 @@ def main():
             "rel_fused_bwd_kernel": lambda: KC.rel_fused(B, cfg["proposals"], 1, dev),
             "sa_mid_fwd_bf3s_kernel": lambda: KC.sa_mid_fwd(R2, 128, 256, dev, "SA2 layer 3"),
             "sa_dgrad_bf3s_kernel": lambda: KC.sa_dgrad(R2, 256, 128, True, 32, dev, "SA2 layer 3"),
-            "tf_ffn_kernel": lambda: KC.tf_ffn(B * 256, 2048, 0, dev),
+            "tf_ffn_kernel": lambda: KC.tf_ffn(256, 2048, 0, dev),
+            "tf_ffn_bf3_kernel": lambda: KC.tf_ffn(B * 256, 2048, 0, dev),
             "tf_rows_kernel": lambda: KC.tf_rows(B * cfg["proposals"], cfg["transformer"].get("d_ff", 2048), dev),
         }
         if top_fn not in top_case:

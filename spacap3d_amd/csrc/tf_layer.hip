@@ -720,8 +720,23 @@ template <bool BWD>
 __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P) {
   __shared__ __attribute__((aligned(16))) __bf16 s_t[3 * FF_IMG];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, lg = lane >> 4;
-  const long row0 = (long)blockIdx.x * 64;
-  const int c0 = blockIdx.y * 128, dff = P.dff;
+  // workgroup -> (row tile, slice of d_ff): workgroups are dealt round robin to the 8 XCDs, each with its own L2.  An XCD takes
+  // nslice / 8 slices for ALL row tiles, so it fetches 2 x 2 x 96 KB of weight images and the 1 MB of rows instead of every
+  // slice's images (3 MB per XCD: 24 MB of the launch's fetches, rocprofv3 FETCH_SIZE) for a few row tiles.
+  const int dff = P.dff, nslice = dff / 128;
+  int slice;
+  long tile;
+  if (nslice % 8 == 0) {
+    const int spx = nslice / 8;
+    const long j = blockIdx.x / 8;
+    slice = (int)(blockIdx.x % 8) * spx + (int)(j % spx);
+    tile = j / spx;
+  } else {
+    const long ntiles = (P.R + 63) / 64;
+    tile = blockIdx.x % ntiles, slice = (int)(blockIdx.x / ntiles);
+  }
+  const long row0 = tile * 64;
+  const int c0 = slice * 128;
   const int c4 = tid & 31, r0 = tid >> 5;
   // ---- the rows' tile: fp32 -> three bf16 images
   {
@@ -775,7 +790,7 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  const size_t wimg = (size_t)dff * D, wofs = (size_t)(blockIdx.y * 4 + w) * 4096;   // (slice, wave) block of 2 x 4 x 64 x 8 elements
+  const size_t wimg = (size_t)dff * D, wofs = (size_t)(slice * 4 + w) * 4096;   // (slice, wave) block of 2 x 4 x 64 x 8 elements
   product(P.Wa + wofs, wimg, acc);
   f32x4 bb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (!BWD && P.bias) bb[0] = ld4(P.bias + c0 + 32 * w + 4 * lg), bb[1] = ld4(P.bias + c0 + 32 * w + 16 + 4 * lg);
@@ -815,7 +830,7 @@ __global__ __launch_bounds__(256, 3) void tf_ffn_bf3_kernel(const TfFfnBf3Args P
   }
   __syncthreads();
   product(P.Wb + wofs, wimg, acc);
-  float *out = P.part + (size_t)blockIdx.y * P.R * D;
+  float *out = P.part + (size_t)slice * P.R * D;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const long row = row0 + 16 * mt + l15;
@@ -1059,8 +1074,8 @@ extern "C" int spacap_tf_ffn_bf3_f32(int mode, const float *x, const void *piece
   P.Wa = pc + (mode == 0 ? 0 : 2) * img, P.Wb = pc + (mode == 0 ? 1 : 3) * img;
   P.seed = seed, P.seed_dev = reinterpret_cast<const unsigned long long *>(seed_dev);
   const long tiles = (R + 63) / 64;
-  SPACAP_REQUIRE(tiles <= 2147483647L, "%s: too many rows", what);
-  const dim3 grid((unsigned)tiles, dff / 128);
+  SPACAP_REQUIRE(tiles * (dff / 128) <= 2147483647L, "%s: too many rows", what);
+  const dim3 grid((unsigned)(tiles * (dff / 128)));
   hipStream_t s = spacap::as_stream(stream);
   if (mode == 0) hipLaunchKernelGGL((tf_ffn_bf3_kernel<false>), grid, dim3(256), 0, s, P);
   else hipLaunchKernelGGL((tf_ffn_bf3_kernel<true>), grid, dim3(256), 0, s, P);

@@ -205,24 +205,42 @@ def mha_fwd(B, h, L, dk, dev, need_p):
 
 
 def tf_ffn(R, dff, mode, dev):
-    """The Transformer feed-forward block as one chained launch (csrc/tf_layer.hip: tf_ffn_kernel), encoder shape."""
+    """The Transformer feed-forward block as one chained launch, encoder shape: the kernel the step runs for that many rows --
+    split-bf16 products with pre-split operand-order weight images above 512 rows (csrc/tf_layer.hip: tf_ffn_bf3_kernel), the
+    fp32-MFMA kernel below (tf_ffn_kernel)."""
+    import ctypes
     x, W1, W2 = _rand(R, 128, dev=dev), _rand(dff, 128, dev=dev) * 0.1, _rand(128, dff, dev=dev) * 0.05
     b1, y = _rand(dff, dev=dev) * 0.1, _rand(R, dff, dev=dev).relu_()
     hid, part = torch.empty(R, dff, dtype=torch.float32, device=dev), torch.empty(dff // 128, R, 128, dtype=torch.float32, device=dev)
+    bf3 = R > 512
+    pieces = None
+    if bf3:
+        pieces = torch.empty(int(lib.spacap_tf_ffn_pieces_elems(dff)), dtype=torch.bfloat16, device=dev)
+        arr = ctypes.c_void_p * 1
+        check(lib.spacap_tf_ffn_split_f32(arr(W1.data_ptr()), arr(W2.data_ptr()), arr(pieces.data_ptr()), 1, dff, _st(dev)), "tf_ffn_split")
 
     def run():
-        if mode == 0:
+        if bf3:
+            check(lib.spacap_tf_ffn_bf3_f32(mode, x.data_ptr(), pieces.data_ptr(), b1.data_ptr() if mode == 0 else None,
+                                            None if mode == 0 else y.data_ptr(), R, dff, 0.1, 7 if mode == 0 else 0, None,
+                                            hid.data_ptr(), part.data_ptr(), _st(dev)), "tf_ffn_bf3")
+        elif mode == 0:
             check(lib.spacap_tf_ffn_f32(0, x.data_ptr(), W1.data_ptr(), W2.data_ptr(), b1.data_ptr(), None, R, dff, 0.1, 7, None,
                                         hid.data_ptr(), part.data_ptr(), _st(dev)), "tf_ffn")
         else:
             check(lib.spacap_tf_ffn_f32(1, x.data_ptr(), W2.data_ptr(), W1.data_ptr(), None, y.data_ptr(), R, dff, 0.1, 0, None,
                                         hid.data_ptr(), part.data_ptr(), _st(dev)), "tf_ffn")
     byts = 4.0 * (R * 128 + R * dff * (1 if mode == 0 else 2) + (dff // 128) * R * 128 + 2 * 128 * dff)
-    return dict(name=f"tf_ffn {'fwd' if mode == 0 else 'bwd'} R={R} d_ff={dff} (encoder feed-forward block)", kernel="tf_ffn_kernel",
-                run=run, flops=4.0 * R * 128 * dff, bytes=byts, keep=(x, W1, W2, b1, y, hid, part),
-                what="hidden = dropout(relu(n W1^T + b1)) stored + partial sums of hidden W2^T per 128-wide slice of d_ff, one launch "
-                     "(fp32 MFMA)" if mode == 0 else
-                     "dhidden = (dy W2) * mask stored + partial sums of dhidden W1 per slice of d_ff, one launch (fp32 MFMA)")
+    arith = "split-bf16 products" if bf3 else "fp32 MFMA"
+    d = dict(name=f"tf_ffn {'fwd' if mode == 0 else 'bwd'} R={R} d_ff={dff} (encoder feed-forward block)",
+             kernel="tf_ffn_bf3_kernel" if bf3 else "tf_ffn_kernel",
+             run=run, flops=4.0 * R * 128 * dff, bytes=byts, keep=(x, W1, W2, b1, y, hid, part, pieces),
+             what=f"hidden = dropout(relu(n W1^T + b1)) stored + partial sums of hidden W2^T per 128-wide slice of d_ff, one launch "
+                  f"({arith})" if mode == 0 else
+                  f"dhidden = (dy W2) * mask stored + partial sums of dhidden W1 per slice of d_ff, one launch ({arith})")
+    if bf3:
+        d["bf16_products"] = 6
+    return d
 
 
 def tf_rows(R, dff, dev):
