@@ -402,6 +402,26 @@ def test_bench_ends_within_seconds_when_one_rank_dies_at_start():
     assert took < 30, took
 
 
+def test_evaluator_stream_of_batches_gives_the_plain_forward():
+    """engine.Evaluator: the next batch's sampling / grouping pyramid is computed on a side stream while the current batch
+    decodes; captions, boxes and sampled indices of every batch equal the plain ``model(data, is_eval=True)`` forward
+    (models/SpaCapNet.py:47-85, models/transformer_captioner.py:402-453)."""
+    from spacap3d_amd.engine import Evaluator, synthetic_batch
+    model = _make().eval()
+    batches = [synthetic_batch(2, 4096, DEV, seed=s, vocab=200) for s in (1, 2, 3)]
+    with torch.no_grad():
+        want = [model(dict(b), is_eval=True) for b in batches]
+    ev = Evaluator(model)
+    got = []
+    for i, b in enumerate(batches):
+        got.append(ev(b, next_data=batches[i + 1] if i + 1 < len(batches) else None))
+    torch.cuda.synchronize()
+    for w, g in zip(want, got):
+        for k in ("sa1_inds", "sa2_inds", "aggregated_vote_inds", "lang_cap", "bbox_mask"):
+            assert torch.equal(w[k], g[k]), k
+        assert torch.equal(w["bbox_corner"], g["bbox_corner"])
+
+
 def test_bench_runs_with_two_ranks_sharing_the_gpu():
     """The multi-rank path of bench.py end to end on a one-GPU box: two ranks launched exactly as the driver does
     (torch.distributed.run), both mapped onto cuda:0 and talking gloo instead of RCCL (test knobs SPACAP_SHARE_GPU /
