@@ -453,10 +453,14 @@ class RelationWide(Function):
             hid2 = bf3_product(hid1, bf3_pieces(W2c), b2, relu=True)
             pred = dense_product(hid2, W3c, True, bias=b3)
         ctx.save_for_backward(Pt, U, W2c, W3c, hid1, hid2)
+        ctx.spent = False
         return pred.view(B, K, K, W3c.shape[0])
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.spent:    # (dhid1 is written into hid2's memory: a second backward over a retained graph would read garbage)
+            raise RuntimeError("RelationWide: its backward can run once per forward (retain_graph is not supported)")
+        ctx.spent = True
         Pt, U, W2, W3, hid1, hid2 = ctx.saved_tensors
         B, K, H, _ = Pt.shape
         C = U.shape[-1]
