@@ -13,6 +13,23 @@ from .distributed import FlatGradBucket, broadcast_parameters, used_parameters
 from .loss_helper import get_scene_cap_loss, start_detection_losses
 
 
+# One stream per (device, role) for the whole process.  torch hands out pool streams round robin and the ROCm runtime maps them onto
+# a handful of hardware queues: a Trainer that made its own side / capture / communication streams could, as the N-th Trainer of a
+# process, get a side stream that shares a hardware queue with the stream its step is replayed on -- the "hidden" sampling chain
+# then serialises with the step (measured: BASELINE config 4 as the third configuration of one bench.py process, 12.7 instead of
+# 9.0 ms per step).  Fixed roles, created once in a fixed order, keep the placement the same for every Trainer / Evaluator.
+_STREAMS = {}
+
+
+def _role_stream(device, role):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _STREAMS:
+        dev = torch.device("cuda", key[1])
+        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm")}
+    return _STREAMS[key][role]
+
+
 class Trainer:
     def __init__(self, model: torch.nn.Module, mean_size_arr, lr: float = 1e-3, weight_decay: float = 1e-5,
                  use_relation: bool = True, split_optimizer: bool = False,
@@ -81,7 +98,7 @@ class Trainer:
         if not pc.is_cuda:
             return
         if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=pc.device)
+            self.side_stream = _role_stream(pc.device, "side")
             # the sampling chain holds one CU per scene while the backbone's forward runs beside it: the forward layer
             # kernels size their persistent grids to the rest of the chip (csrc/sa_mlp.hip: spacap_sa_reserve_cus)
             from ._native import check, lib
@@ -185,7 +202,7 @@ class Trainer:
         if used[0].is_cuda and self._sig is None:
             # here and not at first use: a zero-fill issued inside enable_graph's capture would be replayed every step
             self._sig = torch.zeros(4, dtype=torch.int64, device=used[0].device)
-            self._comm_stream = torch.cuda.Stream(device=used[0].device)
+            self._comm_stream = _role_stream(used[0].device, "comm")
             self._err_host = torch.zeros(1, dtype=torch.int64).pin_memory()
 
     def _adopt_bn_counters(self):
@@ -511,7 +528,7 @@ class Trainer:
         capture of one more step, which is not executed until the first replay."""
         dev = static["point_clouds"].device
         if self._capture_stream is None:
-            self._capture_stream = torch.cuda.Stream(device=dev)
+            self._capture_stream = _role_stream(dev, "capture")
         s = self._capture_stream
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -650,7 +667,7 @@ class Evaluator:
         if not pc.is_cuda:
             return
         if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=pc.device)
+            self.side_stream = _role_stream(pc.device, "side")
         cur = torch.cuda.current_stream(pc.device)
         self.side_stream.wait_stream(cur)
         if self.graph:
