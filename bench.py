@@ -678,7 +678,8 @@ def main():
         if eval_rec is not None:
             line["eval"] = eval_rec
         if world == 1 and args.config == "cfg2" and not args.no_configs and not args.ablate:
-            del model, data, trainer
+            del model, data
+            trainer = None
             import gc
             gc.collect()
             torch.cuda.empty_cache()
