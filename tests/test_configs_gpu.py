@@ -226,3 +226,45 @@ def test_bench_runs_every_config(cfg):
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["value"] > 0 and rec["final_loss"] == rec["final_loss"] and cfg in rec["config"]["workload"]
     assert rec["config"]["hip_graph"] is True, "the hipGraph capture must work for every config"
+
+
+def test_cfg5_wide_relation_head_at_full_size_on_sampled_pair_rows():
+    """BASELINE config 5 at its full per-GPU size: 16 scenes x 512 x 512 = 4 194 304 proposal pairs, 512 channels, 32 heads
+    (8.6 GB per pair tensor) through linear.RelationWide (models/transformer_captioner.py:319-326, 392-397 at d_model = 512).
+    Every stage of the head is LOCAL to a pair row -- hid1 row from P[b, :, i, j] and U[b, j], hid2, pred; backward: dz2, dhid1
+    and dP[b, :, i, j] -- so 256 sampled rows are recomputed in float64 from the same inputs and compared: forward 3e-6 of scale,
+    dP 3e-5 (a hidden unit within fp32 rounding of zero may gate differently: rows with such a unit are excluded, < 2 %)."""
+    from spacap3d_amd.linear import relation_head_wide
+    B, H, K, D, C = 16, 32, 512, 16, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    torch.manual_seed(5)
+    P = torch.softmax(torch.randn(B, H, K, K, generator=g, device=DEV), -1).requires_grad_(True)
+    V = torch.randn(B, H, K, D, generator=g, device=DEV)
+    l1, l2, l3 = torch.nn.Linear(H * D, C).to(DEV), torch.nn.Linear(C, C).to(DEV), torch.nn.Linear(C, 9).to(DEV)
+    pred = relation_head_wide(P, V, l1, l2, l3)
+    assert pred is not None and pred.shape == (B, K, K, 9)
+    wsum = torch.randn(B, K, K, 9, generator=g, device=DEV)
+    (pred * wsum).sum().backward()
+    n = 256
+    bs, is_, js = (torch.randint(0, m, (n,), generator=g, device=DEV) for m in (B, K, K))
+    W1, b1, W2, b2, W3, b3 = (t.detach().double() for t in (l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias))
+    p = P.detach()[bs, :, is_, js].double()                                   # (n, H)
+    v = V[bs, :, js, :].double()                                              # (n, H, D)
+    feat = (p.unsqueeze(-1) * v).reshape(n, H * D)                            # the pair feature rows
+    z1 = feat @ W1.t() + b1
+    h1 = z1.clamp_min(0)
+    z2 = h1 @ W2.t() + b2
+    h2 = z2.clamp_min(0)
+    want = h2 @ W3.t() + b3
+    got = pred.detach()[bs, is_, js].double()
+    assert float((got - want).abs().max() / want.abs().max()) < 3e-6
+    gr = wsum[bs, is_, js].double()
+    dz2 = (gr @ W3) * (z2 > 0)
+    dz1 = (dz2 @ W2) * (z1 > 0)
+    dfeat = dz1 @ W1                                                          # (n, H D)
+    dp = (dfeat.view(n, H, D) * v).sum(-1)                                    # dP[b, :, i, j]
+    near = ((z1.abs() < 2e-7).any(1) | (z2.abs() < 2e-7).any(1))     # (pre-activations here are ~0.03: fp32 noise ~3e-9)
+    assert float(near.double().mean()) < 0.02
+    gotp = P.grad[bs, :, is_, js].double()
+    err = ((gotp - dp).abs().max(1).values / dp.abs().max())[~near]
+    assert float(err.max()) < 3e-5, float(err.max())
