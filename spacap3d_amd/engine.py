@@ -307,7 +307,7 @@ class Trainer:
             # must not be handed views of the flat bucket either, so the slot table is only active in this branch)
             if all(p.grad is None for p in self.bucket.params):
                 with grad_slots(getattr(self, "_grad_slots", None)), deferred_slab_sums() as dq:
-                    d["loss"].backward()
+                    d["loss"].backward(self._seed_grad(d["loss"]))
                     if self._eager_checks > 0:
                         # A queued sum is unfilled until the flush: every byte of it must have reached parameters' .grad
                         # untouched (a parameter consumed by two autograd nodes, or an AccumulateGrad that clones, would
@@ -339,6 +339,14 @@ class Trainer:
         self.last_losses = {k: d[k].detach() for k in ("loss", "vote_loss", "objectness_loss", "box_loss", "sem_cls_loss",
                                                        "cap_loss", "relation_loss") if k in d and torch.is_tensor(d[k])}
         return d["loss"].detach()
+
+    def _seed_grad(self, loss):
+        """The backward's seed d loss / d loss = 1 as a tensor that lives with the Trainer (autograd otherwise fills a fresh
+        ones_like(loss) every step: one more launch inside the captured step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.device != loss.device or one.dtype != loss.dtype or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss)
+        return one
 
     def _optimizer_step(self, sources):
         """gradient all-reduce (multi-rank) + Adam.  FlatAdam reads the packed gradients of the flat bucket and takes the
