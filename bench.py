@@ -70,6 +70,9 @@ def spawn_ranks(n):
                     keep.popleft()
         stream.close()
 
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this image's host driver only supports dmabuf IPC handles; without it RCCL's intra-node
+    # transport set-up fails with `hipIpcGetMemHandle: invalid argument` (the image exports it already: stated here so that a
+    # caller with a scrubbed environment gets the same ranks)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

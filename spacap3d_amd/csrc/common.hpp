@@ -89,6 +89,32 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+// Wave reductions with the DPP modifier ON the max / min itself (the helpers of common.hpp go through a v_mov_dpp: four
+// instructions per step) and the two row_bcast steps instead of four readlanes: 6 steps, result from lane 63.  These sit
+// on the serial chain of every sampling round.
+__device__ __forceinline__ int wave_max_i32_fast(int v) {
+  asm volatile("s_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+               : "+v"(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32_fast(unsigned v) {
+  asm volatile("s_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+               : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -25,6 +25,7 @@
 namespace {
 
 using namespace spacap;
+struct __attribute__((aligned(16))) f32x4s { float x, y, z, w; };
 
 // v_min_f32 without the canonicalising v_max hipcc emits in front of fminf (operands are never sNaN here);
 // in IEEE mode it returns the non-NaN operand, i.e. the reference's fminf (sampling_gpu.cu:106).
@@ -173,6 +174,89 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
   }
 }
 
+// N <= 8 192, the shape of every level below the first (2 048 -> 1 024 -> 512 -> 256) and of the vote-aggregation sampling
+// (1 024 votes -> 256 proposals, on the step's critical path): ONE barrier per round and no dependent global load.
+//   * all coordinates also live in LDS as float4: the new centre is one broadcast ds_read_b128 (fps_kernel: three dependent
+//     global loads, ~0.2 us of every round);
+//   * every wave ALWAYS computes its (maximum, winning key) pair -- 3 more VALU per point, but no second, conditional pass,
+//     no LDS atomic and no second barrier; the pairs meet in an LDS record double-buffered by round parity, and every wave
+//     reduces the NW records itself (two DPP reductions).
+// Same selection rule as fps_kernel: first maximum in the reference's tree order through fps_key; M < 0 (every point
+// skipped) gives index 0.  Rounds: 0.75 -> ~0.35 us at N = 2 048, 0.62 -> ~0.3 us at N = 1 024 (tools/lab/fps_small_bench.py).
+template <int BLOCK, int TPL>
+__global__ __launch_bounds__(BLOCK) void fps_small_kernel(const float *__restrict__ xyz_all, int N, int m, int lg,
+                                                          int32_t *__restrict__ idx_all) {
+  constexpr int NW = BLOCK / 64;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // [N] float4 coordinates
+  __shared__ __attribute__((aligned(8))) int s_rec[2][NW > 1 ? NW : 1][2];   // per round parity, per wave: {max temp bits, key}
+  f32x4s *s_xyz = reinterpret_cast<f32x4s *>(s_dyn);
+  const float *__restrict__ xyz = xyz_all + (size_t)blockIdx.x * N * 3;
+  int32_t *__restrict__ idxs = idx_all + (size_t)blockIdx.x * m;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float t[TPL], px[TPL], py[TPL], pz[TPL];
+  unsigned keys[TPL];
+#pragma unroll
+  for (int i = 0; i < TPL; ++i) {
+    const int k = tid + i * BLOCK;
+    const int kk = k < N ? k : N - 1;
+    const float x = xyz[kk * 3 + 0], y = xyz[kk * 3 + 1], z = xyz[kk * 3 + 2];
+    const float mag = (x * x) + (y * y) + (z * z);
+    const bool skip = (k >= N) || ((double)mag <= 1e-3);
+    t[i] = skip ? -1.0f : 1e10f;
+    px[i] = x; py[i] = y; pz[i] = z;
+    keys[i] = fps_key(k, lg);
+    if (k < N) s_xyz[k] = f32x4s{x, y, z, 0.f};
+  }
+  if (tid == 0) idxs[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const f32x4s c = s_xyz[old];   // wave-uniform address: one broadcast read
+    int lmax = __float_as_int(-1.0f);
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) {
+      const float d = sqdist(px[i], py[i], pz[i], c.x, c.y, c.z);
+      t[i] = vmin_f32(d, t[i]);
+      lmax = max(lmax, __float_as_int(t[i]));   // values are -1 or >= +0, never NaN: signed-integer order == float order
+    }
+    const int wmax = wave_max_i32_fast(lmax);
+    unsigned key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < TPL; ++i) key = min(key, (__float_as_int(t[i]) == wmax) ? keys[i] : 0xFFFFFFFFu);
+    key = wave_min_u32_fast(key);
+    int bw = wmax;
+    unsigned bk = key;
+    if (NW > 1) {
+      if (lane == 0) *reinterpret_cast<int2 *>(&s_rec[j & 1][wid][0]) = make_int2(wmax, (int)key);
+      __syncthreads();
+      if (NW <= 8) {   // every lane reads all NW records (broadcast reads, issued together) and reduces them itself
+        int rw[NW];
+        unsigned rk[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const int2 r = *reinterpret_cast<const int2 *>(&s_rec[j & 1][w][0]);
+          rw[w] = r.x; rk[w] = (unsigned)r.y;
+        }
+        bw = rw[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) bw = max(bw, rw[w]);
+        bk = 0xFFFFFFFFu;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bk = min(bk, rw[w] == bw ? rk[w] : 0xFFFFFFFFu);
+      } else {
+        int rw = (int)0x80000000;
+        unsigned rk = 0xFFFFFFFFu;
+        if (lane < NW) { rw = s_rec[j & 1][lane][0]; rk = (unsigned)s_rec[j & 1][lane][1]; }
+        bw = wave_max_i32_fast(rw);
+        bk = wave_min_u32_fast(rw == bw ? rk : 0xFFFFFFFFu);
+      }
+    }
+    old = (bw < 0) ? 0 : fps_unkey(bk, lg);   // every point skipped: the reference returns index 0
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (tid == 0) idxs[j] = old;
+  }
+}
+
 // Any N: temp lives in the caller's workspace (as in the reference), same round structure.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void fps_generic_kernel(const float *__restrict__ xyz_all,
@@ -239,6 +323,18 @@ void launch_fps(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hip
   hipLaunchKernelGGL((fps_kernel<BLOCK, TPL>), dim3(B), dim3(BLOCK), 0, s, xyz, N, m, lg, idx);
 }
 
+template <int BLOCK, int TPL>
+hipError_t launch_fps_small(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hipStream_t s) {
+  const int lds = N * 16;
+  static unsigned long long lds_ok = 0;
+  if (lds > 48 * 1024) {
+    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 128 * 1024, lds_ok);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((fps_small_kernel<BLOCK, TPL>), dim3(B), dim3(BLOCK), lds, s, xyz, N, m, lg, idx);
+  return hipSuccess;
+}
+
 }  // namespace
 
 // Workspace: the bucket-ordered structure-of-arrays copy of the bucketed kernel (3 planes of ceil(N/4096)*4096
@@ -267,6 +363,25 @@ extern "C" int spacap_fps_f32(const float *xyz, int B, int N, int m, void *works
     SPACAP_CHECK_LAUNCH("spacap_fps_f32");                     \
     return SPACAP_OK;                                          \
   }
+  // SPACAP_FPS_LEGACY=1 (tests / lab): the round-5 kernels (fps_kernel, fps_wave_kernel) instead of fps_small_kernel
+  static const bool legacy = getenv("SPACAP_FPS_LEGACY") != nullptr && atoi(getenv("SPACAP_FPS_LEGACY")) != 0;
+  if (!legacy && N <= 2048) {
+#define FPS_SMALL(BLOCK, TPL)                                                                          \
+  if (N <= (BLOCK) * (TPL)) {                                                                          \
+    SPACAP_CHECK_HIP((launch_fps_small<BLOCK, TPL>(xyz, B, N, m, lg, idx, s)), "spacap_fps_f32(small)"); \
+    SPACAP_CHECK_LAUNCH("spacap_fps_f32(small)");                                                      \
+    return SPACAP_OK;                                                                                  \
+  }
+    // (measured per shape, tools/lab/fps_small_bench.py; beyond 2 048 points the two-barrier kernel with its rare second pass
+    // is the faster one: 16 waves pay 3 VALU per point for keys that one wave needs)
+    FPS_SMALL(64, 1)
+    FPS_SMALL(64, 2)
+    FPS_SMALL(64, 4)
+    FPS_SMALL(64, 8)
+    FPS_SMALL(256, 4)
+    FPS_SMALL(512, 4)
+#undef FPS_SMALL
+  }
   FPS_CASE(64, 1)
   FPS_CASE(64, 2)
   FPS_CASE(64, 4)
@@ -291,4 +406,23 @@ extern "C" int spacap_fps_f32(const float *xyz, int B, int N, int m, void *works
   hipLaunchKernelGGL((fps_generic_kernel<1024>), dim3(B), dim3(1024), 0, s, xyz, ws, N, m, lg, idx);
   SPACAP_CHECK_LAUNCH("spacap_fps_f32(generic)");
   return SPACAP_OK;
+}
+
+// LAB (tools/lab/fps_small_bench.py; not declared in the public header): fps_small_kernel at a chosen workgroup shape
+extern "C" int spacap_lab_fps_small(const float *xyz, int B, int N, int m, int block, int tpl, int32_t *idx, spacap_stream_t stream) {
+  SPACAP_REQUIRE(xyz && idx && B >= 1 && N >= 1 && m >= 1 && N <= 8192 && N <= block * tpl, "spacap_lab_fps_small: bad arguments");
+  hipStream_t s = spacap::as_stream(stream);
+  const int bs = spacap_opt_n_threads(N);
+  int lg = 0;
+  while ((1 << lg) < bs) ++lg;
+#define V(BL, TP)                                                                                             \
+  if (block == BL && tpl == TP) {                                                                             \
+    SPACAP_CHECK_HIP((launch_fps_small<BL, TP>(xyz, B, N, m, lg, idx, s)), "spacap_lab_fps_small");           \
+    SPACAP_CHECK_LAUNCH("spacap_lab_fps_small");                                                              \
+    return SPACAP_OK;                                                                                         \
+  }
+  V(64, 1) V(64, 2) V(64, 4) V(64, 8) V(64, 16) V(128, 2) V(128, 4) V(128, 8) V(256, 1) V(256, 2) V(256, 4) V(256, 8) V(512, 1) V(512, 2)
+  V(512, 4) V(1024, 1) V(1024, 2) V(1024, 4) V(1024, 8)
+#undef V
+  SPACAP_REQUIRE(false, "spacap_lab_fps_small: (%d, %d) not instantiated", block, tpl);
 }

@@ -1283,23 +1283,23 @@ inline bool f32_mfma_only() {
 }
 static std::atomic<int> g_reserved_cus{0};
 inline int reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
-template <typename K>
-int resident_blocks(K kernel, size_t lds) {
-  int per = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, lds) != hipSuccess || per < 1) per = 1;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-    cus = 256;
-  (void)hipGetLastError();
-  return per * cus;
-}
 inline int device_cus() {
   static const int n = [] {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
+    // LAB: the CUs the step's stream may use when it was created with a CU mask (tools/lab/cumask_step.py)
+    if (const char *e = getenv("SPACAP_LAB_CUS")) { const int v = atoi(e); if (v >= 8 && v <= cus) cus = v; }
     return cus;
   }();
   return n;
+}
+template <typename K>
+int resident_blocks(K kernel, size_t lds) {
+  int per = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kernel, 256, lds) != hipSuccess || per < 1) per = 1;
+  (void)hipGetLastError();
+  return per * device_cus();
 }
 // resident workgroups of a FORWARD kernel with the reserved CUs left out (used by the relation tail; the HBM-bound 64-channel
 // fp32 layer kernel runs 1.3x as long beside the sampling kernel with or without it and only loses from a smaller grid when
@@ -1310,6 +1310,18 @@ inline int fwd_resident(int resident) {
   const int per = resident / device_cus();
   return resident - per * reserved_cus() * (per > 1 ? 3 : 1);
 }
+// The BACKWARD kernels with persistent grids leave the reserved CUs out as well: the sampling chain of the next batch now runs
+// beside the first ~5.8 ms of a ~7.4 ms step, i.e. beside the captioner's and most of the detector's backward, and a whole-CU
+// workgroup that finds its CU taken runs as a second round (tools/lab/beside.py: 1.5 - 1.9x beside ANY 8 resident workgroups).
+// (LAB knob SPACAP_LAB_BWD_RESERVE: 0 = full grids as before, 1 = per-CU count x reserved, 3 = the forward formula)
+inline int bwd_resident(int resident) {
+  static const int mode = [] { const char *e = getenv("SPACAP_LAB_BWD_RESERVE"); return e ? atoi(e) : 1; }();
+  if (mode == 0) return resident;
+  if (mode == 3) return fwd_resident(resident);
+  const int per = resident / device_cus();
+  return resident - per * reserved_cus();
+}
+inline int bwd_cus() { return bwd_resident(device_cus()); }
 inline int grid_rows(int resident, int gy, long tiles) {
   long g = resident / gy;
   if (g > NPART) g = NPART;
@@ -1345,7 +1357,7 @@ int wgrad_resident(int CK, int CP, bool pooled) {
 }  // namespace
 extern "C" int spacap_sa_wgrad_slabs(long R, int CK, int CP, int pooled) {
   const int gy = CK >= 128 ? CK / 128 : 1;
-  long n = wgrad_resident(CK, CP, pooled != 0) / gy, cap = (16L << 20) / ((long)CK * CP), tiles = (R + TW - 1) / TW;
+  long n = bwd_resident(wgrad_resident(CK, CP, pooled != 0)) / gy, cap = (16L << 20) / ((long)CK * CP), tiles = (R + TW - 1) / TW;
   if (n > cap) n = cap;
   if (n > tiles) n = tiles;
   return (int)(n < 1 ? 1 : n);
@@ -1569,7 +1581,7 @@ extern "C" int spacap_gemm_rows_f32(const float *x, const float *W, long R, int 
   const size_t ldss = bf3s_lds_bytes(Cin);
   const long wtiles = (R + 31) / 32;
   const int gy = Cout / 128;
-  long gx = device_cus() / gy;
+  long gx = bwd_cus() / gy;
   gx = gx > NPART ? NPART : gx;
   gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
   if (Cin == 64)
@@ -1687,7 +1699,7 @@ extern "C" int spacap_sa_wgrad_pool_supported(int C2, int C3, int S) { return wg
 namespace {
 int wgrad_pool_grid(long R, int C2, int S) {
   // C2 = 64: two workgroups of four waves per CU; C2 = 128: one of eight (its partial is 197 KB: fewer, larger partials)
-  long g = (long)device_cus() * (C2 == 64 ? 2 : 1), tiles = (R + S - 1) / S;
+  long g = (long)bwd_cus() * (C2 == 64 ? 2 : 1), tiles = (R + S - 1) / S;
   if (g > NPART) g = NPART;
   if (g > tiles) g = tiles;
   return (int)(g < 1 ? 1 : g);
@@ -1734,7 +1746,7 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
     const size_t ldsd = bf3s_dgrad_lds_bytes(CK);
     const long wtiles = (R + 31) / 32;
     const int gy = CP / 64;
-    long gx = cus / gy;
+    long gx = bwd_resident(cus) / gy;
     gx = gx > NPART ? NPART : gx;
     gx = gx > (wtiles + 7) / 8 ? (wtiles + 7) / 8 : gx;
 #define DS(CKV, PV)                                                                                                   \
@@ -1753,7 +1765,7 @@ extern "C" int spacap_sa_dgrad_f32(const float *dy, const uint8_t *arg, int S, c
       SPACAP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_dgrad_kernel<CKV, NTV, PV, PF, AL>),   \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what);            \
     static const int res = resident_blocks(sa_dgrad_kernel<CKV, NTV, PV, PF, AL>, lds);                              \
-    hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV, PF, AL>), dim3(grid_rows(res, GY, (R + TM - 1) / TM), GY),     \
+    hipLaunchKernelGGL((sa_dgrad_kernel<CKV, NTV, PV, PF, AL>), dim3(grid_rows(bwd_resident(res), GY, (R + TM - 1) / TM), GY), \
                        dim3(256), lds, s, dy, arg, S, zk, coef, Wk, CP, zp, st_p, R, dyp, part);                      \
   }
   if (arg && CK == 128 && CP == 64) DG(128, 1, true, true, false, 1)
@@ -1784,7 +1796,7 @@ extern "C" int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const fl
   const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
   static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
   L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1, nullptr, L1In{nullptr, 0, 0}};
-  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(res, 1, (R + TM - 1) / TM), 1),
+  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(bwd_resident(res), 1, (R + TM - 1) / TM), 1),
                      dim3(256), lds, s, dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, CP, zp, st_p, R, (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -1800,7 +1812,7 @@ extern "C" int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const 
   const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
   static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
   L1Args L{nullptr, nullptr, nullptr, nullptr, 1.f, 1, N, S, part_l1, rel4, L1In{W1, ldw, has_feat}};
-  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(res, 1, (R + TM - 1) / TM), 1),
+  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(bwd_resident(res), 1, (R + TM - 1) / TM), 1),
                      dim3(256), lds, spacap::as_stream(stream), dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, 64, (const float *)nullptr,
                      st_p, R, (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);

@@ -202,6 +202,8 @@ class Trainer:
         if used[0].is_cuda and self._sig is None:
             # here and not at first use: a zero-fill issued inside enable_graph's capture would be replayed every step
             self._sig = torch.zeros(4, dtype=torch.int64, device=used[0].device)
+            # the backward's seed (see _seed_grad): allocated and filled here, outside any capture, for the same reason
+            self._one = torch.ones_like(d["loss"].detach())
             self._comm_stream = _role_stream(used[0].device, "comm")
             self._err_host = torch.zeros(1, dtype=torch.int64).pin_memory()
 

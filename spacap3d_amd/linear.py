@@ -301,7 +301,12 @@ def conv1x1(x, conv):
     module).  Without gradient recording (the inference forward) only the forward kernel runs."""
     if not (x.is_cuda and x.dtype == torch.float32) or any(k != 1 for k in conv.kernel_size) or not x.is_contiguous():
         return None
-    if not (torch.is_grad_enabled() and conv.weight.requires_grad):
+    # the raw kernel returns a tensor without a grad_fn: only when NOTHING on this call can need a gradient (grad mode off, or
+    # neither the input nor the parameters require one).  A frozen convolution behind a trainable layer goes through
+    # Conv1x1.apply below, whose backward honours needs_input_grad.
+    needs = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad
+                                         or (conv.bias is not None and conv.bias.requires_grad))
+    if not needs:
         return conv1x1_cm(0, conv.weight, x, conv.bias, conv.out_channels) if USE_OWN_CONV else None
     B, CI = x.shape[0], x.shape[1]
     N = x.numel() // max(B * CI, 1)

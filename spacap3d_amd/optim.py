@@ -34,7 +34,8 @@ class FlatAdam:
     def step(self, grad_scale=1.0, skip_word=None):
         """One update from the gradients currently in ``bucket.flat`` (pack them first).  ``skip_word``: a device int64
         tensor; the kernel leaves parameters and moments untouched when it is non-zero (engine.Trainer: the sticky error
-        word of a timed-out stream wait)."""
+        word of a timed-out stream wait).  A non-zero word is TERMINAL: it is sticky and the Trainer raises at its next
+        step(), so the step counter below (which a skipped update still advances) never feeds another update."""
         dev = self.flat_p.device
         self.step_t += 1
         with torch.cuda.device(dev):

@@ -189,8 +189,9 @@ def test_five_step_trajectory_matches_the_oracle_backend():
         for k in a:
             # (the runs drift apart step by step once a selection differs: the band doubles after the third step)
             tol = (5e-3 if k in tight else 5e-2) * (1 if i < 3 else 3)
-            floor = 3.0 * abs(b[k] - gpu2[i][k])
-            assert abs(a[k] - b[k]) <= max(tol * max(abs(a[k]), 1e-2), floor), (i, k, a, b, gpu2[i])
+            band = tol * max(abs(a[k]), 1e-2)
+            floor = min(3.0 * abs(b[k] - gpu2[i][k]), 2.0 * band)   # the run-to-run spread may widen the band, never past 2x
+            assert abs(a[k] - b[k]) <= max(band, floor), (i, k, a, b, gpu2[i])
     # everything goes down on both (anchored boxes, pinned proposals: a stable set of positives)
     for run_ in (cpu, gpu):
         assert run_[-1]["loss"] < run_[0]["loss"] and run_[-1]["cap_loss"] < run_[0]["cap_loss"] \

@@ -60,11 +60,19 @@ def stamp_every_call():
             continue
         fn = getattr(lib, name)
 
+        only = [t for t in os.environ.get("ONLY", "").split(",") if t]
+
         def wrapped(*a, fn=fn, name=name):
-            if torch.cuda.is_current_stream_capturing():
-                count[0] += 1
-                stamp(f"{count[0]:04d} {name[7:]}")
-            return fn(*a)
+            if not torch.cuda.is_current_stream_capturing():
+                return fn(*a)
+            count[0] += 1
+            if only and not any(t in name for t in only):
+                return fn(*a)
+            stamp(f"{count[0]:04d} {name[7:]}")
+            r = fn(*a)
+            if only:   # ONLY=substr,substr: stamps around the named calls and nowhere else (a handful of extra launches per step)
+                stamp(f"{count[0]:04d} {name[7:]} END")
+            return r
         setattr(lib, name, wrapped)
 
 
@@ -117,6 +125,10 @@ def main():
     if not os.environ.get("NO_MARKS"):
         cap.model.decoder.forward = decoder
     tr = Trainer(model, S.mean_size_arr().numpy())
+    if os.environ.get("GEOM") == "0":
+        tr.prefetch_geometry = False      # sampling chain only on the side stream; groupings / neighbour searches inside the step
+    if os.environ.get("SKEW"):
+        tr.prefetch_skew_us = int(os.environ["SKEW"])
     f_loss = tr.loss
 
     def loss(d):
@@ -149,16 +161,23 @@ def main():
     tr.step(data, next_data=data)
     assert tr.enable_graph(data), tr.graph_error
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    one = lambda: tr.step(data, next_data=data)
+    if os.environ.get("NOSIDE"):   # the pyramid computed once and re-attached: no side-stream work beside the step
+        tr.prefetch(data); torch.cuda.synchronize()
+        saved = data["_fps_prefetch"]
+        def one():
+            data["_fps_prefetch"] = saved
+            tr.step(data, next_data=None)
     for _ in range(10):
-        tr.step(data, next_data=data)
+        one()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(steps):
-        tr.step(data, next_data=data)
+        one()
     e1.record()
     torch.cuda.synchronize()
     print(f"{e0.elapsed_time(e1) / steps:.3f} ms/step over {steps} steps")
-    if os.environ.get("NO_MARKS"):
+    if not NAMES:
         return
     t = BUF.cpu().tolist()
     rows = sorted((t[i], n) for i, n in enumerate(NAMES))

@@ -5,8 +5,9 @@ set -u -o pipefail
 TAG=${1:-eval}
 N=${2:-5}
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/$TAG
-rm -rf $OUT && mkdir -p $OUT
+case "$TAG" in */*|*..*|"") echo "prof_eval.sh: bad tag '$TAG'" >&2; exit 2;; esac
+OUT="$REPO/gpurun_out/$TAG"
+rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 fail() { echo "prof_eval.sh: $1 FAILED" >&2; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/tools/eval_profile_run.py $N > $OUT/eval.log 2> $OUT/eval.err \

@@ -12,8 +12,9 @@ for ((i = 0; i < ${#EXTRA[@]}; i++)); do
   if [ "${EXTRA[$i]}" == "--steps" ]; then STEPS=${EXTRA[$((i + 1))]}; fi
 done
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/$TAG
-rm -rf $OUT && mkdir -p $OUT
+case "$TAG" in */*|*..*|"") echo "prof_step.sh: bad tag '$TAG'" >&2; exit 2;; esac
+OUT="$REPO/gpurun_out/$TAG"
+rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 fail() { echo "prof_step.sh: $1 FAILED" >&2; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py --steps $STEPS --warmup 5 --no-configs --no-in-step --no-cpu-baseline --no-drop-in "${EXTRA[@]}" > $OUT/bench.log 2> $OUT/bench.err \
