@@ -439,6 +439,12 @@ int spacap_sa_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef
 int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *rel4,
                              const float *W1, int ldw, int has_feat, const float *st_p, int B, int N, int S, double *part,
                              float *part_l1, spacap_stream_t stream);
+/* spacap_sa_dgrad_l1in_f32 + the layer's weight-gradient partials from the same pass (what spacap_sa_wgrad_l1in_f32 computes from a
+ * second read of dy and zk): partW f32 [spacap_sa_dgrad_wgrad_l1in_slabs(R)][64][64], summed by the caller in slab order. */
+int spacap_sa_dgrad_wgrad_l1in_slabs(long R);
+int spacap_sa_dgrad_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *rel4,
+                                   const float *W1, int ldw, int has_feat, const float *st_p, int B, int N, int S, double *part,
+                                   float *part_l1, float *partW, spacap_stream_t stream);
 /* partW f32 [spacap_sa_wgrad_slabs(R,CK,CP,arg != NULL), CK, CP]: per-slab partial sums of dW_k = dz_k^T relu(bn(z_prev)). */
 int spacap_sa_wgrad_f32(const float *dy, const uint8_t *arg, int S, const float *zk, const float *coef,
                         const float *zp, const float *st_p, long R, int CK, int CP, float *partW,

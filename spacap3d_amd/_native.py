@@ -78,6 +78,8 @@ SIGNATURES = {
     "spacap_sa_mid_fwd_l1in_f32": (_i, [_p, _p, _i, _i, _p, _p, _l, _p, _p, _p]),
     "spacap_sa_wgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _l, _p, _p]),
     "spacap_sa_dgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "spacap_sa_dgrad_wgrad_l1in_slabs": (_i, [_l]),
+    "spacap_sa_dgrad_wgrad_l1in_f32": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_sa_l1_dw_f32": (_i, [_p, _i, _p, _i, _i, _p, _p]),
     "spacap_vote_assemble_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "spacap_vote_assemble_bwd_f32": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),

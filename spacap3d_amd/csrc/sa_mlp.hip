@@ -656,9 +656,14 @@ struct L1Args {
   float *part;  // [NPART][COB*8 + 4]
   const float *rel4;   // optional: the rows' inputs as the statistics pass stored them; then z_prev is rebuilt, not read (zp unused)
   L1In li;
+  float *partW;        // WG only: [gridDim.x][CK][COB] per-workgroup partial sums of dW_k = dz_k^T relu(bn(z_prev))
 };
 
-template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS, bool L1 = false>
+// WG (with L1 + rel4, CK = COB = 64): the layer's WEIGHT gradient from the same pass.  The tile's dz_k is in LDS for the data
+// gradient and the epilogue rebuilds a_prev = relu(bn(z_prev)) for its mask anyway: it leaves a_prev in the output tile's place
+// and one more product per tile, dW_k += dz_k^T a_prev (contraction over the tile's 64 rows), replaces the separate weight-gradient
+// kernel and its second read of dy and z_k (536 MB at SA1).
+template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS, bool L1 = false, bool WG = false>
 __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
                                                        const float *__restrict__ zk, const float *__restrict__ coef,
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
@@ -697,6 +702,10 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
 #pragma unroll
     for (int u = 0; u < 4; ++u) q1[u] = q3[u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  static_assert(!WG || (L1 && !ALIAS && CK == 64 && NT == 1), "fused weight gradient: 64 x 64 first-layer instance only");
+  f32x4 accw[WG ? 4 : 1];
+#pragma unroll
+  for (int n = 0; n < (WG ? 4 : 1); ++n) accw[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 pz[PREFETCH ? NV : 1], pd[DENSE_PF ? NV : 1];
   auto fetch = [&](long t) {
 #pragma unroll
@@ -715,7 +724,8 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     constexpr bool FULL = decltype(full)::value;
     const long row0 = t * TM;
     if (PREFETCH) {
-      if (stores_pending) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
+      // (L1: the epilogue stores nothing, every outstanding operation is one of the prefetched loads)
+      if (stores_pending && !L1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NO) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -813,7 +823,26 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
         } else {
           st4(dyp + o, d);
         }
+        if (WG) {   // a_prev over this thread's own element of the output tile (nobody else reads it in this loop)
+          f32x4 ap;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ap[u] = fmaxf((z[u] - pm[u]) * ps[u] + pb[u], 0.f);
+          st4(&s_o[row * LDO + o4 * 4], ap);
+        }
+      } else if (WG) {
+        st4(&s_o[row * LDO + o4 * 4], f32x4{0.f, 0.f, 0.f, 0.f});   // (rows past the end: dz is zero there as well)
       }
+    }
+    if (WG) {
+      __syncthreads();
+      // dW[ck = 16 w + .][cp = 16 n + .] += sum over the tile's rows of dz[row][ck] a_prev[row][cp]
+#pragma unroll
+      for (int ks = 0; ks < TM / 4; ++ks) {
+        const float af = s_a[(ks * 4 + lg) * LD + 16 * w + l15];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) accw[n] = MFMA16(af, s_o[(ks * 4 + lg) * LDO + 16 * n + l15], accw[n]);
+      }
+      __syncthreads();   // before the next tile is staged over dz / the output tile
     }
     if (ALIAS) __syncthreads();  // the output tile is consumed before the next tile is staged over it
   };
@@ -849,6 +878,13 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
     for (int i = 0; i < OSTEP; ++i) a += s_red[(k * OSTEP + i) * COB + c];
     part[((size_t)blockIdx.x * 2 + k) * CP + cbb + c] = (double)a;
     for (int pr = blockIdx.x + gridDim.x; pr < NPART; pr += gridDim.x) part[((size_t)pr * 2 + k) * CP + cbb + c] = 0.0;
+  }
+  if (WG) {
+    float *o = L.partW + (size_t)blockIdx.x * CK * COB;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) o[(size_t)(16 * w + 4 * lg + u) * COB + 16 * n + l15] = accw[n][u];
   }
   if (L1) {  // S1 / S3: combine the OSTEP row groups; S2: combine the TM row slots
     __syncthreads();
@@ -1795,7 +1831,7 @@ extern "C" int spacap_sa_dgrad_l1_f32(const float *dy, const float *zk, const fl
   hipStream_t s = spacap::as_stream(stream);
   const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
   static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
-  L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1, nullptr, L1In{nullptr, 0, 0}};
+  L1Args L{feat, xyz, new_xyz, idx, rdiv, Np, N, S, part_l1, nullptr, L1In{nullptr, 0, 0}, nullptr};
   hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(bwd_resident(res), 1, (R + TM - 1) / TM), 1),
                      dim3(256), lds, s, dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, CP, zp, st_p, R, (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);
@@ -1811,10 +1847,35 @@ extern "C" int spacap_sa_dgrad_l1in_f32(const float *dy, const float *zk, const 
   const long R = (long)B * N * S;
   const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
   static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true>, lds);
-  L1Args L{nullptr, nullptr, nullptr, nullptr, 1.f, 1, N, S, part_l1, rel4, L1In{W1, ldw, has_feat}};
+  L1Args L{nullptr, nullptr, nullptr, nullptr, 1.f, 1, N, S, part_l1, rel4, L1In{W1, ldw, has_feat}, nullptr};
   hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true>), dim3(grid_rows(bwd_resident(res), 1, (R + TM - 1) / TM), 1),
                      dim3(256), lds, spacap::as_stream(stream), dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, 64, (const float *)nullptr,
                      st_p, R, (float *)nullptr, part, L);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
+// spacap_sa_dgrad_l1in_f32 that ALSO leaves the layer's weight-gradient partials: partW f32 [spacap_sa_dgrad_wgrad_l1in_slabs(R)][64][64],
+// summed by the caller in slab order (what spacap_sa_wgrad_l1in_f32 computes from a second pass over dy and zk)
+namespace {
+int dgrad_wgrad_l1in_grid(long R) {
+  const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
+  static const int res = resident_blocks(sa_dgrad_kernel<64, 1, false, true, false, true, true>, lds);
+  return grid_rows(bwd_resident(res), 1, (R + TM - 1) / TM);
+}
+}  // namespace
+extern "C" int spacap_sa_dgrad_wgrad_l1in_slabs(long R) { return R >= 1 ? dgrad_wgrad_l1in_grid(R) : 0; }
+extern "C" int spacap_sa_dgrad_wgrad_l1in_f32(const float *dy, const float *zk, const float *coef, const float *Wk, const float *rel4,
+                                              const float *W1, int ldw, int has_feat, const float *st_p, int B, int N, int S,
+                                              double *part, float *part_l1, float *partW, spacap_stream_t stream) {
+  const char *what = "spacap_sa_dgrad_wgrad_l1in_f32";
+  SPACAP_REQUIRE(dy && zk && coef && Wk && rel4 && W1 && st_p && part && part_l1 && partW && ldw >= (has_feat ? 4 : 3), "%s: bad arguments", what);
+  const long R = (long)B * N * S;
+  const size_t lds = (size_t)TM * ((64 + 4) + (64 + 4) + 4) * sizeof(float);
+  L1Args L{nullptr, nullptr, nullptr, nullptr, 1.f, 1, N, S, part_l1, rel4, L1In{W1, ldw, has_feat}, partW};
+  hipLaunchKernelGGL((sa_dgrad_kernel<64, 1, false, true, false, true, true>), dim3(dgrad_wgrad_l1in_grid(R), 1), dim3(256), lds,
+                     spacap::as_stream(stream), dy, (const uint8_t *)nullptr, 0, zk, coef, Wk, 64, (const float *)nullptr, st_p, R,
+                     (float *)nullptr, part, L);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }

@@ -27,6 +27,9 @@ L1_MOMENTS = os.environ.get("SPACAP_SA_L1_MOMENTS", "1") not in ("", "0")
 # from POOL_WGRAD_MIN_ROWS rows on (below, the two extra launches of the reduction cost more than the pass saves).
 POOL_WGRAD = os.environ.get("SPACAP_SA_POOL_WGRAD", "1") not in ("", "0")
 POOL_WGRAD_MIN_ROWS = 131072
+# SA1's second layer: weight gradient from the data-gradient kernel's pass (tests / lab: SPACAP_SA_FUSE_L2_WGRAD=0 keeps the two
+# kernels apart)
+FUSE_L2_WGRAD = os.environ.get("SPACAP_SA_FUSE_L2_WGRAD", "1") not in ("", "0")
 
 
 def _ptr(t):
@@ -250,22 +253,34 @@ class _SAMLP(Function):
                                           part.data_ptr(), st), "spacap_sa_dgrad_f32")
             finalize(1, C2, st2)
             # layer 2
-            pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)
             has_feat = int(feat is not None)
-            if ctx.recompute:
-                check(lib.spacap_sa_wgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(), W1.data_ptr(),
-                                                   W1.shape[1], has_feat, st1.data_ptr(), R, pw.data_ptr(), st),
-                      "spacap_sa_wgrad_l1in_f32")
-            else:
-                check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
-                                              st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
-            dW2 = sum_slabs(pw, deferrable=True)
             fuse_l1 = (not ctx.has_Y) and (not ctx.need_xyz) and C1 == 64 and C2 == 64
+            # SA1 with the rebuilt first layer: the layer's weight gradient rides the data-gradient kernel (one read of dy2 / z2
+            # instead of two, one launch fewer: csrc/sa_mlp.hip, sa_dgrad_kernel<.., WG>)
+            fuse_w2 = fuse_l1 and ctx.recompute and FUSE_L2_WGRAD
+            if fuse_w2:
+                pw = torch.empty(int(lib.spacap_sa_dgrad_wgrad_l1in_slabs(R)), C2, C1, **f32)
+            else:
+                pw = torch.empty(int(lib.spacap_sa_wgrad_slabs(R, C2, C1, 0)), C2, C1, **f32)
+                if ctx.recompute:
+                    check(lib.spacap_sa_wgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(), W1.data_ptr(),
+                                                       W1.shape[1], has_feat, st1.data_ptr(), R, pw.data_ptr(), st),
+                          "spacap_sa_wgrad_l1in_f32")
+                else:
+                    check(lib.spacap_sa_wgrad_f32(dy2.data_ptr(), None, 0, z2.data_ptr(), coef[1].data_ptr(), z1.data_ptr(),
+                                                  st1.data_ptr(), R, C2, C1, pw.data_ptr(), st), "spacap_sa_wgrad_f32")
+                dW2 = sum_slabs(pw, deferrable=True)
             if fuse_l1:
                 # SA1: the first layer's weight gradient comes out of this kernel's epilogue as three sums
                 # (csrc/sa_mlp.hip, L1Args); dy1 is never written and the first-layer backward pass is skipped
                 pl1 = torch.empty(nparts, C1 * 8 + 4, **f32)
-                if ctx.recompute:
+                if fuse_w2:
+                    check(lib.spacap_sa_dgrad_wgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
+                                                             z1.data_ptr(), W1.data_ptr(), W1.shape[1], has_feat, st1.data_ptr(), B, N, S,
+                                                             part.data_ptr(), pl1.data_ptr(), pw.data_ptr(), st),
+                          "spacap_sa_dgrad_wgrad_l1in_f32")
+                    dW2 = sum_slabs(pw, deferrable=True)
+                elif ctx.recompute:
                     check(lib.spacap_sa_dgrad_l1in_f32(dy2.data_ptr(), z2.data_ptr(), coef[1].data_ptr(), W2.data_ptr(),
                                                        z1.data_ptr(), W1.data_ptr(), W1.shape[1], has_feat, st1.data_ptr(), B, N, S,
                                                        part.data_ptr(), pl1.data_ptr(), st), "spacap_sa_dgrad_l1in_f32")

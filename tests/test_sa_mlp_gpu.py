@@ -255,6 +255,7 @@ def test_first_layer_rebuilt_instead_of_stored(C, npoint, nsample, n, monkeypatc
     feats = pc[..., 3:].transpose(1, 2).contiguous() if C else None
     inds = pu.furthest_point_sample(xyz, npoint)
     monkeypatch.setattr(sa_mlp, "L1_MOMENTS", False)     # (statistics from the summed z1 on both sides: see the next test)
+    monkeypatch.setattr(sa_mlp, "FUSE_L2_WGRAD", False)  # (the second layer's weight gradient by its own kernel on both sides)
     res = []
     for mod, flag in ((sa, True), (sb, False)):
         monkeypatch.setattr(sa_mlp, "RECOMPUTE_Z1", flag)
@@ -375,6 +376,43 @@ def test_pooled_layer_weight_gradient_from_z2_matches_the_dense_kernel(Cf, mlp, 
             assert torch.equal(pa.grad, pb.grad), na
     if fg[0] is not None:
         assert torch.equal(fg[0], fg[1])
+
+
+@pytest.mark.parametrize("C,npoint,nsample,n,B", [(1, 512, 64, 6000, 2), (0, 200, 32, 3000, 2), (1, 77, 16, 1000, 3), (1, 2048, 64, 40000, 2)])
+def test_second_layer_weight_gradient_from_the_data_gradient_pass(C, npoint, nsample, n, B, monkeypatch):
+    """sa_mlp.FUSE_L2_WGRAD (SA1-shaped modules with the rebuilt first layer): dW2 = dz2^T relu(bn(z1)) accumulated by the
+    data-gradient kernel from the tile it already holds (csrc/sa_mlp.hip: sa_dgrad_kernel<.., WG>) against the separate
+    weight-gradient kernel (lib/pointnet2/pytorch_utils.py:11-36; autograd backward of the second Conv2d).  Everything but dW2
+    comes from the same arithmetic: bit-identical; dW2 agrees at fp32 rounding level (row counts that are not multiples of the
+    64-row tile included)."""
+    from spacap3d_amd import pointnet2_utils as pu
+    from spacap3d_amd import sa_mlp
+    from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(13)
+    sa = PointnetSAModuleVotes(npoint=npoint, radius=0.3, nsample=nsample, mlp=[C, 64, 64, 128], use_xyz=True,
+                               normalize_xyz=True).to(DEV).train()
+    sb = copy.deepcopy(sa)
+    pc = S.scene_batch(B, n, use_height=C == 1, seed=4).to(DEV)
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous() if C else None
+    inds = pu.furthest_point_sample(xyz, npoint)
+    monkeypatch.setattr(sa_mlp, "RECOMPUTE_Z1", True)
+    res = []
+    for mod, flag in ((sa, True), (sb, False)):
+        monkeypatch.setattr(sa_mlp, "FUSE_L2_WGRAD", flag)
+        _, out, _ = mod(xyz, feats, inds)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+        (out * w).sum().backward()
+        res.append(out)
+    assert torch.equal(res[0], res[1])
+    second = [n_ for n_, _ in sa.named_parameters() if n_.endswith("conv.weight")][1]
+    for (na, pa), (nb, pb) in zip(sa.named_parameters(), sb.named_parameters()):
+        if na == second:
+            assert not torch.equal(pa.grad, pb.grad), "the weight gradient did not come from the fused kernel"
+            e = (pa.grad - pb.grad).abs().max() / pb.grad.abs().max().clamp_min(1e-20)
+            assert e.item() < 2e-5, (na, e.item())
+        else:
+            assert torch.equal(pa.grad, pb.grad), na
 
 
 def test_unsupported_mlp_uses_the_per_operator_path():
