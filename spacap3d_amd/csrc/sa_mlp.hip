@@ -664,7 +664,10 @@ struct L1Args {
 // and one more product per tile, dW_k += dz_k^T a_prev (contraction over the tile's 64 rows), replaces the separate weight-gradient
 // kernel and its second read of dy and z_k (536 MB at SA1).
 template <int CK, int NT, bool POOLED, bool PREFETCH, bool ALIAS, bool L1 = false, bool WG = false>
-__global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
+// (first-layer instances: two waves per SIMD asked for explicitly.  Left to itself the compiler spreads their state over 262 - 307
+// VGPRs + AGPRs, one more than half the register file: ONE 256-thread workgroup per CU, 32 KB of loads in flight per CU, 182 us
+// at SA1; bounded to 256 registers the plain instance needs no scratch and runs 142 us, the fused one 256 instead of 311)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(L1 ? 2 : 1))) void sa_dgrad_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ arg, int S,
                                                        const float *__restrict__ zk, const float *__restrict__ coef,
                                                        const float *__restrict__ Wk, int CP, const float *__restrict__ zp,
                                                        const float *__restrict__ st_p, long R, float *__restrict__ dyp,
@@ -770,7 +773,9 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
         if (L.feat) in[3] = L.feat[(size_t)b * L.Np + p];
       }
       st4(&s_rel[tid * 4], in);
+#ifndef SPACAP_HACK_NOQ3
       q2 += in;
+#endif
     }
     __syncthreads();
     if (PREFETCH && FULL) fetch(t + gridDim.x);
@@ -818,7 +823,9 @@ __global__ __launch_bounds__(256) void sa_dgrad_kernel(const float *__restrict__
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             q1[u] += in * d[u];
+#ifndef SPACAP_HACK_NOQ3
             q3[u] += in * z[u];
+#endif
           }
         } else {
           st4(dyp + o, d);
