@@ -15,6 +15,10 @@ torch.manual_seed(0)
 model = build_default(input_feature_dim=1, num_proposal=256).to(dev).train()
 trainer = Trainer(model, S.mean_size_arr().numpy(), use_relation=True)
 if os.environ.get("SKEW"): trainer.prefetch_skew_us = int(os.environ["SKEW"])
+if os.environ.get("RESERVE"):   # a preset side stream keeps prefetch() from setting the reservation itself
+    from spacap3d_amd._native import check, lib
+    trainer.side_stream = engine._role_stream(dev, "side")
+    check(lib.spacap_sa_reserve_cus(int(os.environ["RESERVE"])), "reserve")
 data = synthetic_batch(8, 40000, dev, seed=1000)
 trainer.step(data, next_data=data)
 assert trainer.enable_graph(data), trainer.graph_error
@@ -30,4 +34,4 @@ def reuse():
     data["_fps_prefetch"] = saved
     trainer.step(data, next_data=None)
 timed(reuse, 10)
-print(f"PRIO main={pm} side={ps} SKEW={os.environ.get('SKEW')}: pipelined {ts[0]:.3f} {ts[1]:.3f} {ts[2]:.3f} | no side work {timed(reuse):.3f}", flush=True)
+print(f"PRIO main={pm} side={ps} SKEW={os.environ.get('SKEW')} RESERVE={os.environ.get('RESERVE')}: pipelined {ts[0]:.3f} {ts[1]:.3f} {ts[2]:.3f} | no side work {timed(reuse):.3f}", flush=True)
