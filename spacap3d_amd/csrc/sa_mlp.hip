@@ -2166,6 +2166,19 @@ struct WgradTable {
   int njobs, pad;
   WgradJob job[WG_JOB_MAX];
 };
+#include "wgrad_bf3.inc"
+// (the split-bf16 body, wgrad_bf3.inc: the default; SPACAP_SA_F32MFMA=1 keeps the fp32-MFMA body)
+__global__ __launch_bounds__(256) void linear_wgrad_bf3_batched_kernel(const WgradTable T) {
+  int lo = 0, hi = T.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.job[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const WgradJob J = T.job[lo];
+  const int local = (int)blockIdx.x - J.block0;
+  const int bx = local % J.gx, by = (local / J.gx) % J.gy, bz = local / (J.gx * J.gy);
+  linear_wgrad_bf3_body(J.with_bias != 0, J.g, J.x, J.CK, J.CP, J.R, J.part, bx, by, bz, J.gx);
+}
 __global__ __launch_bounds__(256) void linear_wgrad_batched_kernel(const WgradTable T) {
   int lo = 0, hi = T.njobs - 1;
   while (lo < hi) {
@@ -2199,7 +2212,10 @@ extern "C" int spacap_linear_wgrad_f32(const float *g, const float *x, long R, i
   SPACAP_REQUIRE(g && x && part, "%s: null pointer", what);
   hipStream_t s = spacap::as_stream(stream);
   const dim3 grid(nslab, CK / 128, CP / 128);
-  if (with_bias) hipLaunchKernelGGL((linear_wgrad_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  if (!f32_mfma_only()) {
+    if (with_bias) hipLaunchKernelGGL((linear_wgrad_bf3_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+    else hipLaunchKernelGGL((linear_wgrad_bf3_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  } else if (with_bias) hipLaunchKernelGGL((linear_wgrad_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
   else hipLaunchKernelGGL((linear_wgrad_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -2241,7 +2257,8 @@ extern "C" int spacap_linear_wgrad_batched_f32(const float *const *g, const floa
       blocks += (long)nslab * (CK[i] / 128) * (CP[i] / 128);
       SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
     }
-    hipLaunchKernelGGL(linear_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+    if (!f32_mfma_only()) hipLaunchKernelGGL(linear_wgrad_bf3_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+    else hipLaunchKernelGGL(linear_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
   }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -2353,6 +2370,23 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_batched_kernel(const ConvTa
                      J.with_bias);
 }
 
+// (the split-bf16 bodies of wgrad_bf3.inc: the default; SPACAP_SA_F32MFMA=1 keeps the fp32-MFMA ones)
+__global__ __launch_bounds__(256) void conv1x1_wgrad_bf3_kernel(const float *__restrict__ g, const float *__restrict__ x, int CO,
+                                                                int CI, int N, int nsplit, float *__restrict__ part) {
+  conv1x1_wgrad_bf3_body(g, x, CO, CI, N, nsplit, part, blockIdx.x, blockIdx.y, blockIdx.z, 0);
+}
+__global__ __launch_bounds__(256) void conv1x1_wgrad_bf3_batched_kernel(const ConvTable T) {
+  int lo = 0, hi = T.njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (T.job[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ConvJob J = T.job[lo];
+  const int local = (int)blockIdx.x - J.block0;
+  conv1x1_wgrad_bf3_body(J.g, J.x, J.CO, J.CI, J.N, J.nsplit, J.part, local % J.gx, (local / J.gx) % J.gy, local / (J.gx * J.gy),
+                         J.with_bias);
+}
+
 inline int conv1x1_nsplit(int B, int CO, int CI, int N) {
   const long yz = (long)((CO + 127) / 128) * ((CI + 127) / 128), tiles = N / 32;
   long n = 512 / (yz * B), cap = (4L << 20) / ((long)CO * CI * B);
@@ -2401,7 +2435,8 @@ extern "C" int spacap_conv1x1_wgrad_batched_f32(const float *const *g, const flo
       blocks += (long)nslabs[i] * ((CO[i] + 127) / 128) * ((CI[i] + 127) / 128);
       SPACAP_REQUIRE(blocks < 2147483647L, "%s: too many blocks", what);
     }
-    hipLaunchKernelGGL(conv1x1_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+    if (!f32_mfma_only()) hipLaunchKernelGGL(conv1x1_wgrad_bf3_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
+    else hipLaunchKernelGGL(conv1x1_wgrad_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, s, T);
   }
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
@@ -2414,8 +2449,12 @@ extern "C" int spacap_conv1x1_wgrad_f32(const float *g, const float *x, int B, i
   const int nslab = spacap_conv1x1_wgrad_slabs(B, CO, CI, N);
   SPACAP_REQUIRE(nslab > 0, "%s: (B=%d, CO=%d, CI=%d, N=%d) unsupported", what, B, CO, CI, N);
   SPACAP_REQUIRE(g && x && part, "%s: null pointer", what);
-  hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nslab, (CO + 127) / 128, (CI + 127) / 128), dim3(256), 0, spacap::as_stream(stream), g, x, CO, CI,
-                     N, nslab / B, part);
+  if (!f32_mfma_only())
+    hipLaunchKernelGGL(conv1x1_wgrad_bf3_kernel, dim3(nslab, (CO + 127) / 128, (CI + 127) / 128), dim3(256), 0, spacap::as_stream(stream), g, x,
+                       CO, CI, N, nslab / B, part);
+  else
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3(nslab, (CO + 127) / 128, (CI + 127) / 128), dim3(256), 0, spacap::as_stream(stream), g, x, CO, CI,
+                       N, nslab / B, part);
   SPACAP_CHECK_LAUNCH(what);
   return SPACAP_OK;
 }
