@@ -276,6 +276,9 @@ int spacap_relation_l1_bwd_f32(const float *dH1, const float *H1, const float *P
  * block's query range can straddle workgroups; unused slots are written as zeros).  The caller adds both up in order.
  * nparts = spacap_relation_fused_nparts(B, K) (the grid; depends on the reserved CUs at the time of the call) and
  * zslots = spacap_relation_fused_zsplit(B, K, nparts) are passed back in so that buffers and launch agree. */
+/* CUs the fused relation head's persistent grids leave free in addition to spacap_sa_reserve_cus (process-wide, 0 by default): for a
+ * caller that runs the caption decoder on another stream beside the head.  0 <= n <= CUs / 2. */
+int spacap_relation_fused_leave_cus(int n);
 int spacap_relation_fused_supported(int H, int K, int C, int n_out);
 int spacap_relation_fused_nparts(int B, int K);
 int spacap_relation_fused_zsplit(int B, int K, int nparts);

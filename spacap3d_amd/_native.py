@@ -63,6 +63,7 @@ SIGNATURES = {
     "spacap_relation_l1_fwd_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "spacap_relation_l1_bwd_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "spacap_relation_fused_supported": (_i, [_i, _i, _i, _i]),
+    "spacap_relation_fused_leave_cus": (_i, [_i]),
     "spacap_relation_fused_zsplit": (_i, [_i, _i, _i]),
     "spacap_relation_fused_nparts": (_i, [_i, _i]),
     "spacap_relation_fused_part_floats": (_i, []),

@@ -20,6 +20,9 @@
 // the operands are split once by their producer and live in LDS as bf16 images, row-major where the contraction runs over
 // channels and channel-major (the producing MFMA issued with its operands swapped) where it runs over the rows.  The small
 // products use v_mfma_f32_16x16x4_f32 (exact fp32).  H = 8 heads, 128 channels, 9 outputs, K a multiple of 8.
+#include <stdlib.h>
+#include <atomic>
+
 #include "common.hpp"
 
 namespace {
@@ -463,10 +466,16 @@ constexpr size_t BWD_LDS = (size_t)2 * 3 * IMGT * 2 + (size_t)(TR * LDT + H * TR
 // Grid: one workgroup per CU the caller has not reserved for side-stream work (spacap_sa_reserve_cus), each with a contiguous
 // range of tile units.  A grid sized to ALL CUs would leave its last workgroups waiting behind the sampling chain's (one
 // scene per CU for the first half of the step) and run them as a second round: twice the time.
+// CUs the head's persistent grids leave free IN ADDITION to spacap_sa_reserve_cus: a caller that runs the caption decoder on
+// another stream beside the head (engine.Trainer: the decoder only needs the encoder's output) sets this to what the decoder's
+// launches need to be resident at once (spacap_relation_fused_leave_cus).  Below ~56 the decoder's 64-workgroup launches queue
+// behind the head's persistent workgroups and the two chains serialise again (measured: 7.25 against 6.97 ms per step).
+static std::atomic<int> g_rel_leave{0};
 inline int grid_size(int B, int K, int per_cu) {
   const long units = (long)B * (K / TJ) * (K / TI);
   // (with two workgroups per CU the dispatcher needs slack beyond the occupied CUs themselves: sa_mlp.hip, fwd_resident)
-  const long g = (long)per_cu * std::max(1, spacap::device_cus() - spacap::sa_reserved_cus() * (per_cu > 1 ? 3 : 1));
+  const int extra = g_rel_leave.load(std::memory_order_relaxed);   // CUs left to a stream that runs beside the head (below)
+  const long g = (long)per_cu * std::max(1, spacap::device_cus() - extra - spacap::sa_reserved_cus() * (per_cu > 1 ? 3 : 1));
   return (int)std::min(units, g);
 }
 // dU slots: the largest number of workgroups whose ranges meet one key block
@@ -482,6 +491,11 @@ inline int du_slots(int B, int K, int G) {
 
 }  // namespace
 
+extern "C" int spacap_relation_fused_leave_cus(int n) {
+  if (n < 0 || n > spacap::device_cus() / 2) return SPACAP_E_INVALID;
+  g_rel_leave.store(n, std::memory_order_relaxed);
+  return SPACAP_OK;
+}
 extern "C" int spacap_relation_fused_supported(int H_, int K, int C_, int NO_) {
   return H_ == H && C_ == C && NO_ == NO && K >= 8 && K % 8 == 0;
 }

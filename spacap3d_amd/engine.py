@@ -60,6 +60,7 @@ class Trainer:
         # tests: behave as a multi-rank run does (optimizer + gradient packing outside the graph) on one GPU
         self.split_optimizer = split_optimizer
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
+        self.fork_relation = os.environ.get("SPACAP_FORK_RELATION", "1") != "0"     # relation head beside the decoder (_fork_relation)
         # multi-rank tail: SPACAP_OVERLAP_ALLREDUCE=1 all-reduces the captioner's slice of the flat gradient bucket on a
         # communication stream while the detector's backward is still running (see _boundary / _optimizer_step).  OFF by
         # default -- one all-reduce after the whole backward -- until the RCCL leg has passed the bitwise bucket test on a
@@ -84,6 +85,7 @@ class Trainer:
             # process-wide kernel setting, owned by the newest Trainer: no CUs left out until this one prefetches
             from ._native import check, lib
             check(lib.spacap_sa_reserve_cus(0), "spacap_sa_reserve_cus")
+            self._fork_relation(next(model.parameters()).device)   # (here, not at capture: eager and replayed steps then launch the same grids)
         self._prefetch_graph_key = self._prefetch_graph_obj = self._prefetch_in = self._prefetch_out = None
         broadcast_parameters(model)
 
@@ -296,6 +298,8 @@ class Trainer:
         if self._bn_counters is not None:
             self._bn_counters.add_(1)    # every BatchNorm layer's num_batches_tracked, one launch (see _adopt_bn_counters)
         self._overlap_armed = self._overlap_possible(pc)
+        if pc.is_cuda and (self.fork_relation and self.use_relation and not self._overlap_armed) != getattr(self, "_fork_on", False):
+            self._fork_relation(pc.device, armed=self._overlap_armed)   # (a test switched the overlapped exchange on / off after construction)
         self._armed_step = self._overlap_armed   # (persists through graph replays: the tail counts the step, see _optimizer_step)
         self._boundary_done = False
         if self._overlap_armed:
@@ -531,6 +535,23 @@ class Trainer:
             self.graph_error = f"{type(e).__name__}: {str(e)[:300]}\n" + "".join(traceback.format_tb(e.__traceback__)[-6:])
             torch.cuda.synchronize(dev)
             return False
+
+    # CUs the relation head's grids leave to the decoder running beside it (below 56 the two chains serialise again: measured)
+    RELATION_LEAVE_CUS = 64
+
+    def _fork_relation(self, dev, armed=None):
+        """Inside this Trainer's steps the relation head (forward 0.16 ms, backward 0.46 ms of persistent workgroups) and the caption
+        decoder (two chains of ~50 latency-bound launches on a few CUs) run on two streams: see
+        TransformerDecoderModel.fork_relation.  Not with the overlapped gradient exchange (its boundary hook assumes one stream
+        has produced every captioner gradient)."""
+        from ._native import check, lib
+        from .transformer_captioner import TransformerDecoderModel
+        on = self.fork_relation and self.use_relation and not (self.overlap_allreduce if armed is None else armed)
+        self._fork_on = on
+        for mod in self.model.modules():
+            if isinstance(mod, TransformerDecoderModel):
+                mod.fork_relation = on
+        check(lib.spacap_relation_fused_leave_cus(self.RELATION_LEAVE_CUS if on else 0), "spacap_relation_fused_leave_cus")
 
     def _capture(self, static, warmup):
         """``warmup`` REAL training steps on the static batch (they update the parameters, the BatchNorm statistics

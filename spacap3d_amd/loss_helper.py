@@ -236,6 +236,9 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
             torch.sum(objectness_mask) + 1e-6)
 
+    rel_stream = d.pop("_rel_stream", None)
+    if rel_stream is not None:     # (the relation head ran on a stream of its own: TransformerDecoderModel.fork_relation)
+        torch.cuda.current_stream(d["relation_pred"].device).wait_stream(rel_stream)
     if use_relation:
         from .backend import ops
         frel = getattr(ops(), "relation_losses", None) if d["relation_pred"].is_cuda else None

@@ -486,7 +486,7 @@ class TransformerDecoderModel(nn.Module):
             # as one launch (csrc/caption_prep.hip) and the decoder stack on its output
             memory = self.model.encode(src, src_pos, src_mask)
             if self.check_relation:
-                self._relation_head(ep)
+                self._relation_head_forked(ep)
             te = self.model.tgt_embed
             got = prep(ep["aggregated_vote_xyz"], ep["ref_center_label"], src, memory, ep["lang_label"], te[0], te[1])
             if got is not None:
@@ -531,6 +531,35 @@ class TransformerDecoderModel(nn.Module):
         if self.check_relation and "relation_pred" not in ep:
             self._relation_head(ep)
         return ep
+
+    # The relation head reads the last encoder layer only and the decoder reads the encoder's output only: the two are independent
+    # until the losses are added.  `fork_relation` (set by engine.Trainer for its captured step) runs the head on a stream of its own;
+    # autograd then runs its backward on that stream as well, beside the decoder's backward (the engine orders the streams where
+    # gradients cross).  Values are those of the serial order: no kernel changes, only placement.  The head's persistent grids
+    # leave the decoder's launches room (spacap_relation_fused_leave_cus).
+    fork_relation = False
+    _REL_STREAMS = {}
+
+    def _relation_head_forked(self, ep):
+        src = ep["aggregated_vote_features"]
+        if not (self.fork_relation and src.is_cuda and torch.is_grad_enabled()):
+            return self._relation_head(ep)
+        dev = src.device
+        rs = TransformerDecoderModel._REL_STREAMS.get(dev)
+        if rs is None:
+            rs = TransformerDecoderModel._REL_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        rs.wait_stream(cur)
+        sa = self.model.encoder.layers[-1].self_attn
+        with torch.cuda.stream(rs):
+            self._relation_head(ep)
+        if not torch.cuda.is_current_stream_capturing():
+            # (eager steps: the caching allocator must know both streams touch these)
+            for t in (sa.attn, sa.value):
+                if torch.is_tensor(t):
+                    t.record_stream(rs)
+            ep["relation_pred"].record_stream(cur)
+        ep["_rel_stream"] = rs    # loss_helper.get_scene_cap_loss joins the streams before it reads relation_pred
 
     def _relation_head(self, ep):
         """relation_pred (B,K,K,9) from the last encoder layer's attention map and values (:392-397)."""
