@@ -26,7 +26,7 @@ def _role_stream(device, role):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _STREAMS:
         dev = torch.device("cuda", key[1])
-        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm")}
+        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm", "wgrad")}
     return _STREAMS[key][role]
 
 
@@ -61,6 +61,9 @@ class Trainer:
         self.split_optimizer = split_optimizer
         self.prefetch_graph = os.environ.get("SPACAP_PREFETCH_GRAPH", "1") != "0"   # the side-stream pyramid as one graph launch
         self.fork_relation = os.environ.get("SPACAP_FORK_RELATION", "1") != "0"     # relation head beside the decoder (_fork_relation)
+        self.flush_mid = os.environ.get("SPACAP_FLUSH_MID", "1") != "0"             # captioner weight gradients beside the detector's backward
+        self._flush_mid, self._mid_done = False, 0
+        self._mid_stream = None
         # multi-rank tail: SPACAP_OVERLAP_ALLREDUCE=1 all-reduces the captioner's slice of the flat gradient bucket on a
         # communication stream while the detector's backward is still running (see _boundary / _optimizer_step).  OFF by
         # default -- one all-reduce after the whole backward -- until the RCCL leg has passed the bitwise bucket test on a
@@ -168,14 +171,50 @@ class Trainer:
         d = self.model(dict(data_dict), after_proposal=early)
         det_vec = d.get("_det_vec")
         d = get_scene_cap_loss(d, use_relation=self.use_relation, **kw)
-        if self._overlap_armed:
+        if self._overlap_armed or self._flush_mid:
             # The backward runs the captioner's nodes first (they were created last), then the detection losses, then the
             # detector.  A hook on the first detector-side tensor therefore fires exactly when every captioner gradient exists.
             marks = [t for t in (det_vec, d.get("aggregated_vote_features"), d.get("aggregated_vote_xyz"))
                      if torch.is_tensor(t) and t.requires_grad]
             for t in marks:
-                t.register_hook(self._boundary_hook)
+                t.register_hook(self._boundary_hook if self._overlap_armed else self._mid_flush_hook)
+            # ... and a second time when the backward enters SA4: by then the vote / proposal / feature-propagation nets have
+            # queued their 1x1-convolution weight gradients (one batched launch of 0.07 ms), SA4 - SA2's backward runs beside it
+            t4 = d.get("sa4_features")
+            if self._flush_mid and torch.is_tensor(t4) and t4.requires_grad:
+                t4.register_hook(self._mid_flush_hook2)
         return d
+
+    # -- the captioner's weight gradients beside the detector's backward --------------------------------------------------
+    # When the backward reaches the detector, every weight gradient of the captioner (~50 Linear layers: one batched launch of
+    # 0.12 ms + its slab sums) is queued and nothing but the optimizer will read it.  What follows on the step's stream -- the
+    # backward of the proposal / vote / feature-propagation nets and of SA4 / SA3 -- is ~0.5 ms of short launches that leave most
+    # of the chip idle: the queue is flushed THERE, on a stream of its own, instead of after the whole backward.
+    def _mid_flush_hook2(self, grad):
+        return self._mid_flush_hook(grad, stage=2)
+
+    def _mid_flush_hook(self, grad, stage=1):
+        # _mid_done: 0 nothing flushed yet, 1 the captioner boundary has flushed, 2 the SA4 boundary has flushed
+        if self._flush_mid and self._mid_done < stage:
+            self._mid_done = stage
+            from . import _native
+            dq = _native._DEFERRED
+            if dq is not None and grad.is_cuda:
+                dev = grad.device
+                ws = _role_stream(dev, "wgrad")
+                cur = torch.cuda.current_stream(dev)
+                ws.wait_stream(cur)   # (a second flush queues behind the first on the same stream)
+                if not torch.cuda.is_current_stream_capturing():   # (eager steps: the caching allocator must know both streams)
+                    for j in dq.jobs + dq.conv_jobs:
+                        for t in (j[0], j[1], j[3]):
+                            t.record_stream(ws)
+                    for part, out in dq.items:
+                        part.record_stream(ws)
+                        out.record_stream(ws)
+                with torch.cuda.stream(ws):
+                    dq.flush()
+                self._mid_stream = ws
+        return None
 
     def _setup(self, data_dict):
         """First step: discover which parameters the loss reaches, then lay their gradients out in one flat
@@ -302,6 +341,8 @@ class Trainer:
             self._fork_relation(pc.device, armed=self._overlap_armed)   # (a test switched the overlapped exchange on / off after construction)
         self._armed_step = self._overlap_armed   # (persists through graph replays: the tail counts the step, see _optimizer_step)
         self._boundary_done = False
+        self._mid_done, self._mid_stream = 0, None
+        self._flush_mid = self.flush_mid and pc.is_cuda and not self._overlap_armed
         if self._overlap_armed:
             self._sig[:1].add_(1)        # the step number the boundary will publish
         d = self.loss(data_dict)
@@ -314,6 +355,9 @@ class Trainer:
             if all(p.grad is None for p in self.bucket.params):
                 with grad_slots(getattr(self, "_grad_slots", None)), deferred_slab_sums() as dq:
                     d["loss"].backward(self._seed_grad(d["loss"]))
+                    if self._mid_stream is not None:    # the captioner's weight gradients ran beside the detector's backward
+                        torch.cuda.current_stream(pc.device).wait_stream(self._mid_stream)
+                        self._mid_stream = None
                     if self._eager_checks > 0:
                         # A queued sum is unfilled until the flush: every byte of it must have reached parameters' .grad
                         # untouched (a parameter consumed by two autograd nodes, or an AccumulateGrad that clones, would

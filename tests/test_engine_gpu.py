@@ -660,7 +660,7 @@ def test_no_library_gemm_or_convolution_kernel_inside_a_training_step(cfg):
         tr.step(data, next_data=data)
         torch.cuda.synchronize()
     names = [e.key for e in prof.key_averages() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
-    assert len(names) > 100, len(names)     # the profiler saw the step's kernels
+    assert len(names) > 80, len(names)      # the profiler saw the step's kernels (distinct names: ~95 of ~320 launches)
     bad = [n for n in names if n.startswith("Cijk_") or "naive_conv" in n or "miopen" in n.lower() or "hipblaslt" in n.lower()
            or "rocblas" in n.lower()]
     assert not bad, bad
