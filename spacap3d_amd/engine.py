@@ -26,7 +26,7 @@ def _role_stream(device, role):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _STREAMS:
         dev = torch.device("cuda", key[1])
-        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm", "wgrad")}
+        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm", "wgrad", "relation")}
     return _STREAMS[key][role]
 
 

@@ -545,9 +545,8 @@ class TransformerDecoderModel(nn.Module):
         if not (self.fork_relation and src.is_cuda and torch.is_grad_enabled()):
             return self._relation_head(ep)
         dev = src.device
-        rs = TransformerDecoderModel._REL_STREAMS.get(dev)
-        if rs is None:
-            rs = TransformerDecoderModel._REL_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        from .engine import _role_stream
+        rs = _role_stream(dev, "relation")
         cur = torch.cuda.current_stream(dev)
         rs.wait_stream(cur)
         sa = self.model.encoder.layers[-1].self_attn

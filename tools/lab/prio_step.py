@@ -9,7 +9,7 @@ from spacap3d_amd.spacapnet import build_default
 dev = torch.device("cuda:0")
 pm, ps = [int(v) for v in os.environ.get("PRIO", "0,0").split(",")]
 torch.zeros(1, device=dev)
-engine._STREAMS[("cuda", 0)] = {"side": torch.cuda.Stream(device=dev, priority=ps), "capture": torch.cuda.Stream(device=dev, priority=pm), "wgrad": torch.cuda.Stream(device=dev),
+engine._STREAMS[("cuda", 0)] = {"side": torch.cuda.Stream(device=dev, priority=ps), "capture": torch.cuda.Stream(device=dev, priority=pm), "wgrad": torch.cuda.Stream(device=dev), "relation": torch.cuda.Stream(device=dev),
                                 "comm": torch.cuda.Stream(device=dev)}
 torch.manual_seed(0)
 model = build_default(input_feature_dim=1, num_proposal=256).to(dev).train()
