@@ -3,8 +3,8 @@
 The whole-run `--stats` summary also contains the warm-up steps and the op micro-benchmarks; `adam_flat_kernel` (one launch
 per training step, the step's last kernel) marks the end of every step, so the window
 [end of step (total - K) ... end of the last step] holds exactly the K timed steps.  The queue that carries
-`adam_flat_kernel` is the step's own stream ("main"); every other queue is the side stream (the next batch's sampling
-pyramid).  The table is ordered by summed MAIN-stream time: its first row is the kernel `bench.py` reports as `roofline`.
+`adam_flat_kernel` is the step's own stream ("main"; the queues of the step's forked branches count with it); the queue that
+carries the sampling kernels of the next batch's pyramid is the side stream.  The table is ordered by summed MAIN-stream time: its first row is the kernel `bench.py` reports as `roofline`.
 
 Usage: python tools/prof_window.py <kernel_trace.csv> <K timed steps> [top N]
 Exits non-zero (and prints nothing to stdout) when the marker kernel is missing or there are fewer than K + 1 steps.
@@ -41,7 +41,14 @@ def window(ev, K):
                          f"(one per step marks the step's end; was the optimizer kernel renamed or the trace cut short?)")
     t0, t1 = marks[-K - 1][1], marks[-1][1]
     main_q = marks[-1][3]
-    return [e for e in ev if t0 <= e[0] <= t1], t0, t1, main_q
+    win = [e for e in ev if t0 <= e[0] <= t1]
+    # Since round 6 the captured step forks: the relation head runs beside the caption decoder and the captioner's weight
+    # gradients beside the detector's backward, on queues of their own.  Those launches belong to the STEP; the side stream is
+    # the queue that carries the next batch's sampling chain (its first-level kernel marks it).
+    side_qs = {e[3] for e in win if "fps_bucket_kernel" in e[2] or "delay_kernel" in e[2]} - {main_q}
+    if side_qs:
+        win = [(s, e, n, (q if q in side_qs else main_q)) for s, e, n, q in win]
+    return win, t0, t1, main_q
 
 
 def main():
