@@ -486,6 +486,9 @@ int spacap_sa_dw1_assemble_f32(const float *pw1, int n1, const float *pf, int nf
 int spacap_linear_wgrad_slabs(long R, int CK, int CP);
 int spacap_linear_wgrad_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, float *part,
                             spacap_stream_t stream);
+/* ... with the number of row slabs chosen by the caller: part f32 [nslab][CK*CP (+ CK when with_bias)], 1 <= nslab <= ceil(R / 32). */
+int spacap_linear_wgrad_nslab_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, int nslab, float *part,
+                                  spacap_stream_t stream);
 /* njobs independent weight gradients in ONE launch; part[i] receives nslabs[i] partial results (with nslabs[i] =
  * spacap_linear_wgrad_slabs(...) the values of spacap_linear_wgrad_f32; other counts regroup the rows).  All
  * arrays are HOST arrays read before the call returns; the job table is passed to the kernel by value (capturable in a

@@ -176,6 +176,7 @@ SIGNATURES = {
     "spacap_linear_rows_f32": (_i, [_p, _p, _p, _l, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_f32": (_i, [_p, _p, _l, _i, _i, _i, _p, _p]),
+    "spacap_linear_wgrad_nslab_f32": (_i, [_p, _p, _l, _i, _i, _i, _i, _p, _p]),
     "spacap_linear_wgrad_slabs_batched": (_i, [_l, _i, _i]),
     "spacap_linear_wgrad_batched_f32": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "spacap_layernorm_fwd_f32": (_i, [_p, _p, _p, _l, _i, _f, _p, _p, _p]),

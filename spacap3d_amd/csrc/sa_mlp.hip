@@ -2221,6 +2221,26 @@ extern "C" int spacap_linear_wgrad_f32(const float *g, const float *x, long R, i
   return SPACAP_OK;
 }
 
+// The same with the number of row slabs chosen by the caller (1 <= nslab <= row tiles): part f32 [nslab][CK*CP (+ CK)].  For the
+// wide relation head of the stress configuration (4.2 M pair rows x 512 x 512): 64 slabs fill the chip twice over, where
+// spacap_linear_wgrad_slabs' 4 M-element cap on a partial set would leave it 16.
+extern "C" int spacap_linear_wgrad_nslab_f32(const float *g, const float *x, long R, int CK, int CP, int with_bias, int nslab, float *part,
+                                             spacap_stream_t stream) {
+  const char *what = "spacap_linear_wgrad_nslab_f32";
+  SPACAP_REQUIRE(spacap_linear_wgrad_slabs(R, CK, CP) > 0 && nslab >= 1 && nslab <= 65535 && nslab <= (R + TW - 1) / TW,
+                 "%s: (R=%ld, CK=%d, CP=%d, nslab=%d) unsupported", what, R, CK, CP, nslab);
+  SPACAP_REQUIRE(g && x && part, "%s: null pointer", what);
+  hipStream_t s = spacap::as_stream(stream);
+  const dim3 grid(nslab, CK / 128, CP / 128);
+  if (!f32_mfma_only()) {
+    if (with_bias) hipLaunchKernelGGL((linear_wgrad_bf3_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+    else hipLaunchKernelGGL((linear_wgrad_bf3_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  } else if (with_bias) hipLaunchKernelGGL((linear_wgrad_kernel<true>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  else hipLaunchKernelGGL((linear_wgrad_kernel<false>), grid, dim3(256), 0, s, g, x, CK, CP, R, part);
+  SPACAP_CHECK_LAUNCH(what);
+  return SPACAP_OK;
+}
+
 // njobs independent weight gradients in one launch (same values as njobs calls of spacap_linear_wgrad_f32 with the
 // same arguments when nslabs[i] = spacap_linear_wgrad_slabs(...); any other slab count only changes how the rows are
 // grouped).  All arrays are HOST arrays, read before the call returns; part[i] holds nslabs[i] partial results.

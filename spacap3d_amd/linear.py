@@ -7,6 +7,8 @@ GEMM, see _forward_product); the backward's
 ``dW = g^T x`` and ``db = sum_r g`` -- for <= 2 048 rows a memset + a split-K GEMM + a column-sum kernel of
 ~30 us of latency -- become one kernel producing per-slab partials of both plus one sum over the slabs.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -224,6 +226,9 @@ def packed_views(flat, params_w, params_b):
     ob = (params_b[0].data_ptr() - flat.data_ptr()) // flat.element_size()
     return flat[ow:ow + rows * cols].view(rows, cols), flat[ob:ob + rows]
 
+
+# wide relation head (d_model = 512): weight gradient by csrc/wgrad_bf3.inc instead of gemm_bf3_wgrad_kernel
+WIDE_WGRAD_TR = os.environ.get("SPACAP_WIDE_WGRAD_TR", "1") != "0"   # wide relation head: weight gradient by csrc/wgrad_bf3.inc
 
 
 class Conv1x1(Function):
@@ -484,8 +489,14 @@ class RelationWide(Function):
             dW3, db2, db3 = s[:NO * C].view(NO, C), s[NO * C:NO * C + C], s[NO * C + C:NO * C + C + NO]
             nslab = int(lib.spacap_gemm_bf3_wgrad_slabs(R, C, C))
             pw = torch.empty(nslab, C * C, dtype=torch.float32, device=dev)
-            check(lib.spacap_gemm_bf3_wgrad_f32(dz2.data_ptr(), C, hid1.data_ptr(), C, R, C, C, nslab, pw.data_ptr(), st),
-                  "spacap_gemm_bf3_wgrad_f32")
+            if WIDE_WGRAD_TR:
+                # the Linear layers' split-bf16 weight-gradient kernel (row-major images read by transposing LDS reads:
+                # csrc/wgrad_bf3.inc) instead of gemm_bf3_wgrad_kernel's images staged transposed with two-byte LDS writes
+                check(lib.spacap_linear_wgrad_nslab_f32(dz2.data_ptr(), hid1.data_ptr(), R, C, C, 0, nslab, pw.data_ptr(), st),
+                      "spacap_linear_wgrad_nslab_f32")
+            else:
+                check(lib.spacap_gemm_bf3_wgrad_f32(dz2.data_ptr(), C, hid1.data_ptr(), C, R, C, C, nslab, pw.data_ptr(), st),
+                      "spacap_gemm_bf3_wgrad_f32")
             dW2 = sum_slabs(pw, deferrable=True).view(C, C)
             dh1 = bf3_product(dz2, bf3_pieces(W2, trans=True), out=hid2)      # hid2 is dead: its memory takes dhid1
             del dz2

@@ -56,6 +56,37 @@ def test_eager_is_repeatable_and_prefetch_graph_agree():
             assert abs(x - y) <= 2e-3 * abs(x) + 1e-4, (name, i, a, other)
 
 
+def test_forked_placement_of_the_relation_head_and_of_the_weight_gradients_changes_no_value():
+    """Round 6: inside a Trainer's steps the relation head runs on a stream of its own beside the caption decoder
+    (models/transformer_captioner.py:392-398 against :193-225: independent until the losses are added) and the captioner's
+    queued weight gradients are flushed beside the detector's backward (engine.Trainer._mid_flush_hook).  Placement only: with
+    both switched off the same kernels run in one chain.  Losses step by step and the parameters after the run must agree to
+    rounding (the head's persistent grids leave CUs to the decoder, which regroups its partial sums: not bit for bit)."""
+    from spacap3d_amd.engine import Trainer, synthetic_batch
+    data = synthetic_batch(2, 4096, DEV, seed=3, vocab=200)
+    runs = []
+    for forked in (True, False):
+        model = _make()
+        tr = Trainer(model, S.mean_size_arr().numpy(), lr=1e-6)
+        tr.fork_relation = tr.flush_mid = forked
+        tr._fork_relation(torch.device(DEV))
+        losses = [float(tr.step(data, next_data=data))]
+        assert tr.enable_graph(data, warmup=1), tr.graph_error
+        for _ in range(3):
+            losses.append(float(tr.step(data, next_data=data)))
+        torch.cuda.synchronize()
+        from spacap3d_amd.transformer_captioner import TransformerDecoderModel
+        assert all(m.fork_relation == forked for m in model.modules() if isinstance(m, TransformerDecoderModel))
+        runs.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (la, pa), (lb, pb) = runs
+    for i, (x, y) in enumerate(zip(la, lb)):
+        assert abs(x - y) <= 1e-5 * abs(x) + 1e-6, (i, la, lb)
+    for n in pa:   # (Adam normalises the step: a parameter that started at zero moves by ~lr per step whatever its gradient's size,
+        # so rounding-level gradient differences show at the scale of lr; bounded by the distance the steps can cover)
+        d = float((pa[n] - pb[n]).abs().max())
+        assert d <= 5e-6 + 1e-5 * float(pb[n].abs().max()), (n, d)
+
+
 def test_graph_step_never_reuses_the_previous_batch_geometry():
     """A graph captured WITH a prefetched pyramid reads sampling / grouping indices from static buffers.  Feeding it a
     NEW batch that carries no prefetch (epoch boundary, caller without next_data) must compute that batch's pyramid in
