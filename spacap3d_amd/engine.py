@@ -211,6 +211,9 @@ class Trainer:
                     for part, out in dq.items:
                         part.record_stream(ws)
                         out.record_stream(ws)
+                    for _, tensors in dq.calls:
+                        for t in tensors:
+                            t.record_stream(ws)
                 with torch.cuda.stream(ws):
                     dq.flush()
                 self._mid_stream = ws
@@ -581,7 +584,7 @@ class Trainer:
             return False
 
     # CUs the relation head's grids leave to the decoder running beside it (below 56 the two chains serialise again: measured)
-    RELATION_LEAVE_CUS = 64
+    RELATION_LEAVE_CUS = int(os.environ.get("SPACAP_RELATION_LEAVE_CUS", "64"))
 
     def _fork_relation(self, dev, armed=None):
         """Inside this Trainer's steps the relation head (forward 0.16 ms, backward 0.46 ms of persistent workgroups) and the caption

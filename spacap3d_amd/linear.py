@@ -612,9 +612,16 @@ class VocabProjection(Function):
                            o_zero=1 if skip else 0)
             dW = torch.empty(V, D, dtype=torch.float32, device=dev)
             db = torch.empty(V, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            check(lib.spacap_dense_wgrad_small_f32(g.data_ptr(), V, n.data_ptr(), D, T if skip else 0, L * D, skip, R, V, D,
-                                                   dW.data_ptr(), db.data_ptr() if db is not None else None, st),
-                  "spacap_dense_wgrad_small_f32")
+            def wgrad(stream):
+                check(lib.spacap_dense_wgrad_small_f32(g.data_ptr(), V, n.data_ptr(), D, T if skip else 0, L * D, skip, R, V, D,
+                                                       dW.data_ptr(), db.data_ptr() if db is not None else None, stream),
+                      "spacap_dense_wgrad_small_f32")
+            from . import _native
+            if _native._DEFERRED is not None:
+                # only the optimizer reads dW / db: with the other queued weight gradients, not at the head of the decoder's chain
+                _native._DEFERRED.queue_call(wgrad, [g, n, dW] + ([db] if db is not None else []))
+            else:
+                wgrad(st)
         return dn, dW, db, None
 
 
