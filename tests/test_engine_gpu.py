@@ -84,7 +84,7 @@ def test_forked_placement_of_the_relation_head_and_of_the_weight_gradients_chang
     for n in pa:   # (Adam normalises the step: a parameter that started at zero moves by ~lr per step whatever its gradient's size,
         # so rounding-level gradient differences show at the scale of lr; bounded by the distance the steps can cover)
         d = float((pa[n] - pb[n]).abs().max())
-        assert d <= 5e-6 + 1e-5 * float(pb[n].abs().max()), (n, d)
+        assert d <= 1.2e-5 + 1e-5 * float(pb[n].abs().max()), (n, d)    # 2 lr per step (a sign flip of a near-zero gradient), 5 steps
 
 
 def test_graph_step_never_reuses_the_previous_batch_geometry():
