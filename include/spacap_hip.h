@@ -859,7 +859,8 @@ int spacap_tf_dgrad_mask_f32(const float *g, const float *W, const float *y, flo
  * models/proposal_module.py:41-55, lib/pointnet2/pytorch_utils.py:11-36, models/transformer_captioner.py:251-258), N = points
  * per scene, a multiple of 64 (spacap_conv1x1_cm_supported).  W f32 [CO,CI] dense.
  *   mode 0 (forward):        out[b,co,n] = sum_ci W[co,ci] in[b,ci,n] + bias[co]   in [B,CI,N], out [B,CO,N], bias f32 [CO] or NULL
- *   mode 1 (input gradient): out[b,ci,n] = sum_co W[co,ci] in[b,co,n]              in [B,CO,N], out [B,CI,N] */
+ *   mode 1 (input gradient): out[b,ci,n] = sum_co W[co,ci] in[b,co,n]              in [B,CO,N], out [B,CI,N]
+ *   mode 2: mode 0 with exact fp32 products (mode 0 multiplies split-bf16 pieces, fp32-equivalent to ~1e-6, unless SPACAP_SA_F32MFMA=1) */
 int spacap_conv1x1_cm_supported(int CI, int CO, long N);
 int spacap_conv1x1_cm_f32(int mode, const float *W, const float *in, const float *bias, int B, int CI, int CO, long N,
                           float *out, spacap_stream_t stream);

@@ -259,7 +259,6 @@ class deferred_slab_sums:
         self.items = []   # (part, out): slab sums to run
         self.jobs = []    # (g2, x2, with_bias, part): weight gradients (linear_wgrad_partials) that fill queued partials
         self.conv_jobs = []   # (g, x, (B, CO, CI, N), part): 1x1-convolution weight gradients (conv1x1_wgrad_partials)
-        self.calls = []   # (fn(stream), tensors): other launches whose results only the optimizer reads (queue_call)
         _DEFERRED = self
         return self
 
@@ -275,12 +274,6 @@ class deferred_slab_sums:
         ptr = part.data_ptr()
         return any(j[3].data_ptr() == ptr for j in self.jobs) or any(j[3].data_ptr() == ptr for j in self.conv_jobs)
 
-    def queue_call(self, fn, tensors):
-        """``fn(stream_handle)`` launches a kernel whose outputs nothing but the optimizer reads (the vocabulary projection's
-        weight gradient: 20 us alone, 100 us beside the relation head's backward at the head of the decoder's chain); ``tensors``
-        are what it touches (kept alive until it has been launched)."""
-        self.calls.append((fn, tuple(tensors)))
-
     def outputs(self):
         """The result tensors of the queued slab sums (still unfilled until ``flush``)."""
         return [o for _, o in self.items]
@@ -292,11 +285,6 @@ class deferred_slab_sums:
     def run_jobs(self):
         """Run the queued weight-gradient kernels now (fills their ``part`` buffers)."""
         import torch
-        calls, self.calls = self.calls, []
-        for fn, tensors in calls:
-            dev = tensors[0].device
-            with torch.cuda.device(dev):
-                fn(torch.cuda.current_stream(dev).cuda_stream)
         jobs, self.jobs = self.jobs, []
         if jobs:   # first the weight gradients themselves (one launch), then the sums over their slabs
             by_dev = {}

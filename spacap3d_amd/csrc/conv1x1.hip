@@ -280,20 +280,23 @@ extern "C" int spacap_conv1x1_cm_supported(int CI, int CO, long N) { return CI >
 
 // mode 0: out[b, co, n] = sum_ci W[co, ci] in[b, ci, n] + bias[co]   (in [B,CI,N], out [B,CO,N], bias may be NULL)
 // mode 1: out[b, ci, n] = sum_co W[co, ci] in[b, co, n]              (in [B,CO,N], out [B,CI,N]): the input gradient
+// mode 2: mode 0 on the fp32-MFMA kernel (exact fp32 products; mode 0 is split-bf16 unless SPACAP_SA_F32MFMA=1)
 extern "C" int spacap_conv1x1_cm_f32(int mode, const float *W, const float *in, const float *bias, int B, int CI, int CO, long N,
                                      float *out, spacap_stream_t stream) {
   const char *what = "spacap_conv1x1_cm_f32";
-  SPACAP_REQUIRE((mode == 0 || mode == 1) && B >= 0 && spacap_conv1x1_cm_supported(CI, CO, N) && N <= 2147483647L && B <= 65535,
+  SPACAP_REQUIRE((mode == 0 || mode == 1 || mode == 2) && B >= 0 && spacap_conv1x1_cm_supported(CI, CO, N) && N <= 2147483647L && B <= 65535,
                  "%s: (mode=%d, B=%d, CI=%d, CO=%d, N=%ld) unsupported", what, mode, B, CI, CO, N);
   if (B == 0) return SPACAP_OK;
   SPACAP_REQUIRE(W && in && out && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
                  "%s: null or unaligned pointer", what);
+  const bool f32fwd = mode == 2;   // mode 2: the forward of mode 0 on the fp32-MFMA kernel whatever the environment says
+  if (f32fwd) mode = 0;
   const int M = mode == 0 ? CO : CI, K = mode == 0 ? CI : CO;
   const dim3 grid((unsigned)(N / TN), (unsigned)((M + TM - 1) / TM), (unsigned)B);
   hipStream_t s = spacap::as_stream(stream);
   // measured in the step (cfg2, 12 + 12 launches): forward 219 -> 192 us on the split-bf16 kernel; the input gradient, whose W^T
   // chunk must be split and staged as a second image, 232 -> 246 us: it stays on the fp32-MFMA kernel
-  if (mode == 0 && !conv_f32_mfma_only())
+  if (mode == 0 && !f32fwd && !conv_f32_mfma_only())
     hipLaunchKernelGGL(conv1x1_cm_bf3_kernel<false>, grid, dim3(256), 0, s, W, CI, in, bias, M, K, (int)N, out);
   else if (mode == 0) hipLaunchKernelGGL(conv1x1_cm_kernel<false>, grid, dim3(256), 0, s, W, CI, in, bias, M, K, (int)N, out);
   else hipLaunchKernelGGL(conv1x1_cm_kernel<true>, grid, dim3(256), 0, s, W, CI, in, (const float *)nullptr, M, K, (int)N, out);

@@ -204,16 +204,14 @@ class Trainer:
                 ws = _role_stream(dev, "wgrad")
                 cur = torch.cuda.current_stream(dev)
                 ws.wait_stream(cur)   # (a second flush queues behind the first on the same stream)
-                if not torch.cuda.is_current_stream_capturing():   # (eager steps: the caching allocator must know both streams)
-                    for j in dq.jobs + dq.conv_jobs:
-                        for t in (j[0], j[1], j[3]):
-                            t.record_stream(ws)
-                    for part, out in dq.items:
-                        part.record_stream(ws)
-                        out.record_stream(ws)
-                    for _, tensors in dq.calls:
-                        for t in tensors:
-                            t.record_stream(ws)
+                # (the caching allocator must know both streams touch these, inside a capture as well: see
+                # TransformerDecoderModel._relation_head_forked)
+                for j in dq.jobs + dq.conv_jobs:
+                    for t in (j[0], j[1], j[3]):
+                        t.record_stream(ws)
+                for part, out in dq.items:
+                    part.record_stream(ws)
+                    out.record_stream(ws)
                 with torch.cuda.stream(ws):
                     dq.flush()
                 self._mid_stream = ws

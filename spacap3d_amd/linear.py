@@ -282,6 +282,9 @@ class Conv1x1(Function):
 # discrete selections it cannot control (tests/test_engine_gpu.py) and a re-association passes it.  False restores the library
 # calls (A/B measurements).
 USE_OWN_CONV = True
+# tests: the forward on the fp32-MFMA kernel (exact fp32 products) instead of the split-bf16 one -- for comparisons of two paths
+# whose discrete selections (ReLU gates, pooling arg-max) must not see a 1e-6 difference in a pre-activation
+CONV_FWD_EXACT_F32 = False
 
 
 def conv1x1_cm(mode, weight, t, bias, M):
@@ -295,7 +298,8 @@ def conv1x1_cm(mode, weight, t, bias, M):
         return None
     with torch.cuda.device(t.device):
         out = torch.empty((B, M) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
-        check(lib.spacap_conv1x1_cm_f32(mode, weight.data_ptr(), t.data_ptr(), bias.data_ptr() if bias is not None else None,
+        check(lib.spacap_conv1x1_cm_f32(2 if (mode == 0 and CONV_FWD_EXACT_F32) else mode, weight.data_ptr(), t.data_ptr(),
+                                        bias.data_ptr() if bias is not None else None,
                                         B, CI, CO, N, out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream),
               "spacap_conv1x1_cm_f32")
     return out
@@ -612,16 +616,11 @@ class VocabProjection(Function):
                            o_zero=1 if skip else 0)
             dW = torch.empty(V, D, dtype=torch.float32, device=dev)
             db = torch.empty(V, dtype=torch.float32, device=dev) if ctx.has_bias else None
-            def wgrad(stream):
-                check(lib.spacap_dense_wgrad_small_f32(g.data_ptr(), V, n.data_ptr(), D, T if skip else 0, L * D, skip, R, V, D,
-                                                       dW.data_ptr(), db.data_ptr() if db is not None else None, stream),
-                      "spacap_dense_wgrad_small_f32")
-            from . import _native
-            if _native._DEFERRED is not None:
-                # only the optimizer reads dW / db: with the other queued weight gradients, not at the head of the decoder's chain
-                _native._DEFERRED.queue_call(wgrad, [g, n, dW] + ([db] if db is not None else []))
-            else:
-                wgrad(st)
+            # (launched here, not queued with the other optimizer-only work: the incoming gradient is the caption loss's own buffer,
+            # which does not outlive this node -- queued, the kernel read what the decoder's backward had written over it)
+            check(lib.spacap_dense_wgrad_small_f32(g.data_ptr(), V, n.data_ptr(), D, T if skip else 0, L * D, skip, R, V, D,
+                                                   dW.data_ptr(), db.data_ptr() if db is not None else None, st),
+                  "spacap_dense_wgrad_small_f32")
         return dn, dW, db, None
 
 

@@ -552,12 +552,14 @@ class TransformerDecoderModel(nn.Module):
         sa = self.model.encoder.layers[-1].self_attn
         with torch.cuda.stream(rs):
             self._relation_head(ep)
-        if not torch.cuda.is_current_stream_capturing():
-            # (eager steps: the caching allocator must know both streams touch these)
-            for t in (sa.attn, sa.value):
-                if torch.is_tensor(t):
-                    t.record_stream(rs)
-            ep["relation_pred"].record_stream(cur)
+        # The caching allocator must know that both streams touch these -- INSIDE a capture as well: a block freed on the stream it
+        # was allocated on is handed to the next allocation of that stream at once (the graph's private pool included), while the
+        # other stream's kernel may still be reading it (seen: NaN losses at 2 scenes per GPU, the relation head's backward reading
+        # an attention map whose memory the encoder's backward had already been given).  A recorded block is held back instead.
+        for t in (sa.attn, sa.value):
+            if torch.is_tensor(t):
+                t.record_stream(rs)
+        ep["relation_pred"].record_stream(cur)
         ep["_rel_stream"] = rs    # loss_helper.get_scene_cap_loss joins the streams before it reads relation_pred
 
     def _relation_head(self, ep):

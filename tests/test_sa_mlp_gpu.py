@@ -107,9 +107,14 @@ def test_fused_sa_mlp_matches_float64_reference(name, Np, N, Sn, Cf, mlp, radius
         assert int(l.bn.bn.num_batches_tracked) == 1
 
 
-def test_fused_and_per_operator_paths_agree_including_running_stats():
-    """Same module, same inputs, fused op switched off for the second run."""
+def test_fused_and_per_operator_paths_agree_including_running_stats(monkeypatch):
+    """Same module, same inputs, fused op switched off for the second run.  (The per-operator path's 1x1 convolutions on the
+    exact-fp32 kernel: the split-bf16 one differs from the fused op's split-bf16 layer kernels by ~1e-6 in a pre-activation, which
+    flips a handful of pooling arg-max / ReLU decisions among the padded groups of this input and with them whole gradient routes
+    -- 174 of 262 144 feature-gradient entries; both are within 1e-6 of float64, see the float64 gates above.)"""
+    from spacap3d_amd import linear
     from spacap3d_amd.pointnet2_modules import PointnetSAModuleVotes
+    monkeypatch.setattr(linear, "CONV_FWD_EXACT_F32", True)
     torch.manual_seed(3)
     sa = PointnetSAModuleVotes(npoint=128, radius=0.8, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
                                normalize_xyz=True).to(DEV).train()
