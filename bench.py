@@ -285,6 +285,28 @@ def quick_config(name, rank, dev, steps=5, warmup=5):
     return rec
 
 
+def quick_config_in_child(name, timeout=900):
+    """`quick_config(name)` in a FRESH process (this file with --quick-config): the record of a configuration as a user training it
+    gets it -- one Trainer per process.  Inside the process that has already trained cfg2 the same step replays 2 - 3 ms slower for
+    ONE of the following configurations (which one depends on what ran before: cfg4 after the in-step timers, cfg3 without them;
+    tools/lab/quick_config_steps.py): the runtime places the internal streams of a new graph on the hardware queues that earlier
+    graphs of the process left least used, and the step's forked branches then share a queue with the sampling chain
+    (DESIGN.md section 5).  The parent is idle while the child runs."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--quick-config", name]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout,
+                             env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    except subprocess.TimeoutExpired:
+        raise SystemExit(f"bench.py: sub-record {name} did not finish within {timeout} s")
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        raise SystemExit(f"bench.py: sub-record {name} failed (exit code {out.returncode}):\n" + "\n".join(out.stderr.splitlines()[-15:]))
+    rec = json.loads(lines[-1])
+    rec["process"] = "fresh child process (one Trainer per process)"
+    return rec
+
+
 def eval_record(model, data, iters=5):
     """Inference forward: detector + encoder once + greedy decoding of B*K captions for 31 steps
     (models/transformer_captioner.py:402-453), no gradients; model.eval().  Two figures: a stream of batches through
@@ -371,7 +393,8 @@ def window_table_top():
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_timed_window_kernels.csv")))
-    files = [f for f in files if os.path.getsize(f) > 0]
+    # the headline workload's tables only (rNN_cfg3_... / rNN_eval_... are the other configurations' evidence)
+    files = [f for f in files if os.path.getsize(f) > 0 and "_cfg" not in os.path.basename(f) and "_eval" not in os.path.basename(f)]
     if not files:
         raise SystemExit("bench.py: no non-empty profiles/r*_timed_window_kernels.csv (run tools/prof_step.sh and commit its table)")
     path = files[-1]
@@ -423,8 +446,16 @@ def main():
     ap.add_argument("--no-drop-in", action="store_true", help="skip the extra unpipelined (drop-in caller) measurement")
     ap.add_argument("--no-in-step", action="store_true", help="skip the eager steps that time the roofline kernel inside a step "
                                                               "(for rocprofv3 runs: tools/prof_window.py takes the LAST steps of the trace)")
+    ap.add_argument("--quick-config", default=None, choices=sorted(CFG), help="internal: print quick_config(NAME) as one JSON line "
+                    "and exit (how the default line's cfg3 / cfg4 / cfg5 sub-records are produced, each in its own process)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short cfg3 / cfg4 / cfg5 sub-records and the eval record")
     args = ap.parse_args()
+    if args.quick_config:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        torch.cuda.set_device(0)
+        print(json.dumps(quick_config(args.quick_config, 0, torch.device("cuda", 0))), flush=True)
+        return
 
     # (read and validated on EVERY rank before any rank joins the process group: a bad table ends all ranks at once instead
     # of leaving the others in their next collective)
@@ -686,7 +717,7 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
-            line["configs"] = {name: quick_config(name, rank, dev) for name in ("cfg3", "cfg4", "cfg5")}
+            line["configs"] = {name: quick_config_in_child(name) for name in ("cfg3", "cfg4", "cfg5")}
         if args.ablate:
             line["metric"] += f" [ABLATION {args.ablate}: not the headline metric]"
         if world == 1 and not args.no_cpu_baseline:

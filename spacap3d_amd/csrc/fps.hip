@@ -325,10 +325,11 @@ void launch_fps(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hip
 
 template <int BLOCK, int TPL>
 hipError_t launch_fps_small(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hipStream_t s) {
-  const int lds = N * 16;
+  static const int pad256 = [] { const char *e = getenv("SPACAP_LAB_FPSS_PAD"); return e ? atoi(e) : 0; }();
+  const int lds = (m <= 256 && pad256 > N * 16) ? pad256 : N * 16;
   static unsigned long long lds_ok = 0;
   if (lds > 48 * 1024) {
-    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 128 * 1024, lds_ok);
+    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 160 * 1024, lds_ok);
     if (e != hipSuccess) return e;
   }
   // (giving these workgroups a CU of their own, as the bucketed kernel does, measured slower beside the step: 7.29 vs 7.22 ms)

@@ -26,7 +26,11 @@ def _role_stream(device, role):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     if key not in _STREAMS:
         dev = torch.device("cuda", key[1])
-        _STREAMS[key] = {r: torch.cuda.Stream(device=dev) for r in ("side", "capture", "comm", "wgrad", "relation")}
+        # (lab switch: a high-priority side stream changes nothing in the usual placement and makes the bad one worse,
+        # tools/lab/quick_config_steps.py)
+        prio = int(os.environ.get("SPACAP_SIDE_PRIORITY", "0"))
+        _STREAMS[key] = {r: torch.cuda.Stream(device=dev, priority=prio if r == "side" else 0)
+                         for r in ("side", "capture", "comm", "wgrad", "relation")}
     return _STREAMS[key][role]
 
 

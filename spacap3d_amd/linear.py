@@ -262,6 +262,9 @@ class Conv1x1(Function):
                 dx = torch.ops.aten.convolution_backward(g, x, weight, None, [1] * (x.dim() - 2), [0] * (x.dim() - 2),
                                                          [1] * (x.dim() - 2), False, [0] * (x.dim() - 2), 1,
                                                          [True, False, False])[0]
+        if not ctx.needs_input_grad[1]:    # frozen weights: the data gradient alone
+            db = g.sum(dim=[0] + list(range(2, g.dim()))) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            return dx, None, db
         if int(lib.spacap_conv1x1_wgrad_slabs(B, CO, CI, N)):
             part = conv1x1_wgrad_partials(g, x, B, CO, CI, N, deferrable=True, with_bias=ctx.has_bias)
             s = sum_slabs(part, deferrable=True)

@@ -299,6 +299,31 @@ def test_conv1x1_weight_gradient(B, CO, CI, N, dims):
         assert (y0 is not None) == (N % 64 == 0)
 
 
+def test_conv1x1_with_frozen_weights_still_passes_the_input_gradient():
+    """A frozen 1x1 convolution behind a trainable layer (fine-tuning with the detector's nets fixed): the output keeps its
+    grad_fn, the input gradient is the float64 one and the frozen parameters receive none."""
+    from spacap3d_amd.linear import conv1x1
+    g = torch.Generator().manual_seed(77)
+    B, CI, CO, N = 4, 128, 256, 256
+    conv = torch.nn.Conv1d(CI, CO, 1)
+    x, w = torch.randn(B, CI, N, generator=g), torch.randn(B, CO, N, generator=g)
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.Conv1d(CI, CO, 1).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    (ref(xr) * w.double()).sum().backward()
+    conv = conv.to(DEV).requires_grad_(False)
+    xg = x.to(DEV).requires_grad_(True)
+    y = conv1x1(xg, conv)
+    assert y is not None and y.grad_fn is not None
+    (y * w.to(DEV)).sum().backward()
+    err = float((xg.grad.double().cpu() - xr.grad).abs().max()) / float(xr.grad.abs().max())
+    assert err < 2e-5, err
+    assert conv.weight.grad is None and conv.bias.grad is None
+    # nothing on the call needs a gradient: the forward kernel alone, same values
+    y0 = conv1x1(x.to(DEV), conv)
+    assert y0 is not None and y0.grad_fn is None and torch.equal(y0, y.detach())
+
+
 @pytest.mark.parametrize("B,CO,CI,N", [(8, 259, 256, 1024), (8, 97, 128, 256), (4, 128, 3, 256), (2, 256, 256, 512)])
 def test_conv1x1_gradients_inside_the_deferred_batch(B, CO, CI, N):
     """Inside ``deferred_slab_sums`` (a Trainer's backward) the weight gradient is queued for the step's one batched launch

@@ -285,6 +285,54 @@ def fps(B, N, m, dev):
                 what="furthest point sampling, one workgroup per scene, m-1 sequentially dependent rounds")
 
 
+def sa_dgrad_wgrad_l1in(B, N, S, dev, label):
+    """SA1 layer 2 backward as the step runs it since round 6: data gradient + BN sums + the first layer's three sums + the
+    layer's own weight gradient from ONE read of dy2 / z2 (csrc/sa_mlp.hip, sa_dgrad_kernel<.., L1, WG>)."""
+    R = B * N * S
+    dy, zk, rel4 = _rand(R, 64, dev=dev), _rand(R, 64, dev=dev), _rand(R, 4, dev=dev)
+    coef, stp, W2, W1 = _stats(64, dev), _stats(64, dev), _rand(64, 64, dev=dev) * 0.1, _rand(64, 4, dev=dev)
+    nparts = int(lib.spacap_sa_nparts())
+    part, pl1 = _part(64, dev), torch.empty(nparts, 64 * 8 + 4, dtype=torch.float32, device=dev)
+    pw = torch.empty(int(lib.spacap_sa_dgrad_wgrad_l1in_slabs(R)), 64, 64, dtype=torch.float32, device=dev)
+
+    def run():
+        check(lib.spacap_sa_dgrad_wgrad_l1in_f32(dy.data_ptr(), zk.data_ptr(), coef.data_ptr(), W2.data_ptr(), rel4.data_ptr(),
+                                                 W1.data_ptr(), 4, 1, stp.data_ptr(), B, N, S, part.data_ptr(), pl1.data_ptr(),
+                                                 pw.data_ptr(), _st(dev)), "sa_dgrad_wgrad_l1in")
+    return dict(name=f"sa_dgrad+wgrad 64->64 R={R} ({label}, z1 rebuilt)", kernel="sa_dgrad", run=run, bf16_products=0,
+                flops=2.0 * 2 * 64 * 64 * R, bytes=4.0 * R * (64 + 64 + 4), keep=(dy, zk, rel4, coef, stp, W2, W1, part, pl1, pw),
+                what=f"{label}: dy1 = (dz2 W2) relu'(bn(z1)) reduced to the first layer's three sums, and dW2 = dz2^T a1, {R} rows; "
+                     "reads dy2, z2 and 16 B of inputs per row, writes partials only")
+
+
+def linear_wgrad(R, ck, cp, dev, label):
+    """torch.nn.Linear weight + bias gradient (csrc/wgrad_bf3.inc): split-bf16 products from transposing LDS reads."""
+    g, x = _rand(R, ck, dev=dev), _rand(R, cp, dev=dev)
+    ns = int(lib.spacap_linear_wgrad_slabs(R, ck, cp))
+    part = torch.empty(ns, ck * cp + ck, dtype=torch.float32, device=dev)
+
+    def run():
+        check(lib.spacap_linear_wgrad_f32(g.data_ptr(), x.data_ptr(), R, ck, cp, 1, part.data_ptr(), _st(dev)), "linear_wgrad")
+    import os
+    split = os.environ.get("SPACAP_SA_F32MFMA", "0") in ("", "0")
+    return dict(name=f"linear_wgrad {ck}x{cp} R={R} ({label})", kernel="linear_wgrad", run=run, bf16_products=6 if split else 0,
+                flops=2.0 * ck * cp * R, bytes=4.0 * (R * (ck + cp) + part.numel()), keep=(g, x, part),
+                what=f"{label}: dW = g^T x, db = colsum g per row slab ({ns} slabs), {R} rows")
+
+
+def fps_small(B, N, m, dev, label):
+    from spacap3d_amd import synthetic as S
+    xyz = S.scene_batch(B, N, use_height=False, seed=1001).to(dev)[..., :3].contiguous()
+    ws = torch.empty(max(int(lib.spacap_fps_workspace_bytes(B, N)), 16), dtype=torch.uint8, device=dev)
+    idx = torch.empty(B, m, dtype=torch.int32, device=dev)
+
+    def run():
+        check(lib.spacap_fps_f32(xyz.data_ptr(), B, N, m, ws.data_ptr(), idx.data_ptr(), _st(dev)), "fps")
+    return dict(name=f"fps B={B} {N}->{m} ({label})", kernel="fps_small_kernel", run=run, flops=10.0 * B * (m - 1) * N,
+                bytes=20.0 * B * (m - 1) * N, compulsory_bytes=float(B * (12 * N + 4 * m)), rounds=m - 1, keep=(xyz, ws, idx),
+                what="furthest point sampling of a sampled level: coordinates resident in LDS, one barrier per round")
+
+
 def cases(dev, B=8):
     """name -> case dict, cfg2 shapes with B scenes."""
     R1, R2, R3, R4, RA = B * 2048 * 64, B * 1024 * 32, B * 512 * 16, B * 256 * 16, B * 256 * 16
@@ -312,6 +360,9 @@ def cases(dev, B=8):
         lambda: tf_ffn(B * 256, 2048, 1, dev),
         lambda: tf_rows(B * 256, 2048, dev),
         lambda: fps(B, 40000, 2048, dev),
+        lambda: sa_dgrad_wgrad_l1in(B, 2048, 64, dev, "SA1 layer 2"),
+        lambda: linear_wgrad(B * 256, 2048, 128, dev, "FFN first linear"),
+        lambda: fps_small(B, 2048, 1024, dev, "SA2 sampling"),
     ]
 
 
