@@ -329,7 +329,7 @@ hipError_t launch_fps_small(const float *xyz, int B, int N, int m, int lg, int32
   const int lds = (m <= 256 && pad256 > N * 16) ? pad256 : N * 16;
   static unsigned long long lds_ok = 0;
   if (lds > 48 * 1024) {
-    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 160 * 1024, lds_ok);
+    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 144 * 1024, lds_ok);
     if (e != hipSuccess) return e;
   }
   // (giving these workgroups a CU of their own, as the bucketed kernel does, measured slower beside the step: 7.29 vs 7.22 ms)

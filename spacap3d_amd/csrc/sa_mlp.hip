@@ -80,7 +80,7 @@ __device__ __forceinline__ void l1_weights(const L1In &li, int c0, f32x4 &wx, f3
   }
 }
 
-template <int C1>
+template <int C1, int UR = 4>
 __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict__ Y, const float *__restrict__ feat,
                                                         const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                         const int32_t *__restrict__ idx, const float *__restrict__ W1,
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
   f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
   const long NS = (long)N * S;
   // The row's inputs hang off a dependent chain (idx -> point -> coordinates): four rows per iteration keep four chains in
-  // flight (one row at a time the kernel sat at the chain's latency, 119 us for SA1 against an HBM time of 55 us).  The
+  // flight (one row at a time the kernel sat at the chain's latency, 119 us for SA1 against an HBM time of 55 us; 8 or 16 rows
+  // measured slower at every SA shape: 45.7 -> 65.6 us at SA2, tools/lab/l1_fwd_time.py).  The
   // statistics are accumulated in the same row order as before.
   const long G = (long)gridDim.x * RP;
   long r = (long)blockIdx.x * RP + rs;
@@ -117,7 +118,6 @@ __global__ __launch_bounds__(256) void sa_l1_fwd_kernel(const float *__restrict_
     if (Y) z += ld4(Y + ((size_t)b * Np + p) * C1 + c4 * 4);
     return z;
   };
-  constexpr int UR = 4;
   for (; r + (UR - 1) * G < R; r += UR * G) {
     int p[UR];
     long b[UR];
@@ -1271,8 +1271,17 @@ __global__ __launch_bounds__(256) void sa_dw1_assemble_kernel(const float *__res
     const float *src = j < 3 ? pw1 + (size_t)ch * 4 + j : pf + (size_t)ch * Cf + (j - 3);
     const size_t stride = j < 3 ? (size_t)C1 * 4 : (size_t)C1 * Cf;
     const int ns = j < 3 ? n1 : nf, per = (ns + 3) / 4, s0 = grp * per, s1 = min(ns, s0 + per);
+    // (a dependent chain of strided loads: 32 in flight per thread, added in slab order -- 2 round trips instead of 8 at 256 slabs)
+    int k = s0;
+    for (; k + 32 <= s1; k += 32) {
+      float t[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) t[u] = src[(size_t)(k + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) a += t[u];
+    }
 #pragma unroll 8
-    for (int k = s0; k < s1; ++k) a += src[(size_t)k * stride];
+    for (; k < s1; ++k) a += src[(size_t)k * stride];
   }
   s_g[grp][c] = a;
   __syncthreads();

@@ -13,6 +13,7 @@ Restated so that one training step needs NO host synchronisation:
 """
 import math
 
+import os
 import torch
 import torch.nn.functional as F
 
@@ -24,6 +25,9 @@ OBJECTNESS_CLS_WEIGHTS = [0.2, 0.8]
 
 _CONST = {}
 
+
+# lab switch (same-box A/B): the fused relation loss on the relation head's stream when the head was forked
+REL_LOSS_ON_ITS_STREAM = os.environ.get("SPACAP_REL_LOSS_FORKED", "1") != "0"
 
 def _const(key, device, build):
     """Device-resident constants are built once per device (a host -> device copy is not allowed while a
@@ -203,7 +207,8 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
     dev = d["seed_xyz"].device
     zero = _const("zero", dev, lambda: torch.zeros(()))
 
-    if "_detection_losses" not in d:
+    det_early = "_detection_losses" in d    # computed right after the proposal module (engine.Trainer.loss): before the captioner
+    if not det_early:
         start_detection_losses(d, num_heading_bin, num_size_cluster, mean_size_arr)
     (vote_loss, objectness_loss, objectness_label, objectness_mask, object_assignment, center_loss, heading_cls_loss,
      heading_reg_loss, size_cls_loss, size_reg_loss, sem_cls_loss, box_loss) = d.pop("_detection_losses")
@@ -236,17 +241,32 @@ def get_scene_cap_loss(data_dict, device=None, config=None, detection=True, capt
         d["obj_acc"] = torch.sum((d["bbox_mask"] == objectness_label).float() * objectness_mask) / (
             torch.sum(objectness_mask) + 1e-6)
 
-    rel_stream = d.pop("_rel_stream", None)
-    if rel_stream is not None:     # (the relation head ran on a stream of its own: TransformerDecoderModel.fork_relation)
-        torch.cuda.current_stream(d["relation_pred"].device).wait_stream(rel_stream)
+    rel_stream = d.pop("_rel_stream", None)   # (the relation head ran on a stream of its own: TransformerDecoderModel.fork_relation)
+    cur_stream = torch.cuda.current_stream(d["relation_pred"].device) if rel_stream is not None else None
     if use_relation:
         from .backend import ops
         frel = getattr(ops(), "relation_losses", None) if d["relation_pred"].is_cuda else None
-        rel = frel(d) if frel is not None else compute_relation_loss(d)
+        if rel_stream is not None and frel is not None and det_early and REL_LOSS_ON_ITS_STREAM:
+            # The relation loss stays on the head's stream: its forward (0.03 ms) then runs beside the decoder instead of after it,
+            # and its backward is followed by the head's backward kernel on the same stream without a cross-stream wait.  Everything
+            # it reads besides relation_pred (labels, the detection losses' object assignment) exists since before the fork.
+            for k in ("object_assignment", "box_label_mask_int", "objectness_label", "x_label", "y_label", "z_label"):
+                if torch.is_tensor(d.get(k)) and d[k].is_cuda:
+                    d[k].record_stream(rel_stream)
+            with torch.cuda.stream(rel_stream):
+                rel = frel(d)
+            cur_stream.wait_stream(rel_stream)
+            d["_rel_vec"].record_stream(cur_stream)
+        else:
+            if rel_stream is not None:
+                cur_stream.wait_stream(rel_stream)
+            rel = frel(d) if frel is not None else compute_relation_loss(d)
         d.update(rel)
         if not fast:
             d["relation_loss"] = rel["y_loss"] + rel["z_loss"] + rel["x_loss"]
     else:
+        if rel_stream is not None:
+            cur_stream.wait_stream(rel_stream)
         for k in ("x_loss", "y_loss", "z_loss", "relation_loss", "x_acc", "y_acc", "z_acc"):
             d[k] = zero
 

@@ -5,7 +5,7 @@ import torch
 from spacap3d_amd._native import check, lib
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-for (B, Np, N, S, C1, feat_on, Cf) in ((8, 40000, 2048, 64, 64, True, 0), (8, 2048, 1024, 32, 128, False, 128)):
+for (B, Np, N, S, C1, feat_on, Cf) in ((8, 40000, 2048, 64, 64, True, 0), (8, 2048, 1024, 32, 128, False, 128), (8, 1024, 512, 16, 128, False, 256), (8, 512, 256, 16, 128, False, 256), (8, 1024, 256, 16, 128, False, 256)):
     xyz = torch.rand(B, Np, 3, device=dev); new_xyz = xyz[:, :N].contiguous()
     idx = torch.randint(0, Np, (B, N, S), dtype=torch.int32, device=dev)
     feat = torch.randn(B, Np, device=dev) if feat_on else None

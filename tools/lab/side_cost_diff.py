@@ -12,13 +12,14 @@ top = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 nk = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[nk], r.get("Queue_Id", "0")) for r in rows)
 marks = [i for i, e in enumerate(ev) if "adam_flat_kernel" in e[2]]
-main_q = ev[marks[-1]][3]
+# the side stream is the queue that carries the sampling chain; every other queue belongs to the step (its forked branches included)
+side_qs = {e[3] for e in ev[marks[len(marks) // 2]:] if "fps_bucket_kernel" in e[2] or "delay_kernel" in e[2]}
 steps = []
 for a, b in zip(marks[:-1], marks[1:]):
     t0, t1 = ev[a][1], ev[b][1]
-    ks = [e for e in ev[a + 1:b + 1]] + [e for e in ev[max(0, a - 3):a + 1] if e[3] != main_q and e[1] > ev[a][1]]
-    main = [e for e in ks if e[3] == main_q]
-    side = [e for e in ks if e[3] != main_q]
+    ks = [e for e in ev[a + 1:b + 1]] + [e for e in ev[max(0, a - 3):a + 1] if e[3] in side_qs and e[1] > ev[a][1]]
+    main = [e for e in ks if e[3] not in side_qs]
+    side = [e for e in ks if e[3] in side_qs]
     has_fps = any(MARK in e[2] for e in side)
     steps.append((has_fps, main, side, t1 - t0))
 # keep graph-replayed steps only: the modal main-stream kernel count
