@@ -2431,10 +2431,12 @@ extern "C" int spacap_conv1x1_wgrad_slabs(int B, int CO, int CI, int N) {
   return B * conv1x1_nsplit(B, CO, CI, N);
 }
 
-// slabs per job inside a batch (the batch fills the chip: ~8 point tiles per workgroup)
+// slabs per job inside a batch (the batch fills the chip: ~16 point tiles per workgroup)
 extern "C" int spacap_conv1x1_wgrad_slabs_batched(int B, int CO, int CI, int N) {
   if (spacap_conv1x1_wgrad_slabs(B, CO, CI, N) == 0) return 0;
-  int nsplit = N / 256;
+  // (512 points per workgroup: half the partial-sum traffic of 256 -- 65 instead of 130 MB per step at cfg2 -- and still ~1 000
+  // workgroups in the step's batch; 6.60 -> 6.57 ms same box, 1 024 points gives it back)
+  int nsplit = N / 512;
   if (nsplit < 1) nsplit = 1;
   const int single = conv1x1_nsplit(B, CO, CI, N);
   return B * (nsplit < single ? nsplit : single);

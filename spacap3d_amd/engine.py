@@ -182,11 +182,12 @@ class Trainer:
                      if torch.is_tensor(t) and t.requires_grad]
             for t in marks:
                 t.register_hook(self._boundary_hook if self._overlap_armed else self._mid_flush_hook)
-            # ... and a second time when the backward enters SA4: by then the vote / proposal / feature-propagation nets have
-            # queued their 1x1-convolution weight gradients (one batched launch of 0.07 ms), SA4 - SA2's backward runs beside it
-            t4 = d.get("sa4_features")
-            if self._flush_mid and torch.is_tensor(t4) and t4.requires_grad:
-                t4.register_hook(self._mid_flush_hook2)
+            # (A second flush when the backward enters SA4 -- the vote / proposal / feature-propagation nets' convolution weight
+            # gradients beside SA4 - SA2's backward -- was registered on the typed channel-major VIEW of sa4_features for most of
+            # round 6 and never fired: the consumers take the point-major tensor behind it.  Registered on that tensor it fires and
+            # costs 0.75 ms beside the sampling chain (7.13 -> 7.85 ms same box; without the chain 6.76 = 6.76): the SA modules'
+            # persistent backward kernels are sized for the CUs the chain leaves, a third party on the chip sends their last
+            # workgroups into a second round.  Not registered.)
         return d
 
     # -- the captioner's weight gradients beside the detector's backward --------------------------------------------------
@@ -194,9 +195,6 @@ class Trainer:
     # 0.12 ms + its slab sums) is queued and nothing but the optimizer will read it.  What follows on the step's stream -- the
     # backward of the proposal / vote / feature-propagation nets and of SA4 / SA3 -- is ~0.5 ms of short launches that leave most
     # of the chip idle: the queue is flushed THERE, on a stream of its own, instead of after the whole backward.
-    def _mid_flush_hook2(self, grad):
-        return self._mid_flush_hook(grad, stage=2)
-
     def _mid_flush_hook(self, grad, stage=1):
         # _mid_done: 0 nothing flushed yet, 1 the captioner boundary has flushed, 2 the SA4 boundary has flushed
         if self._flush_mid and self._mid_done < stage:

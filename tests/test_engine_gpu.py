@@ -691,17 +691,19 @@ def test_no_library_gemm_or_convolution_kernel_inside_a_training_step(cfg):
     for _ in range(2):
         tr.step(data, next_data=data)
     torch.cuda.synchronize()
+    expect = ["conv1x1_cm_kernel", "dense_rows_kernel"] + (["dense_wgrad_tall_kernel"] if cfg in ("cfg3", "cfg4") else []) \
+        + (["gemm_bf3_kernel", "linear_wgrad_bf3_kernel", "rel_wide_l1_bwd_kernel"] if cfg == "cfg5" else [])
     names = set()
-    for attempt in range(3):    # (the tracer occasionally returns a truncated event list for a step: the library check applies to
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:   # every profiled step, the presence checks to their union)
-            tr.step(data, next_data=data)
+    for attempt in range(4):    # (the tracer occasionally returns an incomplete event list for a step -- seen: a forked branch's
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:   # kernels missing: the library check applies to every profiled
+            tr.step(data, next_data=data)                           # step, the presence checks to their union)
             torch.cuda.synchronize()
         got = [e.key for e in prof.key_averages() if e.device_type is not None and "cuda" in str(e.device_type).lower()]
         bad = [n for n in got if n.startswith("Cijk_") or "naive_conv" in n or "miopen" in n.lower() or "hipblaslt" in n.lower()
                or "rocblas" in n.lower()]
         assert not bad, bad
         names |= set(got)
-        if len(got) > 80:
+        if len(names) > 80 and all(any(e in n for n in names) for e in expect):
             break
     assert len(names) > 80, len(names)      # the profiler saw the step's kernels (distinct names: ~95 of ~320 launches)
     assert any("conv1x1_cm_kernel" in n for n in names) and any("dense_rows_kernel" in n for n in names)
