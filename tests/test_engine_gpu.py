@@ -1,6 +1,7 @@
 """Training engine on the GPU: the hipGraph replay path and the side-stream sampling prefetch must compute what
 the plain eager step computes (same losses step by step), and two eager runs must agree (no races)."""
 import copy
+import os
 
 import pytest
 import torch
@@ -694,7 +695,7 @@ def test_no_library_gemm_or_convolution_kernel_inside_a_training_step(cfg):
     expect = ["conv1x1_cm_kernel", "dense_rows_kernel"] + (["dense_wgrad_tall_kernel"] if cfg in ("cfg3", "cfg4") else []) \
         + (["gemm_bf3_kernel", "linear_wgrad_bf3_kernel", "rel_wide_l1_bwd_kernel"] if cfg == "cfg5" else [])
     names = set()
-    for attempt in range(4):    # (the tracer occasionally returns an incomplete event list for a step -- seen: a forked branch's
+    for attempt in range(10):   # (the tracer often returns an incomplete event list for a step -- seen: a forked branch's
         with profile(activities=[ProfilerActivity.CUDA]) as prof:   # kernels missing: the library check applies to every profiled
             tr.step(data, next_data=data)                           # step, the presence checks to their union)
             torch.cuda.synchronize()
@@ -712,4 +713,6 @@ def test_no_library_gemm_or_convolution_kernel_inside_a_training_step(cfg):
     if cfg == "cfg5":   # the 512-wide relation head and Linear layers: tiled split-bf16 products (csrc/gemm_bf3.hip)
         # (the wide head's weight gradient: the Linear layers' split-bf16 kernel since round 6, csrc/wgrad_bf3.inc)
         assert any("gemm_bf3_kernel" in n for n in names) and any("linear_wgrad_bf3_kernel" in n for n in names)
-        assert any("rel_wide_l1_bwd_kernel" in n for n in names)
+        if not any("rel_wide_l1_bwd_kernel" in n for n in names) and os.environ.get("SPACAP_TEST_DUMP"):
+            open(os.environ["SPACAP_TEST_DUMP"], "w").write("\n".join(sorted(names)))
+        assert any("rel_wide_l1_bwd_kernel" in n for n in names), sorted(n[:60] for n in names if "rel_" in n or "gemm_bf3" in n)
