@@ -182,7 +182,8 @@ __global__ __launch_bounds__(64) void fps_wave_kernel(const float *__restrict__ 
 //     no LDS atomic and no second barrier; the pairs meet in an LDS record double-buffered by round parity, and every wave
 //     reduces the NW records itself (two DPP reductions).
 // Same selection rule as fps_kernel: first maximum in the reference's tree order through fps_key; M < 0 (every point
-// skipped) gives index 0.  Rounds: 0.75 -> ~0.35 us at N = 2 048, 0.62 -> ~0.3 us at N = 1 024 (tools/lab/fps_small_bench.py).
+// skipped) gives index 0.  Rounds: 0.75 -> 0.57 us at N = 2 048, 0.62 -> 0.50 us at N = 1 024, 0.39 at 512, 0.32 at 256: a
+// single wave costs 0.28 us + 17 ns per point slot and round (tools/lab/fps_small_bench.py).
 template <int BLOCK, int TPL>
 __global__ __launch_bounds__(BLOCK) void fps_small_kernel(const float *__restrict__ xyz_all, int N, int m, int lg,
                                                           int32_t *__restrict__ idx_all) {
@@ -325,14 +326,14 @@ void launch_fps(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hip
 
 template <int BLOCK, int TPL>
 hipError_t launch_fps_small(const float *xyz, int B, int N, int m, int lg, int32_t *idx, hipStream_t s) {
-  static const int pad256 = [] { const char *e = getenv("SPACAP_LAB_FPSS_PAD"); return e ? atoi(e) : 0; }();
-  const int lds = (m <= 256 && pad256 > N * 16) ? pad256 : N * 16;
+  const int lds = N * 16;
   static unsigned long long lds_ok = 0;
   if (lds > 48 * 1024) {
-    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 144 * 1024, lds_ok);
+    const hipError_t e = spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&fps_small_kernel<BLOCK, TPL>), 128 * 1024, lds_ok);
     if (e != hipSuccess) return e;
   }
-  // (giving these workgroups a CU of their own, as the bucketed kernel does, measured slower beside the step: 7.29 vs 7.22 ms)
+  // (giving these workgroups a CU of their own by asking for the CU's whole LDS: slower for the side chain's levels beside the
+  // step, 7.29 vs 7.22 ms; no effect for the vote-aggregation sampling on the step's own stream, nor for the bucketed kernel)
   hipLaunchKernelGGL((fps_small_kernel<BLOCK, TPL>), dim3(B), dim3(BLOCK), lds, s, xyz, N, m, lg, idx);
   return hipSuccess;
 }
