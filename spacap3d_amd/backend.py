@@ -31,6 +31,7 @@ class HipBackend:
         self.relation_layer1 = _att.relation_layer1
         from . import fused_bn as _fbn
         self.bn_relu_train = _fbn.bn_relu_train
+        self.bn_relu_eval = _fbn.bn_relu_eval
         from . import fused_losses as _fl
         self.detection_losses = _fl.detection_losses
         self.relation_losses = _fl.relation_losses

@@ -192,7 +192,11 @@ def _bn_relu(bn, x, training):
     """relu(bn(x)); in training mode one fused op of the backend (batch statistics, csrc/bn_relu.hip) when it has one."""
     from .backend import ops
     f = getattr(ops(), "bn_relu_train", None) if (training and x.is_cuda) else None
-    return f(x.contiguous(), bn) if f is not None else F.relu(bn(x))
+    if f is not None:
+        return f(x.contiguous(), bn)
+    g = getattr(ops(), "bn_relu_eval", None) if (x.is_cuda and not training) else None   # inference: one launch on the running statistics
+    y = g(x, bn) if g is not None else None
+    return F.relu(bn(x)) if y is None else y
 
 
 def _conv(conv, x, training):

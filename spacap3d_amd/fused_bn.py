@@ -110,3 +110,37 @@ def bn_relu_train(z, bn, pool_S=None):
     momentum = 0.0 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return BNReLU.apply(z, bn.weight, bn.bias, rm, rv, momentum, bn.eps, pool_S)
+
+
+# ---- inference: relu(batch_norm(z)) on the running statistics, one launch of the library's apply kernel ------------------------
+# (the stock modules run MIOpen's BatchNorm inference kernel + a ReLU: two launches per layer and the last library kernel of the
+# inference forward).  The kernel takes (mean, 1 / sqrt(var + eps)) per channel: folded once per state of the module's buffers
+# (tensor version counters: a training step's in-place update of the running statistics, load_state_dict or .to() make a new fold).
+_EVAL_FOLD = {}
+
+
+def bn_relu_eval(z, bn):
+    """relu(bn(z)) for a BatchNorm module in eval mode (running statistics) on a float32 CUDA tensor z (B,C,...), without gradient
+    recording; ``None`` when that does not apply (the caller then calls the modules)."""
+    if not (z.is_cuda and z.dtype == torch.float32 and not torch.is_grad_enabled() and not bn.training and bn.track_running_stats
+            and bn.running_mean is not None and bn.affine and z.dim() >= 2 and z.shape[1] == bn.num_features and z.numel() > 0):
+        return None
+    rm, rv = bn.running_mean, bn.running_var
+    key = (rm.data_ptr(), rv.data_ptr(), rm._version, rv._version, float(bn.eps), str(z.device))
+    ent = _EVAL_FOLD.get(id(bn))
+    if ent is None or ent[0] != key:
+        with torch.cuda.device(z.device):
+            stats = torch.stack([rm.float(), torch.rsqrt(rv.float() + bn.eps)], 1).contiguous()
+        ent = _EVAL_FOLD[id(bn)] = (key, stats)
+        if len(_EVAL_FOLD) > 4096:    # (modules come and go in long-lived processes: ids are reused, entries are tiny)
+            _EVAL_FOLD.clear()
+            _EVAL_FOLD[id(bn)] = ent
+    stats = ent[1]
+    z = z.contiguous()
+    B, C = z.shape[0], z.shape[1]
+    L = z.numel() // (B * C)
+    with torch.cuda.device(z.device):
+        out = torch.empty_like(z)
+        check(lib.spacap_bn_relu_apply_f32(z.data_ptr(), stats.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), B, C, L,
+                                           out.data_ptr(), torch.cuda.current_stream(z.device).cuda_stream), "spacap_bn_relu_apply_f32")
+    return out

@@ -56,7 +56,10 @@ class _ConvBNReLU2d(nn.Sequential):
             if not pool or S in (16, 32, 64, 128):
                 return ops().bn_relu_train(z, self.bn.bn, pool_S=S)
             return pointnet2_utils.group_max(ops().bn_relu_train(z, self.bn.bn))
-        y = self.activation(self.bn(z) if self.has_bn else z)
+        g = getattr(ops(), "bn_relu_eval", None) if (self.has_bn and z.is_cuda and not self.training) else None
+        y = g(z, self.bn.bn) if g is not None else None    # inference: BatchNorm on its running statistics + ReLU, one launch
+        if y is None:
+            y = self.activation(self.bn(z) if self.has_bn else z)
         return pointnet2_utils.group_max(y) if pool else y
 
 

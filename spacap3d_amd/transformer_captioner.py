@@ -267,7 +267,10 @@ class PositionalEncodingLearned(nn.Module):
             def c(m, v):
                 y = conv(v, m)
                 return m(v) if y is None else y
-            t = c(h[3], h[2](h[1](c(h[0], t))))
+            g = getattr(ops(), "bn_relu_eval", None)
+            u = c(h[0], t)
+            v = g(u, h[1]) if g is not None else None
+            t = c(h[3], h[2](h[1](u)) if v is None else v)
         else:
             t = h(t)
         return x + t.transpose(1, 2).contiguous()

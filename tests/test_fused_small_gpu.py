@@ -210,3 +210,32 @@ def test_feature_propagation_input_in_one_launch_each_way(B, m, n, K1, K2, known
     dk = known_arg.grad if not known_pm else a1.grad.transpose(1, 2)
     assert float((dk - kc.grad).abs().max()) <= 1e-5 * float(kc.grad.abs().max())
     assert torch.equal(s1.grad.transpose(1, 2), sc.grad)
+
+
+@pytest.mark.parametrize("shape", [(8, 256, 1024), (8, 128, 256, 1), (3, 128, 96)])
+def test_inference_batchnorm_relu_on_the_running_statistics(shape):
+    """fused_bn.bn_relu_eval: relu(bn(z)) of a BatchNorm module in eval mode as one launch of the library's apply kernel
+    (lib/pointnet2/pytorch_utils.py:11-36 and models/voting_module.py:28-61 under model.eval()), against the stock modules; the
+    folded statistics follow the module's buffers (a training-mode update or load_state_dict invalidates the fold); with gradient
+    recording on, or in training mode, the function declines."""
+    from spacap3d_amd.fused_bn import bn_relu_eval
+    g = torch.Generator().manual_seed(5)
+    C = shape[1]
+    bn = (torch.nn.BatchNorm2d(C) if len(shape) == 4 else torch.nn.BatchNorm1d(C)).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(C, generator=g)), bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.3), bn.running_var.copy_(torch.rand(C, generator=g) + 0.2)
+    z = torch.randn(*shape, generator=g).to(DEV)
+    bn.eval()
+    assert bn_relu_eval(z, bn) is None      # gradient recording on
+    with torch.no_grad():
+        want = torch.relu(bn(z))
+        got = bn_relu_eval(z, bn)
+        assert got is not None and float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+        assert bn_relu_eval(z, bn).equal(got)                 # from the cached fold
+        bn.running_mean.add_(0.5)                             # the buffers move: a new fold
+        want2 = torch.relu(bn(z))
+        got2 = bn_relu_eval(z, bn)
+        assert float((got2 - want2).abs().max()) < 2e-6 * max(1.0, float(want2.abs().max())) and not got2.equal(got)
+        bn.train()
+        assert bn_relu_eval(z, bn) is None
