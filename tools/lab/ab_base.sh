@@ -1,5 +1,8 @@
 #!/bin/bash
-# Same-box A/B of the default bench line: the round's start (worktree _base at be7dfd2) against this tree, alternating.
+# Same-box A/B of the default bench line: the round's start against this tree, alternating.  Needs a worktree of the older
+# commit WITH its own built library under _base/ (not kept in the repository; it travels to the GPU box with the snapshot):
+#   git worktree add _base <commit> && make -C _base/spacap3d_amd/csrc && echo _base/ >> .git/info/exclude
+#   gpurun -- 'bash tools/lab/ab_base.sh';  git worktree remove --force _base
 for i in 1 2 3; do
   for d in _base .; do
     (cd $d && timeout 600 python bench.py --no-configs --no-cpu-baseline --no-drop-in --no-in-step 2>/dev/null | python -c "
