@@ -195,17 +195,16 @@ class Trainer:
     # 0.12 ms + its slab sums) is queued and nothing but the optimizer will read it.  What follows on the step's stream -- the
     # backward of the proposal / vote / feature-propagation nets and of SA4 / SA3 -- is ~0.5 ms of short launches that leave most
     # of the chip idle: the queue is flushed THERE, on a stream of its own, instead of after the whole backward.
-    def _mid_flush_hook(self, grad, stage=1):
-        # _mid_done: 0 nothing flushed yet, 1 the captioner boundary has flushed, 2 the SA4 boundary has flushed
-        if self._flush_mid and self._mid_done < stage:
-            self._mid_done = stage
+    def _mid_flush_hook(self, grad):
+        if self._flush_mid and not self._mid_done:    # (registered on up to three boundary tensors: the first to arrive flushes)
+            self._mid_done = 1
             from . import _native
             dq = _native._DEFERRED
             if dq is not None and grad.is_cuda:
                 dev = grad.device
                 ws = _role_stream(dev, "wgrad")
                 cur = torch.cuda.current_stream(dev)
-                ws.wait_stream(cur)   # (a second flush queues behind the first on the same stream)
+                ws.wait_stream(cur)
                 # (the caching allocator must know both streams touch these, inside a capture as well: see
                 # TransformerDecoderModel._relation_head_forked)
                 for j in dq.jobs + dq.conv_jobs:

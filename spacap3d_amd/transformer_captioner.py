@@ -541,7 +541,6 @@ class TransformerDecoderModel(nn.Module):
     # gradients cross).  Values are those of the serial order: no kernel changes, only placement.  The head's persistent grids
     # leave the decoder's launches room (spacap_relation_fused_leave_cus).
     fork_relation = False
-    _REL_STREAMS = {}
 
     def _relation_head_forked(self, ep):
         src = ep["aggregated_vote_features"]
