@@ -227,8 +227,8 @@ def packed_views(flat, params_w, params_b):
     return flat[ow:ow + rows * cols].view(rows, cols), flat[ob:ob + rows]
 
 
-# wide relation head (d_model = 512): weight gradient by csrc/wgrad_bf3.inc instead of gemm_bf3_wgrad_kernel
-WIDE_WGRAD_TR = os.environ.get("SPACAP_WIDE_WGRAD_TR", "1") != "0"   # wide relation head: weight gradient by csrc/wgrad_bf3.inc
+# wide relation head (d_model = 512): weight gradient by csrc/wgrad_bf3.inc instead of gemm_bf3_wgrad_kernel (lab switch)
+WIDE_WGRAD_TR = os.environ.get("SPACAP_WIDE_WGRAD_TR", "1") != "0"
 
 
 class Conv1x1(Function):
