@@ -7,7 +7,7 @@
 // objectness thresholds are applied to sqrt(d + 1e-6) -- the integer outputs (objectness label, assignment) are
 // therefore the ones the PyTorch composition produces.
 //
-// Forward: det_proposal_kernel (one workgroup per scene) assigns proposals to ground-truth boxes and evaluates every
+// Forward: det_proposal_kernel (one workgroup of 1 024 threads per scene, four lanes per proposal) assigns proposals to ground-truth boxes and evaluates every
 // per-proposal loss term together with the UNNORMALISED gradient of that term; det_vote_kernel does the same for the
 // vote loss; det_finalize_kernel adds the per-scene partial sums (fixed order) into the eight losses and the inverse
 // denominators.  Backward: det_scale_kernel multiplies the stored gradient numerators by (upstream gradient x inverse
@@ -78,119 +78,191 @@ __device__ float block_sum(float v, float *s_red) {  // 256 threads, fixed order
   return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// STAGED: the scene's K x CH head outputs are copied into LDS with coalesced loads, every thread works on its own row
-// there (rows are CH floats apart: a per-thread walk over a row in global memory touches 64 cache lines per load
-// instruction), the gradient numerators overwrite the row in place and leave with coalesced stores.
+// 1 024 threads per scene, FOUR lanes per proposal (round 2 - 5: 256 threads, one per proposal, one wave per SIMD with nothing to
+// hide an LDS round trip behind: 49 us on 8 CUs in the middle of the step's critical path).  The three scans over the scene's
+// ground-truth boxes are split over the lanes (j = lane, lane + 4, ...) and joined by a lexicographic (distance, index) minimum --
+// the first minimum of the serial scan; the tail is split by loss term (lane 0 objectness + centre, 1 heading + size residuals,
+// 2 size class, 3 semantic class); the ground truth's nearest proposal (the other direction) takes eight lanes per box; per-box
+// labels, mean sizes and vote positions are staged in LDS (no dependent global load in the tail); the twelve partial sums meet at
+// ONE barrier.  38 us: the kernel is now bound by VALU issue on its one CU per scene (rocprofv3: 3 740 VALU instructions per wave,
+// 16 waves -- the four tail branches diverge inside a wave and the ~98 000 distance evaluations per scene are 11 us of issue by
+// themselves); more would take several workgroups per scene.
+// STAGED: the scene's K x CH head outputs are copied into LDS with coalesced loads, every lane group works on its own row there
+// (rows are CH floats apart: a walk over a row in global memory touches 64 cache lines per load instruction), the gradient
+// numerators overwrite the row in place and leave with coalesced stores.
+constexpr int DET_THREADS = 1024;
+
+// (d, i) <- the lexicographically smaller of (d, i) and the partner lane's pair: joined over a lane group this is the FIRST
+// minimum of the serial scan (NaN distances never win, as with `d < best`)
+__device__ __forceinline__ void lexmin_xor(float &d, int &i, int o) {
+  const float od = __shfl_xor(d, o);
+  const int oi = __shfl_xor(i, o);
+  if (od < d || (od == d && oi < i)) d = od, i = oi;
+}
+
 template <bool STAGED>
-__global__ __launch_bounds__(256) void det_proposal_kernel(const DetArgs A) {
+__global__ __launch_bounds__(DET_THREADS) void det_proposal_kernel(const DetArgs A) {
   extern __shared__ float smem[];
   float *s_gt = smem;                 // [M][3]
   float *s_c = s_gt + 3 * A.M;        // [K][3] predicted centres
   int *s_i2 = reinterpret_cast<int *>(s_c + 3 * A.K);  // [M] nearest proposal of every gt box
   float *s_w2 = reinterpret_cast<float *>(s_i2 + A.M); // [M] box mask
-  float *s_net = s_w2 + A.M;          // [K][CH] (STAGED only)
-  __shared__ float s_red[4];
+  // the per-box labels the tail reads through the assignment (dependent global loads otherwise: two L2 round trips per proposal)
+  int *s_hl = reinterpret_cast<int *>(s_w2 + A.M);      // [M] heading class
+  int *s_sl = s_hl + A.M;                               // [M] size class
+  int *s_se = s_sl + A.M;                               // [M] semantic class
+  float *s_hr = reinterpret_cast<float *>(s_se + A.M);  // [M] heading residual
+  float *s_sr = s_hr + A.M;                             // [M][3] size residual
+  float *s_ms = s_sr + 3 * A.M;                         // [NS][3] mean sizes
+  float *s_ag = s_ms + 3 * A.NS;                        // [K][3] aggregated vote positions
+  float *s_net = s_ag + 3 * A.K + ((4 - ((12 * A.M + 6 * A.K + 3 * A.NS) & 3)) & 3);   // [K][CH] (STAGED only), 16-byte aligned
+  __shared__ float s_red[16][NPARTL];
   const int b = blockIdx.x, tid = threadIdx.x, K = A.K, M = A.M, CH = A.CH;
-  if (STAGED)
-    for (int i = tid; i < K * CH; i += 256) s_net[i] = A.net[(size_t)b * K * CH + i];
-  for (int i = tid; i < 3 * M; i += 256) s_gt[i] = A.gt_center[(size_t)b * M * 3 + i];
-  for (int i = tid; i < 3 * K; i += 256) s_c[i] = A.center[(size_t)b * K * 3 + i];
-  for (int j = tid; j < M; j += 256) s_w2[j] = A.box_mask[(size_t)b * M + j];
+  if (STAGED) {
+    const float *src = A.net + (size_t)b * K * CH;
+    if ((((size_t)K * CH) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(s_net) & 15) == 0) {
+      for (int i = tid; i < K * CH / 4; i += DET_THREADS)
+        reinterpret_cast<float4 *>(s_net)[i] = reinterpret_cast<const float4 *>(src)[i];
+    } else {
+      for (int i = tid; i < K * CH; i += DET_THREADS) s_net[i] = src[i];
+    }
+  }
+  for (int i = tid; i < 3 * M; i += DET_THREADS) s_gt[i] = A.gt_center[(size_t)b * M * 3 + i];
+  for (int i = tid; i < 3 * K; i += DET_THREADS) s_c[i] = A.center[(size_t)b * K * 3 + i];
+  for (int i = tid; i < 3 * K; i += DET_THREADS) s_ag[i] = A.agg_xyz[(size_t)b * K * 3 + i];
+  for (int i = tid; i < 3 * M; i += DET_THREADS) s_sr[i] = A.size_res_label[(size_t)b * M * 3 + i];
+  for (int i = tid; i < 3 * A.NS; i += DET_THREADS) s_ms[i] = A.mean_size[i];
+  for (int j = tid; j < M; j += DET_THREADS) {
+    const size_t bj = (size_t)b * M + j;
+    s_w2[j] = A.box_mask[bj];
+    s_hl[j] = (int)A.heading_cls_label[bj], s_sl[j] = (int)A.size_cls_label[bj], s_se[j] = (int)A.sem_cls_label[bj];
+    s_hr[j] = A.heading_res_label[bj];
+  }
   __syncthreads();
-  // gt -> nearest predicted centre (dist2 / idx2 of nn_distance(center, gt_center))
+  // gt -> nearest predicted centre (dist2 / idx2 of nn_distance(center, gt_center)): 8 lanes per box
   float num_c2 = 0.f, n_box = 0.f;
-  for (int j = tid; j < M; j += 256) {
+  for (int j0 = 0; j0 < M; j0 += DET_THREADS / 8) {
+    const int j = j0 + (tid >> 3), l8 = tid & 7;
+    const bool vj = j < M;
+    const float *gj = s_gt + 3 * (vj ? j : M - 1);
     float best = INFINITY;
     int bi = 0;
-    for (int k = 0; k < K; ++k) {
-      const float d = sqdist(s_c[3 * k], s_c[3 * k + 1], s_c[3 * k + 2], s_gt + 3 * j);
+    for (int k = l8; k < K; k += 8) {
+      const float d = sqdist(s_c[3 * k], s_c[3 * k + 1], s_c[3 * k + 2], gj);
       if (d < best) best = d, bi = k;
     }
-    s_i2[j] = bi;
-    num_c2 += best * s_w2[j];
-    n_box += s_w2[j];
+    lexmin_xor(best, bi, 1); lexmin_xor(best, bi, 2); lexmin_xor(best, bi, 4);
+    if (vj && l8 == 0) {
+      s_i2[j] = bi;
+      num_c2 += best * s_w2[j];
+      n_box += s_w2[j];
+    }
   }
   __syncthreads();
   float n_obj = 0.f, n_mask = 0.f, num_obj = 0.f, num_c1 = 0.f, num_hc = 0.f, num_hr = 0.f, num_sc = 0.f, num_sr = 0.f,
         num_sem = 0.f;
   const int o_hs = 5, o_hr = 5 + A.NH, o_ss = 5 + 2 * A.NH, o_sr = o_ss + A.NS, o_sem = o_sr + 3 * A.NS;
-  for (int k = tid; k < K; k += 256) {
+  for (int k0 = 0; k0 < K; k0 += DET_THREADS / 4) {
+    const int k = min(k0 + (tid >> 2), K - 1), l4 = tid & 3;
+    const bool vk = k0 + (tid >> 2) < K;
     const size_t bk = (size_t)b * K + k;
-    const float *ag = A.agg_xyz + bk * 3;
     // objectness label from the aggregated vote position (lib/loss_helper.py:117-133)
+    const float ax = s_ag[3 * k], ay = s_ag[3 * k + 1], az = s_ag[3 * k + 2];
     float d1 = INFINITY;
     int i1 = 0;
-    for (int j = 0; j < M; ++j) {
-      const float d = sqdist(ag[0], ag[1], ag[2], s_gt + 3 * j);
+    for (int j = l4; j < M; j += 4) {
+      const float d = sqdist(ax, ay, az, s_gt + 3 * j);
       if (d < d1) d1 = d, i1 = j;
     }
+    lexmin_xor(d1, i1, 1); lexmin_xor(d1, i1, 2);
     const float eu = sqrtf(d1 + 1e-6f);
     const int label = eu < A.near_thr ? 1 : 0;
     const float mask = (label || eu > A.far_thr) ? 1.f : 0.f, obj = (float)label;
-    A.obj_label[bk] = label;
-    A.obj_mask[bk] = mask;
-    A.assignment[bk] = i1;
-    n_obj += obj;
-    n_mask += mask;
-    const float *row = STAGED ? s_net + (size_t)k * CH : A.net + bk * CH;
-    float *g = STAGED ? s_net + (size_t)k * CH : A.dnet + bk * CH;
-    // objectness: weighted 2-class cross-entropy
-    num_obj += ce_grad(row, 2, label, (label ? A.w1 : A.w0) * mask, g) * (label ? A.w1 : A.w0) * mask;
-    g[2] = g[3] = g[4] = 0.f;  // centre offsets: their gradient arrives through `center`
     // centre: pred -> nearest gt, weighted by objectness
     const float cx = s_c[3 * k], cy = s_c[3 * k + 1], cz = s_c[3 * k + 2];
     float dc = INFINITY;
     int ic = 0;
-    for (int j = 0; j < M; ++j) {
+    for (int j = l4; j < M; j += 4) {
       const float d = sqdist(cx, cy, cz, s_gt + 3 * j);
       if (d < dc) dc = d, ic = j;
     }
-    num_c1 += dc * obj;
-    float *dcn = A.dcenter + bk * 6;
-    dcn[0] = 2.f * (cx - s_gt[3 * ic]) * obj;
-    dcn[1] = 2.f * (cy - s_gt[3 * ic + 1]) * obj;
-    dcn[2] = 2.f * (cz - s_gt[3 * ic + 2]) * obj;
-    float gx = 0.f, gy = 0.f, gz = 0.f;  // gt -> pred term: every gt box whose nearest proposal is k, ascending j
-    for (int j = 0; j < M; ++j)
+    lexmin_xor(dc, ic, 1); lexmin_xor(dc, ic, 2);
+    float gx = 0.f, gy = 0.f, gz = 0.f;  // gt -> pred term: every gt box whose nearest proposal is k
+    for (int j = l4; j < M; j += 4)
       if (s_i2[j] == k) {
         gx += 2.f * (cx - s_gt[3 * j]) * s_w2[j];
         gy += 2.f * (cy - s_gt[3 * j + 1]) * s_w2[j];
         gz += 2.f * (cz - s_gt[3 * j + 2]) * s_w2[j];
       }
-    dcn[3] = gx, dcn[4] = gy, dcn[5] = gz;
-    // heading
-    const size_t bj = (size_t)b * M + i1;
-    const int hl = (int)A.heading_cls_label[bj];
-    num_hc += ce_grad(row + o_hs, A.NH, hl, obj, g + o_hs) * obj;
-    float hg;
-    const float hv = huber1(row[o_hr + hl] - A.heading_res_label[bj] / A.heading_scale, hg);
-    num_hr += hv * obj;
-    for (int c = 0; c < A.NH; ++c) g[o_hr + c] = c == hl ? hg * obj : 0.f;
-    // size
-    const int sl = (int)A.size_cls_label[bj];
-    num_sc += ce_grad(row + o_ss, A.NS, sl, obj, g + o_ss) * obj;
-    float sr = 0.f;
-    const float res[3] = {row[o_sr + 3 * sl], row[o_sr + 3 * sl + 1], row[o_sr + 3 * sl + 2]};   // (g may alias row)
-    for (int c = 0; c < 3 * A.NS; ++c) g[o_sr + c] = 0.f;
-    for (int d = 0; d < 3; ++d) {
-      float sg;
-      sr += huber1(res[d] - A.size_res_label[bj * 3 + d] / A.mean_size[3 * sl + d], sg);
-      g[o_sr + 3 * sl + d] = sg * obj / 3.0f;
+    gx += __shfl_xor(gx, 1); gy += __shfl_xor(gy, 1); gz += __shfl_xor(gz, 1);
+    gx += __shfl_xor(gx, 2); gy += __shfl_xor(gy, 2); gz += __shfl_xor(gz, 2);
+    if (!vk) continue;   // (after the lane-group exchanges)
+    const float *row = STAGED ? s_net + (size_t)k * CH : A.net + bk * CH;
+    float *g = STAGED ? s_net + (size_t)k * CH : A.dnet + bk * CH;
+    if (l4 == 0) {
+      A.obj_label[bk] = label;
+      A.obj_mask[bk] = mask;
+      A.assignment[bk] = i1;
+      n_obj += obj;
+      n_mask += mask;
+      // objectness: weighted 2-class cross-entropy
+      num_obj += ce_grad(row, 2, label, (label ? A.w1 : A.w0) * mask, g) * (label ? A.w1 : A.w0) * mask;
+      g[2] = g[3] = g[4] = 0.f;  // centre offsets: their gradient arrives through `center`
+      num_c1 += dc * obj;
+      float *dcn = A.dcenter + bk * 6;
+      dcn[0] = 2.f * (cx - s_gt[3 * ic]) * obj;
+      dcn[1] = 2.f * (cy - s_gt[3 * ic + 1]) * obj;
+      dcn[2] = 2.f * (cz - s_gt[3 * ic + 2]) * obj;
+      dcn[3] = gx, dcn[4] = gy, dcn[5] = gz;
+    } else if (l4 == 1) {
+      // heading
+      const int hl = s_hl[i1];
+      float hg;
+      const float hv = huber1(row[o_hr + hl] - s_hr[i1] / A.heading_scale, hg);   // (g may alias row: read first)
+      num_hc += ce_grad(row + o_hs, A.NH, hl, obj, g + o_hs) * obj;
+      num_hr += hv * obj;
+      for (int c = 0; c < A.NH; ++c) g[o_hr + c] = c == hl ? hg * obj : 0.f;
+      // size residuals
+      const int sl = s_sl[i1];
+      float sr = 0.f;
+      const float res[3] = {row[o_sr + 3 * sl], row[o_sr + 3 * sl + 1], row[o_sr + 3 * sl + 2]};   // (g may alias row)
+      for (int c = 0; c < 3 * A.NS; ++c) g[o_sr + c] = 0.f;
+      for (int d = 0; d < 3; ++d) {
+        float sg;
+        sr += huber1(res[d] - s_sr[3 * i1 + d] / s_ms[3 * sl + d], sg);
+        g[o_sr + 3 * sl + d] = sg * obj / 3.0f;
+      }
+      num_sr += sr / 3.0f * obj;
+    } else if (l4 == 2) {
+      // size class
+      num_sc += ce_grad(row + o_ss, A.NS, s_sl[i1], obj, g + o_ss) * obj;
+    } else {
+      // semantic class
+      num_sem += ce_grad(row + o_sem, A.NC, s_se[i1], obj, g + o_sem) * obj;
     }
-    num_sr += sr / 3.0f * obj;
-    // semantic class
-    num_sem += ce_grad(row + o_sem, A.NC, (int)A.sem_cls_label[bj], obj, g + o_sem) * obj;
   }
-  if (STAGED) {
-    __syncthreads();
-    for (int i = tid; i < K * CH; i += 256) A.dnet[(size_t)b * K * CH + i] = s_net[i];
-  }
-  float *p = A.part + (size_t)b * NPARTL;
+  // the twelve partial sums of the scene: per wave by shuffles, the 16 waves' rows through LDS, one barrier, added in wave order
   const float v[NPARTL] = {0.f, num_obj, num_c1, num_c2, num_hc, num_hr, num_sc, num_sr, num_sem, n_obj, n_mask, n_box};
 #pragma unroll
   for (int i = 1; i < NPARTL; ++i) {
-    const float s = block_sum(v[i], s_red);
-    if (tid == 0) p[i] = s;
+    const float w = spacap::wave_sum_f32(v[i]);
+    if ((tid & 63) == 0) s_red[tid >> 6][i] = w;
+  }
+  __syncthreads();   // (also: every row of s_net holds its gradient numerators)
+  if (STAGED) {
+    float *dst = A.dnet + (size_t)b * K * CH;
+    if ((((size_t)K * CH) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(s_net) & 15) == 0) {
+      for (int i = tid; i < K * CH / 4; i += DET_THREADS)
+        reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(s_net)[i];
+    } else {
+      for (int i = tid; i < K * CH; i += DET_THREADS) dst[i] = s_net[i];
+    }
+  }
+  if (tid >= 1 && tid < NPARTL) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) a += s_red[w][tid];
+    A.part[(size_t)b * NPARTL + tid] = a;
   }
 }
 
@@ -410,15 +482,16 @@ extern "C" int spacap_det_losses_fwd_f32(
   A.obj_label = obj_label; A.assignment = assignment; A.obj_mask = obj_mask; A.dnet = dnet_num; A.dcenter = dcenter_num;
   A.part = part;
   hipStream_t s = spacap::as_stream(stream);
-  const size_t lds = sizeof(float) * (3 * (size_t)M + 3 * (size_t)K + 2 * (size_t)M);
+  // [M][3] gt | [K][3] centres | [M] nearest | [M] mask | 3 x [M] class labels | [M] + [M][3] residual labels | [NS][3] | [K][3] (+ pad)
+  const size_t lds = sizeof(float) * (12 * (size_t)M + 6 * (size_t)K + 3 * (size_t)NS + 4);
   SPACAP_REQUIRE(lds <= 60000, "%s: K=%d too large", what, K);
   const size_t lds_staged = lds + sizeof(float) * (size_t)K * A.CH;
   if (lds_staged <= 150 * 1024) {
     static unsigned long long lds_ok = 0;
     SPACAP_CHECK_HIP(spacap::allow_dynamic_lds(reinterpret_cast<const void *>(&det_proposal_kernel<true>), 150 * 1024, lds_ok), what);
-    hipLaunchKernelGGL(det_proposal_kernel<true>, dim3(B), dim3(256), lds_staged, s, A);
+    hipLaunchKernelGGL(det_proposal_kernel<true>, dim3(B), dim3(DET_THREADS), lds_staged, s, A);
   } else {
-    hipLaunchKernelGGL(det_proposal_kernel<false>, dim3(B), dim3(256), lds, s, A);
+    hipLaunchKernelGGL(det_proposal_kernel<false>, dim3(B), dim3(DET_THREADS), lds, s, A);
   }
   float *vpart = part + (size_t)B * NPARTL;
   hipLaunchKernelGGL(det_vote_kernel, dim3(B), dim3(256), 0, s, seed_xyz, vote_xyz, seed_inds, vote_label, vote_mask, NSEED, N,
