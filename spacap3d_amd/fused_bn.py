@@ -4,6 +4,8 @@ Counterpart of the tail of every ``SharedMLP`` layer of the reference (lib/point
 ``Conv2d(1x1) -> BatchNorm2d -> ReLU(inplace)``) and of the pooling that follows the last one
 (lib/pointnet2/pointnet2_modules.py:256-259).  See ``csrc/bn_relu.hip`` for the pass structure.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -114,9 +116,12 @@ def bn_relu_train(z, bn, pool_S=None):
 
 # ---- inference: relu(batch_norm(z)) on the running statistics, one launch of the library's apply kernel ------------------------
 # (the stock modules run MIOpen's BatchNorm inference kernel + a ReLU: two launches per layer and the last library kernel of the
-# inference forward).  The kernel takes (mean, 1 / sqrt(var + eps)) per channel: folded once per state of the module's buffers
-# (tensor version counters: a training step's in-place update of the running statistics, load_state_dict or .to() make a new fold).
-_EVAL_FOLD = {}
+# inference forward).  The kernel takes (mean, 1 / sqrt(var + eps)) per channel: folded once per state of the module's buffers.
+# The fold is kept per MODULE OBJECT (weakly) and is valid for the buffer OBJECTS it was made from at the versions they had: a
+# training step's in-place update, load_state_dict (in-place copies) or .to() (new tensors) make a new fold.  Addresses, ids and
+# version numbers alone are not identities -- a later module of the same shape reuses all three (seen: a stale fold handed to the
+# next parametrisation of a test).
+_EVAL_FOLD = weakref.WeakKeyDictionary()    # module -> (weak refs to the two buffers, their versions, eps, device, folded stats)
 
 
 def bn_relu_eval(z, bn):
@@ -126,16 +131,13 @@ def bn_relu_eval(z, bn):
             and bn.running_mean is not None and bn.affine and z.dim() >= 2 and z.shape[1] == bn.num_features and z.numel() > 0):
         return None
     rm, rv = bn.running_mean, bn.running_var
-    key = (rm.data_ptr(), rv.data_ptr(), rm._version, rv._version, float(bn.eps), str(z.device))
-    ent = _EVAL_FOLD.get(id(bn))
-    if ent is None or ent[0] != key:
+    ent = _EVAL_FOLD.get(bn)
+    # valid for THESE tensor objects at THESE versions (addresses and ids are reused by later modules: not identities)
+    if ent is None or ent[0]() is not rm or ent[1]() is not rv or ent[2] != (rm._version, rv._version, float(bn.eps), z.device):
         with torch.cuda.device(z.device):
             stats = torch.stack([rm.float(), torch.rsqrt(rv.float() + bn.eps)], 1).contiguous()
-        ent = _EVAL_FOLD[id(bn)] = (key, stats)
-        if len(_EVAL_FOLD) > 4096:    # (modules come and go in long-lived processes: ids are reused, entries are tiny)
-            _EVAL_FOLD.clear()
-            _EVAL_FOLD[id(bn)] = ent
-    stats = ent[1]
+        ent = _EVAL_FOLD[bn] = (weakref.ref(rm), weakref.ref(rv), (rm._version, rv._version, float(bn.eps), z.device), stats)
+    stats = ent[3]
     z = z.contiguous()
     B, C = z.shape[0], z.shape[1]
     L = z.numel() // (B * C)

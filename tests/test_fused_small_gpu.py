@@ -239,3 +239,23 @@ def test_inference_batchnorm_relu_on_the_running_statistics(shape):
         assert float((got2 - want2).abs().max()) < 2e-6 * max(1.0, float(want2.abs().max())) and not got2.equal(got)
         bn.train()
         assert bn_relu_eval(z, bn) is None
+
+
+def test_inference_batchnorm_fold_is_not_shared_between_modules_that_reuse_memory():
+    """Modules created and dropped one after the other reuse ids, buffer addresses and version numbers: every one must get the
+    fold of ITS running statistics."""
+    import gc
+    from spacap3d_amd.fused_bn import bn_relu_eval
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(4, 64, 128, generator=g).to(DEV)
+    for i in range(6):
+        bn = torch.nn.BatchNorm1d(64).to(DEV)
+        with torch.no_grad():
+            bn.running_mean.copy_(torch.full((64,), 0.1 * i))      # same history (one in-place copy each), different values
+            bn.running_var.copy_(torch.full((64,), 0.5 + 0.2 * i))
+        bn.eval()
+        with torch.no_grad():
+            got, want = bn_relu_eval(z, bn), torch.relu(bn(z))
+        assert float((got - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max())), i
+        del bn
+        gc.collect()
