@@ -187,7 +187,10 @@ class Trainer:
             # round 6 and never fired: the consumers take the point-major tensor behind it.  Registered on that tensor it fires and
             # costs 0.75 ms beside the sampling chain (7.13 -> 7.85 ms same box; without the chain 6.76 = 6.76): the SA modules'
             # persistent backward kernels are sized for the CUs the chain leaves, a third party on the chip sends their last
-            # workgroups into a second round.  Not registered.)
+            # workgroups into a second round.  Not registered.  A flush of the proposal / vote nets' convolution weight gradients beside
+            # the feature-propagation modules' backward, JOINED before SA4's backward starts, costs 1.05 ms with the chain beside
+            # the step and 0.08 ms without: 0.38 ms with GPU_MAX_HW_QUEUES=8 or 16 and 6 ms with 6 -- the step's graph, its forked
+            # branches and the pyramid's graph share the runtime's four hardware queues, and where a further branch lands decides.)
         return d
 
     # -- the captioner's weight gradients beside the detector's backward --------------------------------------------------
