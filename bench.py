@@ -43,6 +43,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+# Hardware queues of the HIP runtime (read when the runtime starts: before torch is imported; inherited by the rank / sub-record
+# processes).  The captured step, its two forked branches and the next batch's sampling graph run on internal streams that the
+# runtime maps onto this many queues; two of them on one queue serialise.  Measured on one box: 3 -> 9.77 ms
+# per step, 4 (the runtime's default) -> 6.81, 5 -> 9.78, 6 .. 24 -> 6.79 - 6.83.  Eight is inside the flat region instead of
+# between the two cliffs; an explicit setting of the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start N fresh rank processes --
